@@ -1,0 +1,151 @@
+/* simclr_hip.h -- C ABI of libsimclr_hip.so: the MI355X (gfx950) SimCLR pretraining hot path.
+ *
+ * The reference (google-research/simclr, tf2/) has no native/FFI boundary: the hot path sits
+ * behind Python callables that hand everything to TensorFlow ops.  This header is the boundary a
+ * maintainer binds instead (ctypes stub in INTEGRATION.md); every entry point names the reference
+ * lines whose arithmetic it replaces.  Paths are relative to /root/reference/.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / framework types.
+ *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise; the library
+ *     never allocates, frees or synchronises; work is enqueued on `stream` (a hipStream_t).
+ *   - returns 0 on success; nonzero = error (1 bad argument, 2 launch failure) with a message in
+ *     simclr_last_error() (thread-local).  Re-entrant across streams.
+ *   - `dtype`: SIMCLR_DT_F32 (0) or SIMCLR_DT_BF16 (1) = storage type of activations / compute
+ *     weights ("T" below).  Accumulation, statistics, losses and optimizer state are fp32/fp64.
+ *   - layouts: activations NHWC, master conv weights HWIO fp32, dense weights [in,out] fp32
+ *     (tf2/resnet.py:196-203, tf2/model.py:143-146).
+ */
+#ifndef SIMCLR_HIP_H_
+#define SIMCLR_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMCLR_DT_F32 0
+#define SIMCLR_DT_BF16 1
+
+typedef struct ihipStream_t* simclr_stream_t; /* == hipStream_t */
+
+/* ---- runtime ---------------------------------------------------------------------------------- */
+const char* simclr_last_error(void);
+int simclr_abi_version(void);
+/* lane-layout probes used by the GPU tests (0 mfma bf16 16x16x32, 1 mfma f32 16x16x4, 2 ds_read_tr16) */
+int simclr_probe(int which, const void* a, const void* b, void* out, simclr_stream_t stream);
+
+/* ---- NT-Xent contrastive loss: tf2/objective.py:35-89 (add_contrastive_loss) ------------------ */
+/* tf.math.l2_normalize, objective.py:53-54.  z = x*rsqrt(max(sum x^2,1e-12)); inv[row] kept for bwd. */
+int simclr_l2norm_fwd(const float* x, float* z, float* inv, int rows, int D, simclr_stream_t stream);
+int simclr_l2norm_bwd(const float* z, const float* inv, const float* dz, float* dx, int rows, int D,
+                      simclr_stream_t stream);
+size_t simclr_ntxent_workspace_bytes(int n, int N, int D);
+/* objective.py:55-87 + metrics.py:28-31.  z_local [2n,D] = [hidden1;hidden2] of this replica,
+ * z_all [2N,D] = [hidden1_large;hidden2_large] (objective.py:60-61), N = R*n, rank = replica id
+ * (objective.py:64-67).  out[0] = loss, out[1] = contrast_acc.  row_stats [2n,2] feeds the bwd. */
+int simclr_ntxent_fwd(const float* z_local, const float* z_all, int n, int N, int D, int rank,
+                      float temperature, float* out, float* row_stats, void* workspace,
+                      simclr_stream_t stream);
+/* What tape.gradient (tf2/run.py:621) derives for objective.py:76-87.  dz_local [2n,D]: gradient
+ * through the local (query) rows; dz_all [2N,D]: gradient through the gathered rows, to be
+ * reduce-scattered (SUM) across replicas = transpose of objective.py:114-122.  grad_scale = the
+ * upstream factor (1/R, tf2/run.py:617).  out[2] = contrast_entropy (metrics.py:33-35). */
+int simclr_ntxent_bwd(const float* z_local, const float* z_all, int n, int N, int D, int rank,
+                      float temperature, const float* row_stats, float grad_scale, float* dz_local,
+                      float* dz_all, float* out, void* workspace, simclr_stream_t stream);
+/* dense logits_ab [n,N] (objective.py:80,89) for API parity only; not on the hot path. */
+int simclr_ntxent_logits_ab(const float* z_local, const float* z_all, int n, int N, int D,
+                            float temperature, float* logits_ab, simclr_stream_t stream);
+
+/* ---- LARS: tf2/lars_optimizer.py:83-137 (_resource_apply_dense), all tensors in 2 launches ---- */
+/* table: device int64[5*T] = {w ptrs | g ptrs | v ptrs | numel | flags(bit0 use_weight_decay :139-148,
+ * bit1 do_layer_adaptation :150-157)}; chunks: device int64[2*num_chunks] = (tensor id, element
+ * offset), one per simclr_lars_chunk_elems() elements; norms: device double[2*T] scratch.
+ * lr_dev (nullable) overrides lr with a device-resident value (graph replay). */
+int simclr_lars_chunk_elems(void);
+int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long long* chunks,
+                             int num_chunks, const float* lr_dev, float lr, float momentum,
+                             float weight_decay, float eeta, int classic_momentum, int use_nesterov,
+                             double* norms, simclr_stream_t stream);
+
+/* ---- convolution / dense: tf2/resnet.py:183-208 (Conv2dFixedPadding), tf2/model.py:143-154 ----- */
+/* master HWIO fp32 -> compute copies.  mode 0: [Cout][KH*KW*Cin] (fwd), 1: [Cin][KH*KW*Cout]
+ * (dgrad), 2: stem [Cout][KHP][KWP][4] zero padded. */
+int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,
+                        int KHP, int KWP, int dtype, simclr_stream_t stream);
+/* y[V,OH,OW,Cout] = conv(x[V,IH,IW,Cin], w), explicit symmetric padding `pad` (resnet.py:167-180).
+ * stats (nullable) float[nslot][2][Cout], zeroed by caller: per-channel partial (sum, sum sq) of y
+ * for BatchNorm (resnet.py:50-78).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0. */
+int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V, int IH,
+                      int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
+                      int dtype, simclr_stream_t stream);
+/* dx[V,IH,IW,Cin] (+)= conv_transpose(dy[V,OH,OW,Cout], w); autodiff of the above (run.py:621). */
+int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulate, int V, int IH, int IW,
+                        int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,
+                        simclr_stream_t stream);
+size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int Cout, int KH, int KW,
+                                           int dtype);
+/* dw[KH*KW*Cin][Cout] fp32 (HWIO) (+)= x^T * dy.  `pixpitch` = elements between neighbouring pixels
+ * of x (== Cin except for the packed stem input). */
+int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace, int V,
+                        int IH, int IW, int Cin, int pixpitch, int OH, int OW, int Cout, int KH, int KW,
+                        int stride, int pad, int dtype, simclr_stream_t stream);
+/* stem conv (Cin=3; resnet.py:593-599 7x7 s2, :551-556 CIFAR 3x3 s1) on the packed input */
+int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats, int nslot, int V, int HP,
+                         int WP, int OH, int OW, int Cout, int KHP, int KWP, int stride, int dtype,
+                         simclr_stream_t stream);
+int simclr_unpack_stem_dw(const float* src, float* dst, int KH, int KW, int Cin, int Cout, int KWP,
+                          int accumulate, simclr_stream_t stream);
+
+/* ---- BatchNorm: tf2/resnet.py:31-78 (BatchNormRelu), residual tail :382/:487 ------------------- */
+int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, simclr_stream_t stream);
+int simclr_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+                       float* moving_mean, float* moving_var, float decay, float eps, float* mean,
+                       float* rstd, float* scale, float* shift, simclr_stream_t stream);
+int simclr_bn_apply(const void* x, const float* scale, const float* shift, const void* res,
+                    const float* rscale, const float* rshift, void* y, long long rows, int C, int relu,
+                    int dtype, simclr_stream_t stream);
+/* mask_mode: 0 none, 1 (mask_src > 0), 2 (x*scale+shift > 0)  -- the ReLU gradient */
+int simclr_bn_bwd_reduce(const void* dy, const void* x, const void* mask_src, const float* scale,
+                         const float* shift, const float* mean, const float* rstd, long long rows, int C,
+                         int mask_mode, float* partial, int nslot, int dtype, simclr_stream_t stream);
+int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, double count, int C,
+                           float* dgamma, float* dbeta, int accumulate, float* c1, float* c2,
+                           simclr_stream_t stream);
+int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, const float* c1,
+                        const float* c2, long long rows, int C, int mask_mode, void* dx, void* dmasked,
+                        int dtype, simclr_stream_t stream);
+
+/* ---- view packing / pooling: tf2/model.py:250-259, tf2/resnet.py:602-611, :693-696 ------------- */
+int simclr_pack_views(const float* images, void* xp, int b, int H, int W, int k, int HP, int WP, int pad,
+                      int dtype, simclr_stream_t stream);
+int simclr_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y,
+                              unsigned char* arg, int V, int H, int W, int C, int OH, int OW, int ksz,
+                              int stride, int pad_t, int pad_l, int dtype, simclr_stream_t stream);
+int simclr_maxpool_bwd(const void* dy, const unsigned char* arg, void* dx, int V, int H, int W, int C,
+                       int OH, int OW, int ksz, int stride, int pad_t, int pad_l, int dtype,
+                       simclr_stream_t stream);
+int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int dtype,
+                              simclr_stream_t stream);
+int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, int V, int HW, int C,
+                              int dtype, simclr_stream_t stream);
+
+/* ---- supervised (linear-eval) head tail: tf2/objective.py:27-32, tf2/metrics.py:49-55 ---------- */
+int simclr_bias_softmax_xent(const void* z, const float* bias, const int* labels, int rows,
+                             int label_rows, int nclass, int cpad, float gscale, void* dlogits,
+                             float* out, int dtype, simclr_stream_t stream);
+int simclr_colsum(const void* x, int rows, int C, int cvalid, float* out, int accumulate, int dtype,
+                  simclr_stream_t stream);
+
+/* ---- small helpers ------------------------------------------------------------------------------ */
+int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out, simclr_stream_t stream);
+int simclr_axpy_f32(float a, const float* x, float* y, long long n, simclr_stream_t stream);
+int simclr_l2_loss_f32(const float* x, long long n, float* out, simclr_stream_t stream); /* tf.nn.l2_loss, model.py:49-60 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMCLR_HIP_H_ */

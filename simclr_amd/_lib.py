@@ -1,0 +1,103 @@
+"""ctypes binding of libsimclr_hip.so (the C ABI declared in include/simclr_hip.h).
+
+The signatures are generated from the header itself, so the header is the single
+source of truth.  There is NO fallback: if the library is missing or a symbol is
+absent, importing/calling fails loudly (the product path never routes around the
+HIP kernels).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsimclr_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'simclr_hip.h')
+
+DT_F32 = 0
+DT_BF16 = 1
+
+_SCALARS = {
+    'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double,
+    'long long': ctypes.c_longlong, 'size_t': ctypes.c_size_t,
+    'simclr_stream_t': ctypes.c_void_p,
+}
+
+
+def _ctype(decl):
+    decl = decl.strip()
+    if '*' in decl:
+        return ctypes.c_void_p
+    decl = re.sub(r'\bconst\b', '', decl).strip()
+    # drop the parameter name
+    for key in sorted(_SCALARS, key=len, reverse=True):
+        if decl == key or decl.startswith(key + ' '):
+            return _SCALARS[key]
+    raise ValueError('unknown C type in header: %r' % decl)
+
+
+def parse_header(path=HEADER_PATH):
+    """Return {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'^\s*#.*$', '', src, flags=re.M)
+    out = {}
+    for m in re.finditer(r'([A-Za-z_][\w\s\*]*?)\b(simclr_\w+)\s*\(([^;{}]*?)\)\s*;', src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith('typedef'):
+            continue
+        if '*' in ret:
+            restype = ctypes.c_char_p if 'char' in ret else ctypes.c_void_p
+        else:
+            restype = _ctype(ret)
+        argtypes = [] if args in ('', 'void') else [_ctype(a) for a in args.split(',')]
+        out[name] = (restype, argtypes)
+    return out
+
+
+class SimclrHipError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise SimclrHipError(
+                'libsimclr_hip.so not found at %s -- build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or simclr_amd/csrc/build.sh. '
+                'There is no CPU fallback.' % LIB_PATH)
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self.signatures = parse_header()
+        for name, (restype, argtypes) in self.signatures.items():
+            fn = getattr(self._dll, name)   # AttributeError if the symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        self._int_fns = {n for n, (r, _) in self.signatures.items() if r is ctypes.c_int}
+        self._no_check = {'simclr_abi_version', 'simclr_lars_chunk_elems'}
+
+    def last_error(self):
+        return self._dll.simclr_last_error().decode()
+
+    def __getattr__(self, name):
+        full = name if name.startswith('simclr_') else 'simclr_' + name
+        fn = getattr(self._dll, full)
+        if full in self._int_fns and full not in self._no_check:
+            def checked(*args, _fn=fn, _full=full):
+                rc = _fn(*args)
+                if rc != 0:
+                    raise SimclrHipError('%s failed (rc=%d): %s' % (_full, rc, self.last_error()))
+                return rc
+            setattr(self, name, checked)
+            return checked
+        setattr(self, name, fn)
+        return fn
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use)."""
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

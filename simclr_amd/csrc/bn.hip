@@ -1,0 +1,284 @@
+// BatchNorm (training mode, optionally cross-replica) for gfx950: statistics
+// finalisation, fused apply (+ReLU, +residual add), and the two-phase backward.
+//
+// Restates /root/reference/tf2/resnet.py:31-78 (BatchNormRelu over Keras
+// [Sync]BatchNormalization: batch mean and BIASED variance over every axis but
+// channels, eps 1e-5 (:28), moving <- moving*decay + batch*(1-decay)) and the
+// residual tail `relu(inputs + shortcut)` of :382/:487.  The backward is what
+// `tape.gradient` (tf2/run.py:621) derives:
+//   x^ = (x-mean)*rstd,  dbeta = sum dy,  dgamma = sum dy*x^,
+//   dx = gamma*rstd*(dy - mean(dy) - x^*mean(dy*x^))          (means over the GLOBAL batch)
+// All tensors are NHWC with channels contiguous; every kernel moves 16-byte chunks
+// (8 bf16 / 4 f32 channels per lane).  Statistics are fp32/fp64 regardless of T.
+//
+// Cross-replica (global_bn, resnet.py:50-60): the per-channel sums produced here are
+// all-reduced by the host (RCCL) between the *_reduce and *_finalize entry points.
+#include "common.h"
+
+namespace {
+
+// sums[2][C] (double) = sum over slots of partial[slot][2][C] (float)
+__global__ void bn_reduce_slots(const float* __restrict__ partial, int nslot, int C,
+                                double* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  double a = 0.0;
+  for (int s = 0; s < nslot; ++s) a += (double)partial[(long long)s * 2 * C + i];
+  sums[i] = a;
+}
+
+// From global sums -> mean/rstd/scale/shift, moving-stat update.
+__global__ void bn_finalize(const double* __restrict__ sums, double count, int C,
+                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                            float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                            float decay, float eps, float* __restrict__ mean_out,
+                            float* __restrict__ rstd_out, float* __restrict__ scale,
+                            float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;  // biased variance (Keras non-fused BN)
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f;
+  const float b = beta ? beta[c] : 0.f;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  scale[c] = g * rstd;
+  shift[c] = b - (float)mean * g * rstd;
+  if (moving_mean) moving_mean[c] = moving_mean[c] * decay + (float)mean * (1.f - decay);
+  if (moving_var) moving_var[c] = moving_var[c] * decay + (float)var * (1.f - decay);
+}
+
+// y = act(x*scale + shift [+ r] [+ r*rscale + rshift])
+template <typename T>
+__global__ void bn_apply(const T* __restrict__ x, const float* __restrict__ scale,
+                         const float* __restrict__ shift, const T* __restrict__ res,
+                         const float* __restrict__ rscale, const float* __restrict__ rshift,
+                         T* __restrict__ y, long long nchunks, int C, int relu) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cpr) * EPC;
+    float v[EPC], r[EPC];
+    chunk_to_f32<T>(*(const u32x4*)(x + i * EPC), v);
+    if (res) chunk_to_f32<T>(*(const u32x4*)(res + i * EPC), r);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float o = fmaf(v[e], scale[c0 + e], shift[c0 + e]);
+      if (res) o += rscale ? fmaf(r[e], rscale[c0 + e], rshift[c0 + e]) : r[e];
+      v[e] = relu ? fmaxf(o, 0.f) : o;
+    }
+    *(u32x4*)(y + i * EPC) = f32_to_chunk<T>(v);
+  }
+}
+
+// mask modes for the backward: 0 none, 1 mask_src > 0, 2 recompute x*scale+shift > 0
+template <typename T>
+__device__ __forceinline__ void masked_dy(const T* dy, const T* x, const T* mask_src,
+                                          const float* scale, const float* shift, long long i, int c0,
+                                          int mask_mode, float* d, float* xv) {
+  constexpr int EPC = Elem<T>::EPC;
+  chunk_to_f32<T>(*(const u32x4*)(dy + i * EPC), d);
+  chunk_to_f32<T>(*(const u32x4*)(x + i * EPC), xv);
+  if (mask_mode == 1) {
+    float mk[EPC];
+    chunk_to_f32<T>(*(const u32x4*)(mask_src + i * EPC), mk);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) d[e] = mk[e] > 0.f ? d[e] : 0.f;
+  } else if (mask_mode == 2) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) d[e] = fmaf(xv[e], scale[c0 + e], shift[c0 + e]) > 0.f ? d[e] : 0.f;
+  }
+}
+
+// partial[slot][2][C] += (sum dy_masked, sum dy_masked * x^) over this block's rows
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mask_src,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, long long rows, int C,
+    int mask_mode, int rows_per_block, float* __restrict__ partial, int nslot) {
+  constexpr int EPC = Elem<T>::EPC;
+  __shared__ float red[256 * 2 * EPC];
+  const int cpr = C / EPC;
+  const int cw = min(cpr, 256);
+  const int rl = 256 / cw;              // row lanes
+  const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(rows, r0 + rows_per_block);
+  float* slot = partial + (long long)(blockIdx.x % nslot) * 2 * C;
+  for (int cc0 = 0; cc0 < cpr; cc0 += cw) {
+    const int cc = cc0 + tcol;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (cc < cpr && trow < rl) {
+      const int c0 = cc * EPC;
+      float mu[EPC], rs[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; }
+      for (long long r = r0 + trow; r < r1; r += rl) {
+        float d[EPC], xv[EPC];
+        masked_dy<T>(dy, x, mask_src, scale, shift, r * cpr + cc, c0, mask_mode, d, xv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { s1[e] += d[e]; s2[e] += d[e] * (xv[e] - mu[e]) * rs[e]; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      red[(threadIdx.x * EPC + e) * 2] = s1[e];
+      red[(threadIdx.x * EPC + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    if (trow == 0 && cc < cpr) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < rl; ++q) {
+          a += red[((q * cw + tcol) * EPC + e) * 2];
+          b += red[((q * cw + tcol) * EPC + e) * 2 + 1];
+        }
+        atomicAdd(slot + cc * EPC + e, a);
+        atomicAdd(slot + C + cc * EPC + e, b);
+      }
+    }
+  }
+}
+
+// local sums -> dgamma/dbeta (+=), global sums/count -> c1 = mean(dy), c2 = mean(dy*x^)
+__global__ void bn_bwd_finalize(const double* __restrict__ local_sums,
+                                const double* __restrict__ global_sums, double count, int C,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                float* __restrict__ c1, float* __restrict__ c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)local_sums[c];
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)local_sums[C + c];
+  c1[c] = (float)(global_sums[c] / count);
+  c2[c] = (float)(global_sums[C + c] / count);
+}
+
+// dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]
+template <typename T>
+__global__ void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
+                             const T* __restrict__ mask_src, const float* __restrict__ scale,
+                             const float* __restrict__ shift, const float* __restrict__ mean,
+                             const float* __restrict__ rstd, const float* __restrict__ c1,
+                             const float* __restrict__ c2, long long nchunks, int C, int mask_mode,
+                             T* __restrict__ dx, T* __restrict__ dmasked) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cpr) * EPC;
+    float d[EPC], xv[EPC], o[EPC];
+    masked_dy<T>(dy, x, mask_src, scale, shift, i, c0, mask_mode, d, xv);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float xh = (xv[e] - mean[c0 + e]) * rstd[c0 + e];
+      o[e] = scale[c0 + e] * (d[e] - c1[c0 + e] - xh * c2[c0 + e]);
+    }
+    *(u32x4*)(dx + i * EPC) = f32_to_chunk<T>(o);
+    if (dmasked) *(u32x4*)(dmasked + i * EPC) = f32_to_chunk<T>(d);
+  }
+}
+
+int grid_for(long long n) { return (int)min((long long)8192, (n + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+// partial [nslot][2][C] fp32 -> sums [2][C] fp64 (the buffer the host all-reduces)
+int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(nslot > 0 && C > 0, "bn_reduce_slots: bad shape");
+  hipLaunchKernelGGL(bn_reduce_slots, dim3(ceil_div(2 * C, 256)), dim3(256), 0, stream, partial, nslot, C, sums);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// sums [2][C] (global), count = global elements per channel.  gamma/beta nullable
+// (scale=False / center=False).  moving_* nullable (no update).
+int simclr_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+                       float* moving_mean, float* moving_var, float decay, float eps, float* mean,
+                       float* rstd, float* scale, float* shift, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(C > 0 && count > 0, "bn_finalize: bad shape");
+  hipLaunchKernelGGL(bn_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, count, C, gamma, beta,
+                     moving_mean, moving_var, decay, eps, mean, rstd, scale, shift);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// y = act(x*scale+shift [+ res | + res*rscale+rshift]); rows x C, T = dtype
+int simclr_bn_apply(const void* x, const float* scale, const float* shift, const void* res,
+                    const float* rscale, const float* rshift, void* y, long long rows, int C, int relu,
+                    int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "bn_apply: C=%d must be a multiple of %d", C, epc);
+  const long long nchunks = rows * (C / epc);
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((bn_apply<uint16_t>), dim3(grid_for(nchunks)), dim3(256), 0, stream, (const uint16_t*)x,
+                       scale, shift, (const uint16_t*)res, rscale, rshift, (uint16_t*)y, nchunks, C, relu);
+  else
+    hipLaunchKernelGGL((bn_apply<float>), dim3(grid_for(nchunks)), dim3(256), 0, stream, (const float*)x, scale,
+                       shift, (const float*)res, rscale, rshift, (float*)y, nchunks, C, relu);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// partial [nslot][2][C] must be zeroed by the caller.
+int simclr_bn_bwd_reduce(const void* dy, const void* x, const void* mask_src, const float* scale,
+                         const float* shift, const float* mean, const float* rstd, long long rows, int C,
+                         int mask_mode, float* partial, int nslot, int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_reduce: C=%d must be a multiple of %d", C, epc);
+  SIMCLR_CHECK_ARG(mask_mode != 1 || mask_src, "bn_bwd_reduce: mask_mode 1 needs mask_src");
+  const int cpr = C / epc;
+  const int rl = max(1, 256 / min(cpr, 256));
+  long long want_blocks = 2048;
+  int rows_per_block = (int)max((long long)rl * 4, (rows + want_blocks - 1) / want_blocks);
+  const int grid = ceil_div(rows, rows_per_block);
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((bn_bwd_reduce<uint16_t>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)dy,
+                       (const uint16_t*)x, (const uint16_t*)mask_src, scale, shift, mean, rstd, rows, C,
+                       mask_mode, rows_per_block, partial, nslot);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce<float>), dim3(grid), dim3(256), 0, stream, (const float*)dy,
+                       (const float*)x, (const float*)mask_src, scale, shift, mean, rstd, rows, C, mask_mode,
+                       rows_per_block, partial, nslot);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, double count, int C,
+                           float* dgamma, float* dbeta, int accumulate, float* c1, float* c2,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, stream, local_sums, global_sums,
+                     count, C, dgamma, dbeta, accumulate, c1, c2);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, const float* c1,
+                        const float* c2, long long rows, int C, int mask_mode, void* dx, void* dmasked,
+                        int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, epc);
+  const long long nchunks = rows * (C / epc);
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply<uint16_t>), dim3(grid_for(nchunks)), dim3(256), 0, stream,
+                       (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)mask_src, scale, shift, mean,
+                       rstd, c1, c2, nchunks, C, mask_mode, (uint16_t*)dx, (uint16_t*)dmasked);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply<float>), dim3(grid_for(nchunks)), dim3(256), 0, stream, (const float*)dy,
+                       (const float*)x, (const float*)mask_src, scale, shift, mean, rstd, c1, c2, nchunks, C,
+                       mask_mode, (float*)dx, (float*)dmasked);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

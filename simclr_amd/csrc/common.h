@@ -1,0 +1,110 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) SimCLR hot-path kernels.
+// Wave = 64 lanes everywhere.  No portability layer: this code targets gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define SIMCLR_DT_F32 0
+#define SIMCLR_DT_BF16 1
+
+// ---- error plumbing (C-ABI: int return codes + simclr_last_error()) ----------
+extern "C" const char* simclr_last_error(void);
+void simclr_set_error(const char* fmt, ...);
+
+#define SIMCLR_CHECK_ARG(cond, ...)                 \
+  do {                                              \
+    if (!(cond)) {                                  \
+      simclr_set_error(__VA_ARGS__);                \
+      return 1;                                     \
+    }                                               \
+  } while (0)
+
+#define SIMCLR_CHECK_LAUNCH()                                        \
+  do {                                                               \
+    hipError_t e__ = hipGetLastError();                              \
+    if (e__ != hipSuccess) {                                         \
+      simclr_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, \
+                       hipGetErrorString(e__));                      \
+      return 2;                                                      \
+    }                                                                \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -----------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+// Element traits: storage type T is float or uint16_t (bf16 bits).
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<uint16_t> {
+  static constexpr int EPC = 8;
+  __device__ static __forceinline__ float ld(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+  __device__ static __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16_bits(v); }
+};
+
+// unpack a 16-byte chunk into floats (4 for f32, 8 for bf16)
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const u32x4& c, float* out);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const u32x4& c, float* out) {
+  out[0] = __uint_as_float(c[0]); out[1] = __uint_as_float(c[1]);
+  out[2] = __uint_as_float(c[2]); out[3] = __uint_as_float(c[3]);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<uint16_t>(const u32x4& c, float* out) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(c[i] << 16);
+    out[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ u32x4 f32_to_chunk(const float* in);
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<float>(const float* in) {
+  u32x4 c;
+  c[0] = __float_as_uint(in[0]); c[1] = __float_as_uint(in[1]);
+  c[2] = __float_as_uint(in[2]); c[3] = __float_as_uint(in[3]);
+  return c;
+}
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<uint16_t>(const float* in) {
+  u32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = pack_bf16x2(in[2 * i], in[2 * i + 1]);
+  return c;
+}
+
+// ---- wave64 reductions --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,809 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X): forward, data-gradient and
+// weight-gradient of the bias-free NHWC/HWIO convolutions of
+// /root/reference/tf2/resnet.py:183-208 (Conv2dFixedPadding: explicit symmetric
+// (k-1)//2 padding, VALID for stride>1 / SAME for stride 1) and the Dense layers of
+// /root/reference/tf2/model.py:143-154 (a 1x1 conv on a 1x1 image).
+//
+// GEMM view (forward):  Y[M, N] = A[M, K] * Wt[N, K]^T
+//   M = V*OH*OW output pixels, N = Cout, K = KH*KW*Cin (Cin fastest), A gathered on the
+//   fly from the NHWC activation (never materialised), Wt = weights re-laid K-contiguous.
+// dgrad is the same kernel with a transposed-conv gather (MODE_DGRAD) and weights
+// re-laid as [Cin][KH*KW*Cout].  wgrad reduces over pixels: dW[K, N] = A^T * dY.
+//
+// Matrix cores: v_mfma_f32_16x16x32_bf16 (bf16 storage, fp32 accumulate) or
+// v_mfma_f32_16x16x4_f32 (exact fp32 "parity mode").  Both element types share one
+// byte geometry: operands move in 16-byte chunks (8 bf16 / 4 f32), an LDS tile row is
+// 8 chunks = 128 B, XOR-swizzled (chunk ^= row&7) so ds_read_b128 fragment reads are
+// bank-conflict free.  The weight fragment is the MFMA A operand and the activation
+// fragment the B operand, so D[n=(lane>>4)*4+reg][m=lane&15]: every lane owns 4
+// CONSECUTIVE output channels of one pixel -> 8/16-byte NHWC stores and per-channel
+// BatchNorm statistics (tf2/resnet.py:50-60) reduce with 4 xor-shuffles in the epilogue.
+#include "common.h"
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct ConvP {
+  const void* x;   // gathered tensor [V, IH, IW, *] (pixel pitch = pixpitch elements)
+  const void* w;   // [N][K] K-contiguous
+  void* y;         // [M][N]
+  float* stats;    // nullable: [nslot][2][N] partial (sum, sumsq) per output channel
+  int V, IH, IW, IC, OH, OW, N, KH, KW, stride, pad;
+  int pixpitch;    // elements between consecutive ix of the gathered tensor (usually IC)
+  int M, K;
+  int nslot, accumulate;
+  int m_tiles, n_tiles;
+};
+
+template <typename T> struct MMA;
+template <> struct MMA<uint16_t> {
+  __device__ static __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct MMA<float> {
+  __device__ static __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    return c;
+  }
+};
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
+__device__ __forceinline__ u32x4 zero16() { return (u32x4){0u, 0u, 0u, 0u}; }
+
+// XCD-aware tile mapping: workgroup b runs on XCD b%8; all N-tiles of one M-tile are
+// consecutive on ONE XCD so the gathered A tile is re-read from that XCD's L2.
+__device__ __forceinline__ bool tile_of_block(int m_tiles, int n_tiles, int& mt, int& nt) {
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+  nt = idx % n_tiles;
+  mt = (idx / n_tiles) * 8 + xcd;
+  return mt < m_tiles;
+}
+
+// ------------------------------------------------------------------------------------
+// forward / dgrad implicit GEMM.  Tile BM=128 x BN (128|64) x 128 bytes of K; 4 waves.
+// ------------------------------------------------------------------------------------
+template <typename T, int MODE, int BN, bool STATS>
+__global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BM = 128;
+  constexpr int BK = 8 * EPC;           // elements per k-tile (128 bytes)
+  constexpr int WN = BN / 64;           // waves along N (2 or 1)
+  constexpr int WM = 4 / WN;            // waves along M (2 or 4)
+  constexpr int MI = BM / WM / 16;      // 16-row m fragments per wave (4 or 2)
+  constexpr int NI = 4;                 // 16-col n fragments per wave (64 cols)
+  constexpr int AJ = BM / 32;           // A chunks per thread per k-tile (4)
+  constexpr int BJ = BN / 32;           // B chunks per thread per k-tile (4 or 2)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* As = (u32x4*)smem;                       // [2][BM*8]
+  u32x4* Bs = As + 2 * BM * 8;                    // [2][BN*8]
+
+  int mt, nt;
+  if (!tile_of_block(p.m_tiles, p.n_tiles, mt, nt)) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, fl = lane & 15;
+  const int wm = wave / WN, wn = wave % WN;
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ Wt = (const T*)p.w;
+
+  // ---- per-thread gather bookkeeping: rows (tid>>3)+32j, chunk tid&7 ----
+  const int kc = tid & 7;
+  int a_by[AJ], a_bx[AJ];
+  long long a_img[AJ];
+  bool a_ok[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + (tid >> 3) + 32 * j;
+    a_ok[j] = m < p.M;
+    const int mm = a_ok[j] ? m : 0;
+    const int v = mm / (p.OH * p.OW);
+    const int rem = mm - v * (p.OH * p.OW);
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    a_img[j] = (long long)v * p.IH * p.IW;
+    if (MODE == MODE_FWD) { a_by[j] = oy * p.stride - p.pad; a_bx[j] = ox * p.stride - p.pad; }
+    else { a_by[j] = oy + p.pad; a_bx[j] = ox + p.pad; }
+  }
+  const int KT = p.K / BK;
+
+  u32x4 ra[AJ], rb[BJ];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    const int tap = k0 / p.IC;
+    const int ci0 = k0 - tap * p.IC;
+    const int ty = tap / p.KW, tx = tap - ty * p.KW;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      int iy, ix;
+      bool ok = a_ok[j];
+      if (MODE == MODE_FWD) {
+        iy = a_by[j] + ty; ix = a_bx[j] + tx;
+      } else {
+        const int tyy = a_by[j] - ty, txx = a_bx[j] - tx;
+        ok = ok && tyy >= 0 && txx >= 0;
+        if (p.stride > 1) {
+          ok = ok && (tyy % p.stride == 0) && (txx % p.stride == 0);
+          iy = tyy / p.stride; ix = txx / p.stride;
+        } else { iy = tyy; ix = txx; }
+      }
+      ok = ok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      ra[j] = zero16();
+      if (ok) ra[j] = ld16(X + ((a_img[j] + (long long)iy * p.IW + ix) * p.pixpitch + ci0 + kc * EPC));
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int n = n0 + (tid >> 3) + 32 * j;
+      rb[j] = zero16();
+      if (n < p.N) rb[j] = ld16(Wt + ((long long)n * p.K + k0 + kc * EPC));
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int r = (tid >> 3) + 32 * j;
+      As[buf * BM * 8 + r * 8 + (kc ^ (r & 7))] = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int r = (tid >> 3) + 32 * j;
+      Bs[buf * BN * 8 + r * 8 + (kc ^ (r & 7))] = rb[j];
+    }
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * (MI * 16) + i * 16 + fl;
+        af[i] = As[buf * BM * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = wn * 64 + i * 16 + fl;
+        bf[i] = Bs[buf * BN * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MMA<T>::run(bf[ni], af[mi], acc[ni][mi]);
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: NHWC store (4 consecutive channels per lane) ----
+  T* __restrict__ Y = (T*)p.y;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * 64 + ni * 16 + g * 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (MI * 16) + mi * 16 + fl;
+      if (m < p.M && n < p.N) {
+        T* dst = Y + (long long)m * p.N + n;
+        float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+        if (p.accumulate) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += Elem<T>::ld(dst + r);
+        }
+        if (sizeof(T) == 4) {
+          *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)dst = pk;
+        }
+      }
+    }
+  }
+  if (STATS) {
+    // per-channel sum / sum-of-squares over this tile's rows (rows >= M are exact zeros)
+    float* red = (float*)smem;  // [WM][BN][2] floats, reuse LDS (all MFMA reads are done)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { const float v = acc[ni][mi][r]; s += v; ss += v * v; }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+        if (fl == 0) {
+          const int nl = wn * 64 + ni * 16 + g * 4 + r;
+          red[(wm * BN + nl) * 2] = s;
+          red[(wm * BN + nl) * 2 + 1] = ss;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; ss += red[(w * BN + tid) * 2 + 1]; }
+      float* st = p.stats + (long long)(mt % p.nslot) * 2 * p.N;
+      atomicAdd(st + n0 + tid, s);
+      atomicAdd(st + p.N + n0 + tid, ss);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// wgrad: dW[K, N] (fp32 split-slabs) = sum over pixels A(m, k) * dY(m, n).
+// Tile BKW (k rows: one tap x BKW input channels) x BNW, reduction chunks of BR pixels.
+// LDS tiles keep the natural [pixel][channel] layout (coalesced 16-byte staging); the
+// 32-byte channel blocks are XOR-permuted by the pixel group so the per-element
+// fragment gathers of the 4 lane groups hit different banks.
+// ------------------------------------------------------------------------------------
+struct WgradP {
+  const void* x;    // activation [V, IH, IW, pixpitch...]
+  const void* dy;   // [M, N]
+  float* dw;        // [splits][K][N] fp32 slabs
+  int V, IH, IW, IC, OH, OW, N, KH, KW, stride, pad, pixpitch;
+  int M, K, splits, chunks_per_split;
+  int k_tiles, n_tiles;
+};
+
+template <typename T, int BKW, int BNW>
+__global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BR = 8 * EPC;                 // pixels per reduction chunk (64 bf16 / 32 f32)
+  constexpr int WK = (BKW >= 64) ? 2 : 2;     // waves along k rows
+  constexpr int WNN = 2;                      // waves along n
+  constexpr int KI = BKW / WK / 16;           // 16-row fragments per wave along k
+  constexpr int NI = BNW / WNN / 16;
+  constexpr int A_CPR = BKW / EPC;            // 16B chunks per pixel row of the A tile
+  constexpr int B_CPR = BNW / EPC;
+  constexpr int A_CH = BR * A_CPR / 256;      // chunks per thread
+  constexpr int B_CH = BR * B_CPR / 256;
+  constexpr int A_BLK = BKW * sizeof(T) / 32; // 32-byte blocks per pixel row
+  constexpr int B_BLK = BNW * sizeof(T) / 32;
+  constexpr int PG = (sizeof(T) == 2) ? 8 : 1;  // pixels per lane-group per MFMA k slot
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                            // [BR][BKW] T
+  unsigned char* Bs = smem + BR * BKW * sizeof(T);     // [BR][BNW] T
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, fl = lane & 15;
+  const int wk = wave / WNN, wn = wave % WNN;
+  const int ktile = blockIdx.x % p.k_tiles;
+  const int ntile = (blockIdx.x / p.k_tiles) % p.n_tiles;
+  const int split = blockIdx.x / (p.k_tiles * p.n_tiles);
+  const int kk0 = ktile * BKW;
+  const int tap = kk0 / p.IC, ci0 = kk0 - tap * p.IC;
+  const int ty = tap / p.KW, tx = tap - ty * p.KW;
+  const int n0 = ntile * BNW;
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ DY = (const T*)p.dy;
+
+  f32x4 acc[KI][NI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (p.M + BR - 1) / BR;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+
+  u32x4 ra[A_CH], rb[B_CH];
+  auto load_chunk = [&](int c) {
+    const int mbase = c * BR;
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int id = tid + 256 * j;
+      const int px = id / A_CPR, cc = id % A_CPR;
+      const int m = mbase + px;
+      ra[j] = zero16();
+      if (m < p.M) {
+        const int v = m / (p.OH * p.OW);
+        const int rem = m - v * (p.OH * p.OW);
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int iy = oy * p.stride - p.pad + ty, ix = ox * p.stride - p.pad + tx;
+        if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+          ra[j] = ld16(X + (((long long)v * p.IH + iy) * p.IW + ix) * p.pixpitch + ci0 + cc * EPC);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      const int id = tid + 256 * j;
+      const int px = id / B_CPR, cc = id % B_CPR;
+      const int m = mbase + px;
+      rb[j] = zero16();
+      if (m < p.M && n0 + cc * EPC < p.N) rb[j] = ld16(DY + (long long)m * p.N + n0 + cc * EPC);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int id = tid + 256 * j;
+      const int px = id / A_CPR, cc = id % A_CPR;
+      const int blk = (cc >> 1) ^ ((px / PG) & (A_BLK - 1));
+      *(u32x4*)(As + px * (BKW * sizeof(T)) + blk * 32 + (cc & 1) * 16) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+      const int id = tid + 256 * j;
+      const int px = id / B_CPR, cc = id % B_CPR;
+      const int blk = (cc >> 1) ^ ((px / PG) & (B_BLK - 1));
+      *(u32x4*)(Bs + px * (BNW * sizeof(T)) + blk * 32 + (cc & 1) * 16) = rb[j];
+    }
+  };
+  // element (pixel px, channel ch) of a tile with row bytes RB and NBLK 32-byte blocks
+  auto lds_elem = [&](const unsigned char* base, int RB, int NBLK, int px, int ch) -> const T* {
+    const int byte = ch * (int)sizeof(T);
+    const int blk = (byte >> 5) ^ ((px / PG) & (NBLK - 1));
+    return (const T*)(base + px * RB + blk * 32 + (byte & 31));
+  };
+
+  for (int c = c_begin; c < c_end; ++c) {
+    load_chunk(c);
+    __syncthreads();   // previous chunk's fragment reads are done
+    store_chunk();
+    __syncthreads();
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < BR / 32; ++ks) {
+        u32x4 af[KI], bf[NI];
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+          const int ch = wk * (KI * 16) + i * 16 + fl;
+          uint32_t w4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int px = ks * 32 + g * 8 + 2 * e;
+            const uint16_t lo = *(const uint16_t*)lds_elem(As, BKW * 2, A_BLK, px, ch);
+            const uint16_t hi = *(const uint16_t*)lds_elem(As, BKW * 2, A_BLK, px + 1, ch);
+            w4[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+          }
+          af[i] = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int ch = wn * (NI * 16) + i * 16 + fl;
+          uint32_t w4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int px = ks * 32 + g * 8 + 2 * e;
+            const uint16_t lo = *(const uint16_t*)lds_elem(Bs, BNW * 2, B_BLK, px, ch);
+            const uint16_t hi = *(const uint16_t*)lds_elem(Bs, BNW * 2, B_BLK, px + 1, ch);
+            w4[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+          }
+          bf[i] = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+        }
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, bf[ni]), __builtin_bit_cast(bf16x8, af[ki]), acc[ki][ni], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < BR / 4; ++ks) {
+        float af[KI], bf[NI];
+        const int px = ks * 4 + g;
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+          af[i] = *(const float*)lds_elem(As, BKW * 4, A_BLK, px, wk * (KI * 16) + i * 16 + fl);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          bf[i] = *(const float*)lds_elem(Bs, BNW * 4, B_BLK, px, wn * (NI * 16) + i * 16 + fl);
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni], af[ki], acc[ki][ni], 0, 0, 0);
+      }
+    }
+  }
+  // D[n = g*4+reg][k row = fl]  ->  slab[split][kk][n .. n+3]
+  float* slab = p.dw + (long long)split * p.K * p.N;
+#pragma unroll
+  for (int ki = 0; ki < KI; ++ki) {
+    const int kk = kk0 + wk * (KI * 16) + ki * 16 + fl;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (NI * 16) + ni * 16 + g * 4;
+      if (kk < p.K && n < p.N)
+        *(float4*)(slab + (long long)kk * p.N + n) =
+            make_float4(acc[ki][ni][0], acc[ki][ni][1], acc[ki][ni][2], acc[ki][ni][3]);
+    }
+  }
+}
+
+// dw[i] = sum_s slabs[s][i]  (+ dw[i] if accumulate)
+__global__ void slab_reduce(const float* __restrict__ slabs, int splits, long long numel,
+                            float* __restrict__ out, int accumulate) {
+  const long long n4 = numel / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < splits; ++s) {
+      const float4 v = *(const float4*)(slabs + (long long)s * numel + i * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (accumulate) {
+      const float4 v = *(const float4*)(out + i * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *(float4*)(out + i * 4) = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Stem convolution (Cin=3): tf2/resnet.py:593-599 (7x7 s2) and :551-556 (CIFAR 3x3 s1).
+// The input is pre-packed (simclr_pack_views) as [V][HP][WP][4] with physical zero
+// borders and a zero 4th channel, so one kernel row of KWP taps x 4 channels is one
+// contiguous, bounds-check-free run and every MFMA A fragment is a single 16-byte
+// global load (no LDS for the activation); the padded weights [N][KHP][KWP][4] sit
+// in LDS for the whole (persistent) workgroup.
+// ------------------------------------------------------------------------------------
+struct StemP {
+  const void* xp;  // [V][HP][WP][4]
+  const void* w;   // [N][KP] padded weights, KP = KHP*KWP*4
+  void* y;         // [M][N]
+  float* stats;
+  int V, HP, WP, OH, OW, N, KHP, KWP, stride, M, KP, nslot, m_tiles;
+};
+
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int KSTEP = 4 * EPC;     // elements per MFMA k-step
+  constexpr int BN = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, fl = lane & 15;
+  const int n0 = blockIdx.y * BN;
+  const int pitch = p.KP * (int)sizeof(T) + 16;  // bytes per weight row in LDS (+16: bank spread)
+  const T* __restrict__ Wt = (const T*)p.w;
+  const int cpr = p.KP / EPC;  // chunks per weight row
+  for (int id = tid; id < BN * cpr; id += 256) {
+    const int r = id / cpr, c = id % cpr;
+    u32x4 v = zero16();
+    if (n0 + r < p.N) v = ld16(Wt + (long long)(n0 + r) * p.KP + c * EPC);
+    *(u32x4*)(smem + r * pitch + c * 16) = v;
+  }
+  __syncthreads();
+  float* red = (float*)(smem + BN * pitch);  // [4 waves][64][2]
+  const T* __restrict__ X = (const T*)p.xp;
+  T* __restrict__ Y = (T*)p.y;
+  const int row_elems = p.KWP * 4;             // elements per kernel row
+  const int ksteps = p.KP / KSTEP;
+  for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
+    const int mw = mt * 128 + wave * 32;
+    long long base[2];
+    bool ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mw + i * 16 + fl;
+      ok[i] = m < p.M;
+      const int mm = ok[i] ? m : 0;
+      const int v = mm / (p.OH * p.OW);
+      const int rem = mm - v * (p.OH * p.OW);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      base[i] = (((long long)v * p.HP + oy * p.stride) * p.WP + ox * p.stride) * 4;
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int e = ks * KSTEP + g * EPC;          // element offset along padded K
+      const int kh = e / row_elems, within = e - kh * row_elems;
+      u32x4 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = ok[i] ? ld16(X + base[i] + (long long)kh * p.WP * 4 + within) : zero16();
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const u32x4 bf = *(const u32x4*)(smem + (ni * 16 + fl) * pitch + (ks * 4 + g) * 16);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = MMA<T>::run(bf, af[mi], acc[ni][mi]);
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + ni * 16 + g * 4;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = mw + mi * 16 + fl;
+        if (m < p.M && n < p.N) {
+          T* dst = Y + (long long)m * p.N + n;
+          if (sizeof(T) == 4) {
+            *(float4*)dst = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+          } else {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(acc[ni][mi][0], acc[ni][mi][1]);
+            pk[1] = pack_bf16x2(acc[ni][mi][2], acc[ni][mi][3]);
+            *(u32x2*)dst = pk;
+          }
+        }
+      }
+    }
+    if (STATS) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) { const float v = acc[ni][mi][r]; s += v; ss += v * v; }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+          if (fl == 0) {
+            const int nl = ni * 16 + g * 4 + r;
+            red[(wave * BN + nl) * 2] = s;
+            red[(wave * BN + nl) * 2 + 1] = ss;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s += red[(w * BN + tid) * 2]; ss += red[(w * BN + tid) * 2 + 1]; }
+        float* st = p.stats + (long long)(mt % p.nslot) * 2 * p.N;
+        atomicAdd(st + n0 + tid, s);
+        atomicAdd(st + p.N + n0 + tid, ss);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- weight re-layout (fp32 HWIO master -> compute copies) ---------------------------
+// mode 0: fwd   dst[co][(kh*KW+kw)*CI+ci]
+// mode 1: dgrad dst[ci][(kh*KW+kw)*CO+co]
+// mode 2: stem  dst[co][(kh*KWP+kw)*4+ci]   zero padded to KHP x KWP x 4
+template <typename T>
+__global__ void prep_weights(const float* __restrict__ w, T* __restrict__ dst, int KH, int KW, int CI,
+                             int CO, int mode, int KHP, int KWP) {
+  long long total;
+  if (mode == 2) total = (long long)CO * KHP * KWP * 4;
+  else total = (long long)KH * KW * CI * CO;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (mode == 0) {
+      const int co = (int)(i / ((long long)KH * KW * CI));
+      const int k = (int)(i % ((long long)KH * KW * CI));
+      const int tap = k / CI, ci = k % CI;
+      v = w[((long long)tap * CI + ci) * CO + co];
+    } else if (mode == 1) {
+      const int ci = (int)(i / ((long long)KH * KW * CO));
+      const int k = (int)(i % ((long long)KH * KW * CO));
+      const int tap = k / CO, co = k % CO;
+      v = w[((long long)tap * CI + ci) * CO + co];
+    } else {
+      const int co = (int)(i / (KHP * KWP * 4));
+      const int k = (int)(i % (KHP * KWP * 4));
+      const int kh = k / (KWP * 4), kw = (k / 4) % KWP, ci = k % 4;
+      if (kh < KH && kw < KW && ci < CI) v = w[(((long long)kh * KW + kw) * CI + ci) * CO + co];
+    }
+    Elem<T>::st(dst + i, v);
+  }
+}
+
+// stem wgrad result [KHP*KWP*4][CO] -> HWIO [KH][KW][CI][CO]  (+= if accumulate)
+__global__ void unpack_stem_dw(const float* __restrict__ src, float* __restrict__ dst, int KH, int KW,
+                               int CI, int CO, int KWP, int accumulate) {
+  const int total = KH * KW * CI * CO;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % CO;
+    const int ci = (i / CO) % CI;
+    const int kw = (i / (CO * CI)) % KW;
+    const int kh = i / (CO * CI * KW);
+    const float v = src[(long long)((kh * KWP + kw) * 4 + ci) * CO + co];
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
+}
+
+template <typename T, int MODE>
+int launch_igemm(const ConvP& p0, hipStream_t stream) {
+  ConvP p = p0;
+  const int BN = (p.N <= 64) ? 64 : 128;
+  p.m_tiles = ceil_div(p.M, 128);
+  p.n_tiles = ceil_div(p.N, BN);
+  const int grid = ceil_div(p.m_tiles, 8) * 8 * p.n_tiles;
+  const size_t lds = 2 * (128 + BN) * 128;
+  const bool st = p.stats != nullptr;
+#define L(BNv, STv) \
+  hipLaunchKernelGGL((conv_igemm<T, MODE, BNv, STv>), dim3(grid), dim3(256), lds, stream, p)
+  if (BN == 64) { if (st) L(64, true); else L(64, false); }
+  else { if (st) L(128, true); else L(128, false); }
+#undef L
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Forward conv / dense.  x [V,IH,IW,Cin] (T), w_t [Cout][KH*KW*Cin] (T), y [V,OH,OW,Cout] (T).
+// stats (nullable): float [nslot][2][Cout], must be zeroed by the caller; receives
+// per-channel partial (sum, sum of squares) of the fp32 results (BatchNorm statistics).
+int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V,
+                      int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
+                      int pad, int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_fwd: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(Cin % (8 * epc) == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 8 * epc);
+  SIMCLR_CHECK_ARG(Cout % 4 == 0, "conv2d_fwd: Cout=%d must be a multiple of 4", Cout);
+  SIMCLR_CHECK_ARG(V > 0 && OH > 0 && OW > 0 && stride >= 1, "conv2d_fwd: bad geometry");
+  SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd: M overflows int32");
+  SIMCLR_CHECK_ARG(!stats || nslot > 0, "conv2d_fwd: nslot must be > 0 with stats");
+  ConvP p = {};
+  p.x = x; p.w = w_t; p.y = y; p.stats = stats; p.nslot = nslot;
+  p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
+  p.M = V * OH * OW; p.K = KH * KW * Cin;
+  if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_FWD>(p, stream);
+  else launch_igemm<float, MODE_FWD>(p, stream);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// Data gradient.  dy [V,OH,OW,Cout] (T), w_d [Cin][KH*KW*Cout] (T), dx [V,IH,IW,Cin] (T).
+// accumulate != 0: dx += result.
+int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulate, int V, int IH,
+                        int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
+                        int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0, "conv2d_dgrad: Cout=%d must be a multiple of %d", Cout, 8 * epc);
+  SIMCLR_CHECK_ARG(Cin % 4 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 4", Cin);
+  SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad: M overflows int32");
+  ConvP p = {};
+  p.x = dy; p.w = w_d; p.y = dx; p.stats = nullptr; p.nslot = 1; p.accumulate = accumulate;
+  p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cout;
+  p.M = V * IH * IW; p.K = KH * KW * Cout;
+  if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
+  else launch_igemm<float, MODE_DGRAD>(p, stream);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int Cout, int KH, int KW,
+                                           int dtype);
+
+static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int* chunks_per_split) {
+  const int tiles = (K / bkw) * ceil_div(N, bnw);
+  const int nchunks = ceil_div(M, br);
+  int splits = max(1, min(nchunks, 1024 / max(1, tiles)));
+  splits = min(splits, 256);
+  *chunks_per_split = ceil_div(nchunks, splits);
+  return ceil_div(nchunks, *chunks_per_split);
+}
+static void wgrad_tile(int Cin, int Cout, int* bkw, int* bnw) {
+  *bkw = (Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : 32);
+  *bnw = (Cout % 128 == 0 || Cout > 128) ? 128 : 64;
+  if (*bkw == 32) *bnw = 64;
+}
+
+size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int Cout, int KH, int KW,
+                                           int dtype) {
+  int bkw, bnw, cps;
+  wgrad_tile(Cin, Cout, &bkw, &bnw);
+  const int br = dtype == SIMCLR_DT_BF16 ? 64 : 32;
+  const int splits = wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, br, &cps);
+  return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
+}
+
+// Weight gradient.  x [V,IH,IW,*] (T, pixel pitch `pixpitch` elements, Cin channels used),
+// dy [V,OH,OW,Cout] (T), dw fp32 [KH*KW*Cin][Cout] (= HWIO).  accumulate != 0: dw += result.
+int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace,
+                        int V, int IH, int IW, int Cin, int pixpitch, int OH, int OW, int Cout, int KH,
+                        int KW, int stride, int pad, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_wgrad: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(Cin % 32 == 0, "conv2d_wgrad: Cin=%d must be a multiple of 32", Cin);
+  SIMCLR_CHECK_ARG(Cout % 8 == 0, "conv2d_wgrad: Cout=%d must be a multiple of 8", Cout);
+  SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_wgrad: M overflows int32");
+  WgradP p = {};
+  p.x = x; p.dy = dy; p.dw = (float*)workspace;
+  p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = pixpitch;
+  p.M = V * OH * OW; p.K = KH * KW * Cin;
+  int bkw, bnw;
+  wgrad_tile(Cin, Cout, &bkw, &bnw);
+  const int br = dtype == SIMCLR_DT_BF16 ? 64 : 32;
+  p.splits = wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split);
+  p.k_tiles = p.K / bkw;
+  p.n_tiles = ceil_div(p.N, bnw);
+  const int grid = p.k_tiles * p.n_tiles * p.splits;
+  const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
+  const size_t lds = (size_t)br * (bkw + bnw) * esz;
+#define LW(TT, A, B) hipLaunchKernelGGL((conv_wgrad<TT, A, B>), dim3(grid), dim3(256), lds, stream, p)
+  if (dtype == SIMCLR_DT_BF16) {
+    if (bkw == 128 && bnw == 128) LW(uint16_t, 128, 128);
+    else if (bkw == 128) LW(uint16_t, 128, 64);
+    else if (bkw == 64 && bnw == 128) LW(uint16_t, 64, 128);
+    else if (bkw == 64) LW(uint16_t, 64, 64);
+    else LW(uint16_t, 32, 64);
+  } else {
+    if (bkw == 128 && bnw == 128) LW(float, 128, 128);
+    else if (bkw == 128) LW(float, 128, 64);
+    else if (bkw == 64 && bnw == 128) LW(float, 64, 128);
+    else if (bkw == 64) LW(float, 64, 64);
+    else LW(float, 32, 64);
+  }
+#undef LW
+  SIMCLR_CHECK_LAUNCH();
+  const long long numel = (long long)p.K * p.N;
+  hipLaunchKernelGGL(slab_reduce, dim3(min(2048, ceil_div(numel / 4, 256))), dim3(256), 0, stream,
+                     (const float*)workspace, p.splits, numel, dw, accumulate);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// Stem forward on the packed input (see simclr_pack_views).  w_s [Cout][KHP*KWP*4] (T).
+int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats, int nslot, int V,
+                         int HP, int WP, int OH, int OW, int Cout, int KHP, int KWP, int stride,
+                         int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "stem_conv_fwd: bad dtype %d", dtype);
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  StemP p = {};
+  p.xp = xp; p.w = w_s; p.y = y; p.stats = stats; p.nslot = nslot > 0 ? nslot : 1;
+  p.V = V; p.HP = HP; p.WP = WP; p.OH = OH; p.OW = OW; p.N = Cout; p.KHP = KHP; p.KWP = KWP;
+  p.stride = stride; p.M = V * OH * OW; p.KP = KHP * KWP * 4;
+  SIMCLR_CHECK_ARG(p.KP % (4 * epc) == 0, "stem_conv_fwd: padded K=%d not a multiple of %d", p.KP, 4 * epc);
+  SIMCLR_CHECK_ARG((KWP * 4) % epc == 0, "stem_conv_fwd: KWP*4 must be a multiple of %d", epc);
+  SIMCLR_CHECK_ARG(Cout % 4 == 0, "stem_conv_fwd: Cout %% 4 != 0");
+  p.m_tiles = ceil_div(p.M, 128);
+  const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
+  const size_t lds = 64 * (p.KP * esz + 16) + 4 * 64 * 2 * sizeof(float);
+  dim3 grid(min(p.m_tiles, 2048), ceil_div(Cout, 64));
+  if (dtype == SIMCLR_DT_BF16) {
+    if (stats) hipLaunchKernelGGL((stem_conv_fwd<uint16_t, true>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((stem_conv_fwd<uint16_t, false>), grid, dim3(256), lds, stream, p);
+  } else {
+    if (stats) hipLaunchKernelGGL((stem_conv_fwd<float, true>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((stem_conv_fwd<float, false>), grid, dim3(256), lds, stream, p);
+  }
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// fp32 HWIO master weights -> compute-dtype copies.  mode 0 fwd, 1 dgrad, 2 stem (padded).
+int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,
+                        int KHP, int KWP, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(mode >= 0 && mode <= 2, "prep_weights: bad mode %d", mode);
+  const long long total = mode == 2 ? (long long)Cout * KHP * KWP * 4 : (long long)KH * KW * Cin * Cout;
+  const int grid = min(4096, ceil_div(total, 256));
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((prep_weights<uint16_t>), dim3(grid), dim3(256), 0, stream, w_hwio, (uint16_t*)dst,
+                       KH, KW, Cin, Cout, mode, KHP, KWP);
+  else
+    hipLaunchKernelGGL((prep_weights<float>), dim3(grid), dim3(256), 0, stream, w_hwio, (float*)dst, KH,
+                       KW, Cin, Cout, mode, KHP, KWP);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_unpack_stem_dw(const float* src, float* dst, int KH, int KW, int Cin, int Cout, int KWP,
+                          int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(unpack_stem_dw, dim3(ceil_div(KH * KW * Cin * Cout, 256)), dim3(256), 0, stream, src,
+                     dst, KH, KW, Cin, Cout, KWP, accumulate);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,395 @@
+// View packing, stem BN+ReLU+max-pool, global average pool, supervised-head loss and
+// small elementwise helpers for gfx950.  HBM-bound kernels: 16-byte accesses along the
+// contiguous channel axis, grid-stride loops.
+//
+// References: /root/reference/tf2/model.py:250-259 (split the 3k-channel input into k
+// views and concatenate on the batch axis), /root/reference/tf2/resnet.py:602-611
+// (BN+ReLU then MaxPooling2D(3, 2, 'SAME')), :693-696 (global mean over H,W),
+// /root/reference/tf2/objective.py:27-32 + /root/reference/tf2/metrics.py:49-55
+// (supervised softmax cross-entropy and top-1 accuracy).
+#include "common.h"
+
+namespace {
+
+// images f32 [b][H][W][3k] -> xp T [k*b][HP][WP][4], interior at (pad, pad), zero elsewhere
+template <typename T>
+__global__ void pack_views(const float* __restrict__ img, T* __restrict__ xp, int b, int H, int W,
+                           int k, int HP, int WP, int pad) {
+  const long long total = (long long)k * b * HP * WP;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % WP);
+    const int py = (int)((i / WP) % HP);
+    const int v = (int)(i / ((long long)WP * HP));
+    const int view = v / b, n = v % b;
+    const int y = py - pad, x = px - pad;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const float* s = img + (((long long)n * H + y) * W + x) * (3 * k) + 3 * view;
+      c[0] = s[0]; c[1] = s[1]; c[2] = s[2];
+    }
+    if (sizeof(T) == 4) {
+      *(float4*)((float*)xp + i * 4) = make_float4(c[0], c[1], c[2], c[3]);
+    } else {
+      u32x2 pk; pk[0] = pack_bf16x2(c[0], c[1]); pk[1] = pack_bf16x2(c[2], c[3]);
+      *(u32x2*)((uint16_t*)xp + i * 4) = pk;
+    }
+  }
+}
+
+// y[v,oy,ox,c] = max over the k x k window of relu(x*scale+shift); arg = first max tap.
+template <typename T>
+__global__ void bnrelu_maxpool_fwd(const T* __restrict__ x, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, T* __restrict__ y,
+                                   uint8_t* __restrict__ arg, int V, int H, int W, int C, int OH, int OW,
+                                   int ksz, int stride, int pad_t, int pad_l) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long long total = (long long)V * OH * OW * cpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const long long pix = i / cpr;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), v = (int)(pix / ((long long)OW * OH));
+    const int c0 = cc * EPC;
+    float best[EPC];
+    int bi[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    for (int ky = 0; ky < ksz; ++ky) {
+      const int iy = oy * stride - pad_t + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < ksz; ++kx) {
+        const int ix = ox * stride - pad_l + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float xv[EPC];
+        chunk_to_f32<T>(*(const u32x4*)(x + (((long long)v * H + iy) * W + ix) * C + c0), xv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float a = fmaxf(fmaf(xv[e], scale[c0 + e], shift[c0 + e]), 0.f);
+          if (a > best[e]) { best[e] = a; bi[e] = ky * ksz + kx; }
+        }
+      }
+    }
+    *(u32x4*)(y + pix * C + c0) = f32_to_chunk<T>(best);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) arg[pix * C + c0 + e] = (uint8_t)bi[e];
+  }
+}
+
+// dx[v,iy,ix,c] = sum over windows containing (iy,ix) whose argmax is this tap of dy
+template <typename T>
+__global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict__ arg,
+                            T* __restrict__ dx, int V, int H, int W, int C, int OH, int OW, int ksz,
+                            int stride, int pad_t, int pad_l) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long long total = (long long)V * H * W * cpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const long long pix = i / cpr;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), v = (int)(pix / ((long long)W * H));
+    const int c0 = cc * EPC;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int ky = 0; ky < ksz; ++ky) {
+      const int t = iy + pad_t - ky;
+      if (t < 0 || t % stride) continue;
+      const int oy = t / stride;
+      if (oy >= OH) continue;
+      for (int kx = 0; kx < ksz; ++kx) {
+        const int u = ix + pad_l - kx;
+        if (u < 0 || u % stride) continue;
+        const int ox = u / stride;
+        if (ox >= OW) continue;
+        const long long op = (((long long)v * OH + oy) * OW + ox) * C + c0;
+        float d[EPC];
+        chunk_to_f32<T>(*(const u32x4*)(dy + op), d);
+        const int tapid = ky * ksz + kx;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (arg[op + e] == tapid) acc[e] += d[e];
+      }
+    }
+    *(u32x4*)(dx + pix * C + c0) = f32_to_chunk<T>(acc);
+  }
+}
+
+// y[v][c] = mean over HW of x[v][hw][c]
+template <typename T>
+__global__ void global_avgpool_fwd(const T* __restrict__ x, T* __restrict__ y, int V, int HW, int C) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long long total = (long long)V * cpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const int v = (int)(i / cpr);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      float xv[EPC];
+      chunk_to_f32<T>(*(const u32x4*)(x + ((long long)v * HW + p) * C + cc * EPC), xv);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += xv[e];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] *= inv;
+    *(u32x4*)(y + (long long)v * C + cc * EPC) = f32_to_chunk<T>(acc);
+  }
+}
+// dx[v][hw][c] = (dy[v][c] [+ dy2[v][c]]) / HW, optionally masked by mask_src > 0
+template <typename T>
+__global__ void global_avgpool_bwd(const T* __restrict__ dy, const T* __restrict__ mask_src,
+                                   T* __restrict__ dx, int V, int HW, int C) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long long total = (long long)V * HW * cpr;
+  const float inv = 1.f / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const int v = (int)(i / ((long long)cpr * HW));
+    float d[EPC];
+    chunk_to_f32<T>(*(const u32x4*)(dy + (long long)v * C + cc * EPC), d);
+    if (mask_src) {
+      float mk[EPC];
+      chunk_to_f32<T>(*(const u32x4*)(mask_src + i * EPC), mk);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) d[e] = mk[e] > 0.f ? d[e] * inv : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) d[e] *= inv;
+    }
+    *(u32x4*)(dx + i * EPC) = f32_to_chunk<T>(d);
+  }
+}
+
+// Supervised head tail: logits = z + bias; softmax CE vs int labels (mean over rows);
+// dlogits = (softmax - onehot) * gscale / rows ; padded classes (>= nclass) get 0.
+// One wave per row.  out[0] += loss contribution, out[1] += top-1 hits  (atomics; caller zeroes)
+template <typename T>
+__global__ void bias_softmax_xent(const T* __restrict__ z, const float* __restrict__ bias,
+                                  const int* __restrict__ labels, int rows, int label_rows, int nclass,
+                                  int cpad, float gscale, T* __restrict__ dlogits, float* __restrict__ out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int label = labels[row % label_rows];   // labels duplicated per view (tf2/run.py:599-600)
+  const T* zr = z + (long long)row * cpad;
+  float mx = -INFINITY; int am = 0x7fffffff;
+  for (int c = lane; c < nclass; c += 64) {
+    const float v = Elem<T>::ld(zr + c) + bias[c];
+    if (v > mx) { mx = v; am = c; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(am, o, 64);
+    if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+  }
+  float se = 0.f, zl = 0.f;
+  for (int c = lane; c < nclass; c += 64) {
+    const float v = Elem<T>::ld(zr + c) + bias[c];
+    se += __expf(v - mx);
+    if (c == label) zl = v;
+  }
+  se = wave_sum(se);
+  zl = wave_sum(zl);
+  const float lse = mx + __logf(se);
+  const float g = gscale / (float)rows;
+  T* dr = dlogits + (long long)row * cpad;
+  for (int c = lane; c < cpad; c += 64) {
+    float d = 0.f;
+    if (c < nclass) {
+      const float v = Elem<T>::ld(zr + c) + bias[c];
+      d = (__expf(v - lse) - (c == label ? 1.f : 0.f)) * g;
+    }
+    Elem<T>::st(dr + c, d);
+  }
+  if (lane == 0) {
+    atomicAdd(out, (lse - zl) / (float)rows);
+    atomicAdd(out + 1, (am == label ? 1.f : 0.f) / (float)rows);
+  }
+}
+
+// out[c] (+)= sum over rows of x[row][c]   (bias gradient)
+template <typename T>
+__global__ void colsum(const T* __restrict__ x, int rows, int C, int cvalid, float* __restrict__ out,
+                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cvalid) return;
+  float a = 0.f;
+  for (int r = 0; r < rows; ++r) a += Elem<T>::ld(x + (long long)r * C + c);
+  out[c] = accumulate ? out[c] + a : a;
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    Elem<TO>::st(y + i, Elem<TI>::ld(x + i));
+}
+
+// y = a*x + y  (fp32) ; also returns nothing.  Used for the sup-head L2 term (tf2/model.py:49-60)
+__global__ void axpy_f32(float a, const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+// out[0] = 0.5 * sum x^2  (tf.nn.l2_loss), single workgroup, fp64 accumulate
+__global__ __launch_bounds__(256) void l2_loss_f32(const float* __restrict__ x, long long n,
+                                                   float* __restrict__ out) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) a += (double)x[i] * x[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(0.5 * sh[0]);
+}
+
+int grid_for(long long n) { return (int)min((long long)8192, (n + 255) / 256); }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, EXPR_BF16, EXPR_F32) \
+  do { if ((dtype) == SIMCLR_DT_BF16) { EXPR_BF16; } else { EXPR_F32; } } while (0)
+
+extern "C" {
+
+int simclr_pack_views(const float* images, void* xp, int b, int H, int W, int k, int HP, int WP, int pad,
+                      int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(b > 0 && k > 0 && HP >= H + pad && WP >= W + pad, "pack_views: bad geometry");
+  const long long total = (long long)k * b * HP * WP;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((pack_views<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream, images,
+                                (uint16_t*)xp, b, H, W, k, HP, WP, pad),
+             hipLaunchKernelGGL((pack_views<float>), dim3(grid_for(total)), dim3(256), 0, stream, images,
+                                (float*)xp, b, H, W, k, HP, WP, pad));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y,
+                              unsigned char* arg, int V, int H, int W, int C, int OH, int OW, int ksz,
+                              int stride, int pad_t, int pad_l, int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "bnrelu_maxpool_fwd: C %% %d != 0", epc);
+  SIMCLR_CHECK_ARG(ksz * ksz <= 255, "bnrelu_maxpool_fwd: window too large");
+  const long long total = (long long)V * OH * OW * (C / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bnrelu_maxpool_fwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)x, scale, shift, (uint16_t*)y, arg, V, H, W, C, OH, OW, ksz,
+                                stride, pad_t, pad_l),
+             hipLaunchKernelGGL((bnrelu_maxpool_fwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)x, scale, shift, (float*)y, arg, V, H, W, C, OH, OW, ksz, stride,
+                                pad_t, pad_l));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_maxpool_bwd(const void* dy, const unsigned char* arg, void* dx, int V, int H, int W, int C,
+                       int OH, int OW, int ksz, int stride, int pad_t, int pad_l, int dtype,
+                       hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "maxpool_bwd: C %% %d != 0", epc);
+  const long long total = (long long)V * H * W * (C / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((maxpool_bwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)dy, arg, (uint16_t*)dx, V, H, W, C, OH, OW, ksz, stride, pad_t,
+                                pad_l),
+             hipLaunchKernelGGL((maxpool_bwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)dy, arg, (float*)dx, V, H, W, C, OH, OW, ksz, stride, pad_t,
+                                pad_l));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "global_avgpool_fwd: C %% %d != 0", epc);
+  const long long total = (long long)V * (C / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((global_avgpool_fwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)x, (uint16_t*)y, V, HW, C),
+             hipLaunchKernelGGL((global_avgpool_fwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)x, (float*)y, V, HW, C));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx = dy/HW broadcast; mask_src (nullable, same shape as dx): zero where mask_src <= 0
+int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, int V, int HW, int C,
+                              int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "global_avgpool_bwd: C %% %d != 0", epc);
+  const long long total = (long long)V * HW * (C / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((global_avgpool_bwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)dy, (const uint16_t*)mask_src, (uint16_t*)dx, V, HW, C),
+             hipLaunchKernelGGL((global_avgpool_bwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)dy, (const float*)mask_src, (float*)dx, V, HW, C));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[0] += mean CE loss, out[1] += top-1 accuracy (caller zeroes out[0..1])
+int simclr_bias_softmax_xent(const void* z, const float* bias, const int* labels, int rows,
+                             int label_rows, int nclass, int cpad, float gscale, void* dlogits, float* out,
+                             int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(rows > 0 && nclass > 0 && cpad >= nclass && label_rows > 0, "bias_softmax_xent: bad shape");
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bias_softmax_xent<uint16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, stream,
+                                (const uint16_t*)z, bias, labels, rows, label_rows, nclass, cpad, gscale,
+                                (uint16_t*)dlogits, out),
+             hipLaunchKernelGGL((bias_softmax_xent<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, stream,
+                                (const float*)z, bias, labels, rows, label_rows, nclass, cpad, gscale,
+                                (float*)dlogits, out));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_colsum(const void* x, int rows, int C, int cvalid, float* out, int accumulate, int dtype,
+                  hipStream_t stream) {
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((colsum<uint16_t>), dim3(ceil_div(cvalid, 256)), dim3(256), 0, stream,
+                                (const uint16_t*)x, rows, C, cvalid, out, accumulate),
+             hipLaunchKernelGGL((colsum<float>), dim3(ceil_div(cvalid, 256)), dim3(256), 0, stream,
+                                (const float*)x, rows, C, cvalid, out, accumulate));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// dtype_in/dtype_out in {f32, bf16}
+int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out, hipStream_t stream) {
+  const int grid = grid_for(n);
+  if (dtype_in == SIMCLR_DT_F32 && dtype_out == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, uint16_t>), dim3(grid), dim3(256), 0, stream, (const float*)x, (uint16_t*)y, n);
+  else if (dtype_in == SIMCLR_DT_BF16 && dtype_out == SIMCLR_DT_F32)
+    hipLaunchKernelGGL((cast_kernel<uint16_t, float>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, (float*)y, n);
+  else if (dtype_in == SIMCLR_DT_F32 && dtype_out == SIMCLR_DT_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, n);
+  else
+    hipLaunchKernelGGL((cast_kernel<uint16_t, uint16_t>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, n);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_axpy_f32(float a, const float* x, float* y, long long n, hipStream_t stream) {
+  hipLaunchKernelGGL(axpy_f32, dim3(grid_for(n)), dim3(256), 0, stream, a, x, y, n);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+int simclr_l2_loss_f32(const float* x, long long n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(l2_loss_f32, dim3(1), dim3(256), 0, stream, x, n, out);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

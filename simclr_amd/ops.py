@@ -1,0 +1,322 @@
+"""Thin torch-tensor wrappers over the C ABI (include/simclr_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function
+below only validates shapes and forwards raw device pointers to libsimclr_hip.so.
+All tensors must be CUDA (ROCm) tensors, contiguous.
+"""
+import ctypes
+
+import torch
+
+from ._lib import DT_BF16, DT_F32, lib
+
+NSLOT = 32  # partial-statistics slots (spreads atomic contention; summed by bn_reduce_slots)
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError('unsupported dtype %s' % t.dtype)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'need contiguous device tensor'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------- NT-Xent
+def l2norm_fwd(x):
+    rows, D = x.shape
+    z = torch.empty_like(x)
+    inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    lib().l2norm_fwd(_p(x), _p(z), _p(inv), rows, D, _s())
+    return z, inv
+
+
+def l2norm_bwd(z, inv, dz):
+    dx = torch.empty_like(z)
+    lib().l2norm_bwd(_p(z), _p(inv), _p(dz), _p(dx), z.shape[0], z.shape[1], _s())
+    return dx
+
+
+def ntxent_workspace(n, N, D, device):
+    nbytes = lib().ntxent_workspace_bytes(n, N, D)
+    return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+
+
+def ntxent_fwd(z_local, z_all, rank, temperature, ws=None):
+    n, D = z_local.shape[0] // 2, z_local.shape[1]
+    N = z_all.shape[0] // 2
+    assert z_local.dtype == torch.float32 and z_all.dtype == torch.float32
+    if ws is None:
+        ws = ntxent_workspace(n, N, D, z_local.device)
+    out = torch.zeros(4, device=z_local.device, dtype=torch.float32)
+    row_stats = torch.empty(2 * n, 2, device=z_local.device, dtype=torch.float32)
+    lib().ntxent_fwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(out), _p(row_stats),
+                     _p(ws), _s())
+    return out, row_stats, ws
+
+
+def ntxent_bwd(z_local, z_all, rank, temperature, row_stats, grad_scale, out, ws):
+    n, D = z_local.shape[0] // 2, z_local.shape[1]
+    N = z_all.shape[0] // 2
+    dz_local = torch.empty_like(z_local)
+    dz_all = torch.empty_like(z_all)
+    lib().ntxent_bwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(row_stats),
+                     float(grad_scale), _p(dz_local), _p(dz_all), _p(out), _p(ws), _s())
+    return dz_local, dz_all
+
+
+def ntxent_logits_ab(z_local, z_all, temperature):
+    n, D = z_local.shape[0] // 2, z_local.shape[1]
+    N = z_all.shape[0] // 2
+    out = torch.empty(n, N, device=z_local.device, dtype=torch.float32)
+    lib().ntxent_logits_ab(_p(z_local), _p(z_all), n, N, D, float(temperature), _p(out), _s())
+    return out
+
+
+# ---------------------------------------------------------------- conv / dense
+def prep_weights(w_hwio, mode, dtype, khp=0, kwp=0, out=None):
+    KH, KW, CI, CO = w_hwio.shape
+    if mode == 2:
+        shape = (CO, khp * kwp * 4)
+    elif mode == 0:
+        shape = (CO, KH * KW * CI)
+    else:
+        shape = (CI, KH * KW * CO)
+    if out is None:
+        out = torch.empty(shape, device=w_hwio.device, dtype=dtype)
+    lib().prep_weights(_p(w_hwio), _p(out), KH, KW, CI, CO, mode, khp, kwp, dt(out), _s())
+    return out
+
+
+def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None):
+    V, IH, IW, Cin = x.shape
+    Cout = w_t.shape[0]
+    if out is None:
+        out = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
+    lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), NSLOT if stats is not None else 0, V, IH, IW, Cin,
+                     OH, OW, Cout, KH, KW, stride, pad, dt(x), _s())
+    return out
+
+
+def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=False):
+    V, OH, OW, Cout = dy.shape
+    Cin = w_d.shape[0]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(V, IH, IW, Cin, device=dy.device, dtype=dy.dtype)
+    lib().conv2d_dgrad(_p(dy), _p(w_d), _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout, KH, KW,
+                       stride, pad, dt(dy), _s())
+    return out
+
+
+_wgrad_ws = {}
+
+
+def _workspace(nbytes, device, key='ws'):
+    buf = _wgrad_ws.get((key, device))
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _wgrad_ws[(key, device)] = buf
+    return buf
+
+
+def conv2d_wgrad(x, dy, KH, KW, stride, pad, Cin=None, pixpitch=None, out=None, accumulate=False):
+    V, IH, IW = x.shape[0], x.shape[1], x.shape[2]
+    if Cin is None:
+        Cin = x.shape[3]
+    if pixpitch is None:
+        pixpitch = x.shape[3]
+    _, OH, OW, Cout = dy.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty(KH * KW * Cin, Cout, device=x.device, dtype=torch.float32)
+    nbytes = lib().conv2d_wgrad_workspace_bytes(V, OH, OW, Cin, Cout, KH, KW, dt(x))
+    ws = _workspace(nbytes, x.device)
+    lib().conv2d_wgrad(_p(x), _p(dy), _p(out), int(accumulate), _p(ws), V, IH, IW, Cin, pixpitch, OH, OW,
+                       Cout, KH, KW, stride, pad, dt(x), _s())
+    return out
+
+
+def stem_geometry(H, W, KH, KW, stride):
+    """Packed-input geometry for the stem conv (Conv2dFixedPadding: pad (k-1)//2 before)."""
+    pad = (KH - 1) // 2
+    OH = (H + (KH - 1) - KH) // stride + 1
+    OW = (W + (KW - 1) - KW) // stride + 1
+    KWP = 8
+    KHP = KH
+    HP = (OH - 1) * stride + KHP
+    WP = (OW - 1) * stride + KWP
+    HP = max(HP, H + pad)
+    WP = max(WP, W + pad)
+    WP = (WP + 1) // 2 * 2     # 16-byte aligned rows for bf16 (8 B / pixel)
+    return dict(pad=pad, OH=OH, OW=OW, KHP=KHP, KWP=KWP, HP=HP, WP=WP)
+
+
+def pack_views(images, k, geo, dtype):
+    b, H, W, C = images.shape
+    assert C == 3 * k and images.dtype == torch.float32
+    xp = torch.empty(k * b, geo['HP'], geo['WP'], 4, device=images.device, dtype=dtype)
+    lib().pack_views(_p(images), _p(xp), b, H, W, k, geo['HP'], geo['WP'], geo['pad'], dt(xp), _s())
+    return xp
+
+
+def stem_conv_fwd(xp, w_s, geo, stride, stats=None):
+    V = xp.shape[0]
+    Cout = w_s.shape[0]
+    y = torch.empty(V, geo['OH'], geo['OW'], Cout, device=xp.device, dtype=xp.dtype)
+    lib().stem_conv_fwd(_p(xp), _p(w_s), _p(y), _p(stats), NSLOT if stats is not None else 0, V, geo['HP'],
+                        geo['WP'], geo['OH'], geo['OW'], Cout, geo['KHP'], geo['KWP'], stride, dt(xp), _s())
+    return y
+
+
+def stem_conv_wgrad(xp, dy, geo, KH, KW, stride, out=None, accumulate=False):
+    """dW (HWIO [KH,KW,3,Cout] fp32) of the stem from the packed input."""
+    Cout = dy.shape[3]
+    kp = geo['KHP'] * geo['KWP'] * 4
+    tmp = torch.empty(kp, Cout, device=dy.device, dtype=torch.float32)
+    # one 'tap' per kernel row: KWP*4 = 32 contiguous elements, pixel pitch 4
+    conv2d_wgrad(xp, dy, geo['KHP'], 1, stride, 0, Cin=geo['KWP'] * 4, pixpitch=4, out=tmp)
+    if out is None:
+        out = torch.empty(KH, KW, 3, Cout, device=dy.device, dtype=torch.float32)
+    lib().unpack_stem_dw(_p(tmp), _p(out), KH, KW, 3, Cout, geo['KWP'], int(accumulate), _s())
+    return out
+
+
+# ---------------------------------------------------------------- batch norm
+def new_stats(C, device):
+    return torch.zeros(NSLOT, 2, C, device=device, dtype=torch.float32)
+
+
+def bn_reduce_slots(partial):
+    C = partial.shape[2]
+    sums = torch.empty(2, C, device=partial.device, dtype=torch.float64)
+    lib().bn_reduce_slots(_p(partial), partial.shape[0], C, _p(sums), _s())
+    return sums
+
+
+def bn_finalize(sums, count, gamma, beta, moving_mean, moving_var, decay, eps=1e-5):
+    C = sums.shape[1]
+    dev = sums.device
+    mean, rstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
+    lib().bn_finalize(_p(sums), float(count), C, _p(gamma), _p(beta), _p(moving_mean), _p(moving_var),
+                      float(decay), float(eps), _p(mean), _p(rstd), _p(scale), _p(shift), _s())
+    return mean, rstd, scale, shift
+
+
+def bn_apply(x, scale, shift, relu, res=None, rscale=None, rshift=None, out=None):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    lib().bn_apply(_p(x), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift), _p(out), rows, C,
+                   int(relu), dt(x), _s())
+    return out
+
+
+def bn_bwd_reduce(dy, x, mask_src, scale, shift, mean, rstd, mask_mode):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    partial = new_stats(C, x.device)
+    lib().bn_bwd_reduce(_p(dy), _p(x), _p(mask_src), _p(scale), _p(shift), _p(mean), _p(rstd), rows, C,
+                        mask_mode, _p(partial), NSLOT, dt(x), _s())
+    return partial
+
+
+def bn_bwd_finalize(local_sums, global_sums, count, dgamma, dbeta, accumulate=False):
+    C = local_sums.shape[1]
+    c1 = torch.empty(C, device=local_sums.device, dtype=torch.float32)
+    c2 = torch.empty(C, device=local_sums.device, dtype=torch.float32)
+    lib().bn_bwd_finalize(_p(local_sums), _p(global_sums), float(count), C, _p(dgamma), _p(dbeta),
+                          int(accumulate), _p(c1), _p(c2), _s())
+    return c1, c2
+
+
+def bn_bwd_apply(dy, x, mask_src, scale, shift, mean, rstd, c1, c2, mask_mode, want_masked=False, out=None):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x) if out is None else out
+    dmasked = torch.empty_like(x) if want_masked else None
+    lib().bn_bwd_apply(_p(dy), _p(x), _p(mask_src), _p(scale), _p(shift), _p(mean), _p(rstd), _p(c1), _p(c2),
+                       rows, C, mask_mode, _p(dx), _p(dmasked), dt(x), _s())
+    return dx, dmasked
+
+
+# ---------------------------------------------------------------- pooling
+def same_pad(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+def bnrelu_maxpool_fwd(x, scale, shift, ksz=3, stride=2):
+    V, H, W, C = x.shape
+    OH, pt = same_pad(H, ksz, stride)
+    OW, pl = same_pad(W, ksz, stride)
+    y = torch.empty(V, OH, OW, C, device=x.device, dtype=x.dtype)
+    arg = torch.empty(V, OH, OW, C, device=x.device, dtype=torch.uint8)
+    lib().bnrelu_maxpool_fwd(_p(x), _p(scale), _p(shift), _p(y), _p(arg), V, H, W, C, OH, OW, ksz, stride,
+                             pt, pl, dt(x), _s())
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, H, W, ksz=3, stride=2):
+    V, OH, OW, C = dy.shape
+    _, pt = same_pad(H, ksz, stride)
+    _, pl = same_pad(W, ksz, stride)
+    dx = torch.empty(V, H, W, C, device=dy.device, dtype=dy.dtype)
+    lib().maxpool_bwd(_p(dy), _p(arg), _p(dx), V, H, W, C, OH, OW, ksz, stride, pt, pl, dt(dy), _s())
+    return dx
+
+
+def global_avgpool_fwd(x):
+    V, H, W, C = x.shape
+    y = torch.empty(V, C, device=x.device, dtype=x.dtype)
+    lib().global_avgpool_fwd(_p(x), _p(y), V, H * W, C, dt(x), _s())
+    return y
+
+
+def global_avgpool_bwd(dy, H, W, mask_src=None):
+    V, C = dy.shape
+    dx = torch.empty(V, H, W, C, device=dy.device, dtype=dy.dtype)
+    lib().global_avgpool_bwd(_p(dy), _p(mask_src), _p(dx), V, H * W, C, dt(dy), _s())
+    return dx
+
+
+# ---------------------------------------------------------------- supervised head / misc
+def bias_softmax_xent(z, bias, labels, nclass, gscale, out):
+    rows, cpad = z.shape
+    dlogits = torch.empty_like(z)
+    lib().bias_softmax_xent(_p(z), _p(bias), _p(labels), rows, labels.shape[0], nclass, cpad, float(gscale),
+                            _p(dlogits), _p(out), dt(z), _s())
+    return dlogits
+
+
+def colsum(x, cvalid, out, accumulate=False):
+    rows, C = x.shape
+    lib().colsum(_p(x), rows, C, cvalid, _p(out), int(accumulate), dt(x), _s())
+    return out
+
+
+def cast(x, dtype, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    lib().cast(_p(x), _p(out), x.numel(), dt(x), dt(out), _s())
+    return out
+
+
+def axpy_f32(a, x, y):
+    lib().axpy_f32(float(a), _p(x), _p(y), x.numel(), _s())
+
+
+def l2_loss_f32(x, out):
+    lib().l2_loss_f32(_p(x), x.numel(), _p(out), _s())

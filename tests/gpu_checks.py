@@ -1,0 +1,373 @@
+"""Kernel-level parity checks: HIP path (through the C ABI) vs CPU references.
+
+Each check returns a dict {name, err, tol, ok, ...}.  The CPU references are the
+oracle (`oracle/`, float64) for the loss / LARS and plain torch-CPU float64 ops
+for conv / BN / pooling.  Used by tests/test_gpu_kernels.py (pytest -m gpu) and
+tools/run_gpu_checks.py (prints everything; first-contact diagnostics).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import lars as olars
+from oracle import ntxent as ont
+from simclr_amd import ops
+from simclr_amd._lib import lib
+
+DEV = 'cuda'
+
+
+def _res(name, got, ref, rtol, atol=0.0, **kw):
+    got = torch.as_tensor(got).detach().double().cpu()
+    ref = torch.as_tensor(ref).detach().double().cpu()
+    err = float((got - ref).abs().max()) if got.numel() else 0.0
+    scale = float(ref.abs().max()) if ref.numel() else 0.0
+    tol = rtol * scale + atol
+    bad = int(((got - ref).abs() > tol).sum())
+    d = dict(name=name, err=err, tol=tol, scale=scale, ok=bool(err <= tol) and bool(torch.isfinite(got).all()),
+             nbad=bad, numel=got.numel())
+    d.update(kw)
+    return d
+
+
+def _tol(dtype):
+    # bf16: inputs are pre-rounded to bf16, so the only error is fp32 accumulation order
+    # plus one final bf16 rounding of the output (2^-9 relative) ; f32: accumulation order.
+    return 6e-3 if dtype == torch.bfloat16 else 2e-5
+
+
+# ------------------------------------------------------------------ probes
+def check_probes():
+    out = []
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(16, 32, generator=g).bfloat16()
+    b = torch.randn(32, 16, generator=g).bfloat16()   # asymmetric on purpose
+    o = torch.zeros(64 * 4, device=DEV)
+    lib().probe(0, ops._p(a.to(DEV).view(torch.int16)), ops._p(b.to(DEV).view(torch.int16)), ops._p(o), ops._s())
+    d = o.cpu().view(64, 4)
+    ref = a.double() @ b.double()
+    got = torch.zeros(16, 16, dtype=torch.float64)
+    for l in range(64):
+        for r in range(4):
+            got[(l >> 4) * 4 + r, l & 15] = d[l, r]
+    out.append(_res('probe_mfma_bf16_16x16x32_layout', got, ref, 1e-5))
+    a = torch.randn(16, 4, generator=g)
+    b = torch.randn(4, 16, generator=g)
+    o = torch.zeros(64 * 4, device=DEV)
+    lib().probe(1, ops._p(a.to(DEV)), ops._p(b.to(DEV)), ops._p(o), ops._s())
+    d = o.cpu().view(64, 4)
+    got = torch.zeros(16, 16, dtype=torch.float64)
+    for l in range(64):
+        for r in range(4):
+            got[(l >> 4) * 4 + r, l & 15] = d[l, r]
+    out.append(_res('probe_mfma_f32_16x16x4_layout', got, a.double() @ b.double(), 1e-6))
+    return out
+
+
+def probe_ds_read_tr16():
+    """Returns the raw lane mapping of ds_read_b64_tr_b16 for a [*,16]-element row-major tile:
+    lane l supplies address (l>>4)*64 + ((l&15)>>2)*16 + (l&3)*4 (elements)."""
+    src = torch.arange(1024, dtype=torch.int16)
+    lanes = torch.arange(64)
+    addr = ((lanes >> 4) * 64 + ((lanes & 15) >> 2) * 16 + (lanes & 3) * 4).int()
+    o = torch.zeros(256, dtype=torch.int16, device=DEV)
+    lib().probe(2, ops._p(src.to(DEV)), ops._p(addr.to(DEV)), ops._p(o), ops._s())
+    return o.cpu().view(64, 4)
+
+
+# ------------------------------------------------------------------ NT-Xent
+def check_ntxent(n, R, D=128, temperature=0.1, rank=0, seed=3, hidden_norm=True):
+    g = np.random.default_rng(seed)
+    hs = [g.standard_normal((2 * n, D)).astype(np.float32) for _ in range(R)]
+    losses, grads = ont.contrastive_loss_and_grad(hs, hidden_norm, temperature)
+    loss_r, logits_ab, labels = ont.add_contrastive_loss(hs[rank], hidden_norm, temperature,
+                                                        all_hiddens=hs if R > 1 else None, replica_id=rank)
+    acc_ref, ent_ref = ont.contrastive_metrics(logits_ab, labels)
+    # device path: normalise every replica's hidden, build z_all, run rank's fwd/bwd
+    zs, invs = [], []
+    for h in hs:
+        x = torch.from_numpy(h).to(DEV)
+        if hidden_norm:
+            z, inv = ops.l2norm_fwd(x)
+        else:
+            z, inv = x, None
+        zs.append(z); invs.append(inv)
+    z_all = torch.cat([z[:n] for z in zs] + [z[n:] for z in zs], 0).contiguous()
+    res = []
+    if hidden_norm:
+        zref = ont.l2_normalize(hs[rank].astype(np.float64))
+        res.append(_res('l2norm_fwd n=%d' % n, zs[rank], zref, 0, 1e-6))
+    out, row_stats, ws = ops.ntxent_fwd(zs[rank], z_all, rank, temperature)
+    # total gradient wrt rank's hidden = local part + sum over replicas q of dz_all_q[rank slot]
+    dz_local_r = None
+    dz_slot = torch.zeros(2 * n, D, device=DEV)
+    for q in range(R):
+        o_q, rs_q, ws_q = ops.ntxent_fwd(zs[q], z_all, q, temperature)
+        dl, da = ops.ntxent_bwd(zs[q], z_all, q, temperature, rs_q, 1.0 / R, o_q, ws_q)
+        if q == rank:
+            dz_local_r = dl
+            out = o_q
+        N = n * R
+        dz_slot[:n] += da[rank * n:(rank + 1) * n]
+        dz_slot[n:] += da[N + rank * n:N + (rank + 1) * n]
+    dz = dz_local_r + dz_slot
+    dh = ops.l2norm_bwd(zs[rank], invs[rank], dz) if hidden_norm else dz
+    torch.cuda.synchronize()
+    o = out.cpu().double()
+    tag = 'n=%d R=%d D=%d T=%g rank=%d' % (n, R, D, temperature, rank)
+    res.append(_res('ntxent_loss ' + tag, o[0], loss_r, 1e-5))
+    res.append(_res('ntxent_acc ' + tag, o[1], acc_ref, 0, 1e-6))
+    res.append(_res('ntxent_entropy ' + tag, o[2], ent_ref, 1e-4, 1e-6))
+    res.append(_res('ntxent_grad ' + tag, dh, grads[rank], 2e-4))
+    lab = ops.ntxent_logits_ab(zs[rank], z_all, temperature)
+    res.append(_res('ntxent_logits_ab ' + tag, lab, logits_ab, 1e-5))
+    return res
+
+
+def check_ntxent_closed_forms():
+    """SURVEY section 4 known answers: (i) identical rows -> 2*log(2N-1); (ii) orthogonal one-hot."""
+    res = []
+    n, D, T = 64, 128, 0.1
+    h = torch.ones(2 * n, D, device=DEV)
+    z, _ = ops.l2norm_fwd(h)
+    out, _, _ = ops.ntxent_fwd(z, z, 0, T)
+    res.append(_res('ntxent_closed_identical', out.cpu()[0], 2 * np.log(2 * n - 1), 1e-5))
+    e = torch.eye(n, D, device=DEV)
+    h = torch.cat([e, e], 0).contiguous()
+    z, _ = ops.l2norm_fwd(h)
+    out, _, _ = ops.ntxent_fwd(z, z, 0, T)
+    closed = 2 * (np.log(np.exp(1 / T) + (2 * n - 2)) - 1 / T)
+    res.append(_res('ntxent_closed_orthogonal', out.cpu()[0], closed, 1e-4, 1e-7))
+    return res
+
+
+# ------------------------------------------------------------------ LARS
+def check_lars(seed=0, classic=True, nesterov=False):
+    from simclr_amd.lars_optimizer import LARSOptimizer, Variable
+    g = np.random.default_rng(seed)
+    shapes = [('conv2d/kernel:0', (3, 3, 64, 64)), ('batch_normalization/gamma:0', (64,)),
+              ('dense/kernel:0', (300, 77)), ('head_supervised/linear_layer/dense/bias:0', (10,)),
+              ('zero/kernel:0', (1000,)), ('conv2d_1/kernel:0', (1, 1, 256, 1030))]
+    vs = []
+    ref = {}
+    for name, shp in shapes:
+        w = (g.standard_normal(shp) * 0.05).astype(np.float32)
+        if name.startswith('zero'):
+            w[:] = 0
+        gr = (g.standard_normal(shp) * 1e-3).astype(np.float32)
+        m = (g.standard_normal(shp) * 1e-3).astype(np.float32)
+        v = Variable(name, torch.from_numpy(w).to(DEV))
+        v.grad = torch.from_numpy(gr).to(DEV)
+        vs.append(v)
+        ref[name] = (w, gr, m)
+    opt = LARSOptimizer(0.3, momentum=0.9, weight_decay=1e-4, use_nesterov=nesterov, classic_momentum=classic,
+                        exclude_from_weight_decay=['batch_normalization', 'bias', 'head_supervised'])
+    opt._build(vs)
+    for v in vs:
+        opt.get_slot(v, 'Momentum').copy_(torch.from_numpy(ref[v.name][2]).to(DEV))
+    opt.apply_gradients([(v.grad, v) for v in vs])
+    torch.cuda.synchronize()
+    res = []
+    for v in vs:
+        w, gr, m = ref[v.name]
+        nw, nv = olars.lars_apply(v.name, w, gr, m, 0.3, momentum=0.9, weight_decay=1e-4, use_nesterov=nesterov,
+                                  classic_momentum=classic,
+                                  exclude_from_weight_decay=['batch_normalization', 'bias', 'head_supervised'])
+        tag = 'lars[%s classic=%d nest=%d]' % (v.name, classic, nesterov)
+        res.append(_res(tag + ' w', v.value, nw, 2e-6, 1e-9))
+        res.append(_res(tag + ' v', opt.get_slot(v, 'Momentum'), nv, 2e-6, 1e-9))
+    return res
+
+
+# ------------------------------------------------------------------ conv
+def _rand(shape, dtype, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def check_conv(V, H, W, Cin, Cout, k, stride, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    pad = (k - 1) // 2
+    OH = (H + (k - 1) - k) // stride + 1
+    OW = (W + (k - 1) - k) // stride + 1
+    x = _rand((V, H, W, Cin), dtype, g)
+    w = _rand((k, k, Cin, Cout), dtype, g, (k * k * Cin) ** -0.5)     # HWIO, values representable in T
+    dy = _rand((V, OH, OW, Cout), dtype, g)
+    # CPU float64 reference with TF Conv2dFixedPadding semantics
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    pe = (k - 1) - pad
+    yr = F.conv2d(F.pad(xr, (pad, pe, pad, pe)), wr.permute(3, 2, 0, 1), stride=stride)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    y_ref = yr.detach().permute(0, 2, 3, 1)
+    dx_ref = xr.grad.permute(0, 2, 3, 1)
+    dw_ref = wr.grad
+    # device
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    wd32 = w.float().to(DEV)
+    w_t = ops.prep_weights(wd32, 0, dtype)
+    w_d = ops.prep_weights(wd32, 1, dtype)
+    stats = ops.new_stats(Cout, DEV)
+    y = ops.conv2d_fwd(xd, w_t, k, k, stride, pad, OH, OW, stats=stats)
+    sums = ops.bn_reduce_slots(stats)
+    dx = ops.conv2d_dgrad(dyd, w_d, k, k, stride, pad, H, W)
+    dx2 = dx.clone()
+    ops.conv2d_dgrad(dyd, w_d, k, k, stride, pad, H, W, out=dx2, accumulate=True)
+    dw = ops.conv2d_wgrad(xd, dyd, k, k, stride, pad)
+    torch.cuda.synchronize()
+    tag = 'V%d %dx%d %d->%d k%d s%d %s' % (V, H, W, Cin, Cout, k, stride, str(dtype).split('.')[-1])
+    t = _tol(dtype)
+    res = [_res('conv_fwd ' + tag, y, y_ref, t),
+           _res('conv_stats_sum ' + tag, sums[0], y_ref.sum((0, 1, 2)), 1e-4, 1e-3 * float(y_ref.abs().sum((0, 1, 2)).max())),
+           _res('conv_stats_sq ' + tag, sums[1], (y_ref ** 2).sum((0, 1, 2)), 1e-4),
+           _res('conv_dgrad ' + tag, dx, dx_ref, t),
+           _res('conv_dgrad_acc ' + tag, dx2, 2 * dx_ref, 2 * t),
+           _res('conv_wgrad ' + tag, dw.view(k, k, Cin, Cout), dw_ref, 2e-5 if dtype == torch.float32 else 1e-4)]
+    return res
+
+
+def check_stem(V, H, k, stride, Cout, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(V // 2, H, H, 6, generator=g)
+    w = _rand((k, k, 3, Cout), dtype, g, (k * k * 3) ** -0.5)
+    geo = ops.stem_geometry(H, H, k, k, stride)
+    dy = _rand((V, geo['OH'], geo['OW'], Cout), dtype, g)
+    views = torch.cat(torch.split(img, 3, dim=3), 0).to(dtype)      # tf2/model.py:250-259
+    xr = views.double().permute(0, 3, 1, 2)
+    wr = w.double().requires_grad_(True)
+    pad = geo['pad']
+    pe = (k - 1) - pad
+    yr = F.conv2d(F.pad(xr, (pad, pe, pad, pe)), wr.permute(3, 2, 0, 1), stride=stride)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    xp = ops.pack_views(img.to(DEV), 2, geo, dtype)
+    w_s = ops.prep_weights(w.float().to(DEV), 2, dtype, geo['KHP'], geo['KWP'])
+    stats = ops.new_stats(Cout, DEV)
+    y = ops.stem_conv_fwd(xp, w_s, geo, stride, stats=stats)
+    sums = ops.bn_reduce_slots(stats)
+    dw = ops.stem_conv_wgrad(xp, dy.to(DEV), geo, k, k, stride)
+    torch.cuda.synchronize()
+    tag = 'V%d %d k%d s%d ->%d %s' % (V, H, k, stride, Cout, str(dtype).split('.')[-1])
+    t = _tol(dtype)
+    y_ref = yr.detach().permute(0, 2, 3, 1)
+    return [_res('stem_fwd ' + tag, y, y_ref, t),
+            _res('stem_stats_sq ' + tag, sums[1], (y_ref ** 2).sum((0, 1, 2)), 1e-4),
+            _res('stem_wgrad ' + tag, dw, wr.grad, 2e-5 if dtype == torch.float32 else 1e-4)]
+
+
+# ------------------------------------------------------------------ BN
+def check_bn(rows_shape, C, dtype, relu, residual, seed=0):
+    """residual: None | 'identity' | 'bn'"""
+    g = torch.Generator().manual_seed(seed)
+    shape = tuple(rows_shape) + (C,)
+    x = _rand(shape, dtype, g) * 2 + 0.5
+    gamma = (0.5 + torch.rand(C, generator=g))
+    beta = 0.1 * torch.randn(C, generator=g)
+    dy = _rand(shape, dtype, g)
+    res_t = _rand(shape, dtype, g) if residual else None
+    mm, mv = torch.zeros(C), torch.ones(C)
+    # reference (float64)
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    axes = tuple(range(len(shape) - 1))
+    mean = xr.mean(axes)
+    var = ((xr - mean) ** 2).mean(axes)
+    y = (xr - mean) * torch.rsqrt(var + 1e-5) * gr + br
+    rr = None
+    if residual == 'identity':
+        rr = res_t.double().requires_grad_(True)
+        y = y + rr
+    elif residual == 'bn':
+        rr = res_t.double().requires_grad_(True)
+        y = y + (rr * 1.5 - 0.25)
+    if relu:
+        y = F.relu(y)
+    y.backward(dy.double())
+    # device
+    xd = x.to(DEV)
+    m = x.numel() // C
+    xf = xd.float().view(-1, C)
+    part = ops.new_stats(C, DEV)
+    part[0, 0] = xf.double().sum(0).float()          # statistics normally come from the conv epilogue
+    part[0, 1] = (xf.double() ** 2).sum(0).float()
+    sums = ops.bn_reduce_slots(part)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    mmd, mvd = mm.to(DEV), mv.to(DEV)
+    mean_d, rstd_d, scale, shift = ops.bn_finalize(sums, m, gd, bd, mmd, mvd, 0.9)
+    rs = torch.full((C,), 1.5, device=DEV) if residual == 'bn' else None
+    rb = torch.full((C,), -0.25, device=DEV) if residual == 'bn' else None
+    yd = ops.bn_apply(xd, scale, shift, relu, res=res_t.to(DEV) if residual else None, rscale=rs, rshift=rb)
+    mask_mode = 1 if relu else 0
+    dyd = dy.to(DEV)
+    p = ops.bn_bwd_reduce(dyd, xd, yd, scale, shift, mean_d, rstd_d, mask_mode)
+    ls = ops.bn_reduce_slots(p)
+    dgamma = torch.zeros(C, device=DEV); dbeta = torch.zeros(C, device=DEV)
+    c1, c2 = ops.bn_bwd_finalize(ls, ls, m, dgamma, dbeta)
+    dx, dmask = ops.bn_bwd_apply(dyd, xd, yd, scale, shift, mean_d, rstd_d, c1, c2, mask_mode, want_masked=True)
+    torch.cuda.synchronize()
+    tag = '%s C%d %s relu=%d res=%s' % ('x'.join(map(str, rows_shape)), C, str(dtype).split('.')[-1], relu, residual)
+    t = _tol(dtype)
+    out = [_res('bn_apply ' + tag, yd, y.detach(), t, 1e-6),
+           _res('bn_moving_mean ' + tag, mmd, 0.1 * mean.detach(), 1e-5, 1e-7),
+           _res('bn_moving_var ' + tag, mvd, 0.9 + 0.1 * var.detach(), 1e-5),
+           _res('bn_dgamma ' + tag, dgamma, gr.grad, 2e-4 if dtype == torch.float32 else 2e-3),
+           _res('bn_dbeta ' + tag, dbeta, br.grad, 2e-4 if dtype == torch.float32 else 2e-3),
+           _res('bn_dx ' + tag, dx, xr.grad, 5e-5 if dtype == torch.float32 else 1e-2)]
+    if residual == 'identity':
+        out.append(_res('bn_dmasked ' + tag, dmask, rr.grad, t))
+    return out
+
+
+def check_pool(V, H, C, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = _rand((V, H, H, C), dtype, g)
+    scale = (torch.rand(C, generator=g) - 0.3)          # some negative scales on purpose
+    shift = 0.2 * torch.randn(C, generator=g)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    a = F.relu(xr * scale.double().view(1, C, 1, 1) + shift.double().view(1, C, 1, 1))
+    OH, pt = ops.same_pad(H, 3, 2)
+    total = max((OH - 1) * 2 + 3 - H, 0)
+    pr = F.max_pool2d(F.pad(a, (pt, total - pt, pt, total - pt), value=float('-inf')), 3, 2)
+    dy = _rand((V, OH, OH, C), dtype, g)
+    pr.backward(dy.double().permute(0, 3, 1, 2))
+    d_act_ref = (xr.grad / torch.where(scale == 0, torch.ones_like(scale), scale).double().view(1, C, 1, 1))
+    y, arg = ops.bnrelu_maxpool_fwd(x.to(DEV), scale.to(DEV), shift.to(DEV))
+    da = ops.maxpool_bwd(dy.to(DEV), arg, H, H)
+    # avg pool
+    p = ops.global_avgpool_fwd(x.to(DEV))
+    dp = _rand((V, C), dtype, g)
+    dxa = ops.global_avgpool_bwd(dp.to(DEV), H, H)
+    torch.cuda.synchronize()
+    tag = 'V%d %d C%d %s' % (V, H, C, str(dtype).split('.')[-1])
+    t = _tol(dtype)
+    # d_act: gradient wrt the ReLU output routed to the argmax; compare where the ReLU is active
+    act = (a.detach() > 0).permute(0, 2, 3, 1)
+    da_ref = torch.where(act, d_act_ref.permute(0, 2, 3, 1), torch.zeros(1, dtype=torch.float64))
+    da_got = torch.where(act, da.double().cpu(), torch.zeros(1, dtype=torch.float64))
+    return [_res('maxpool_fwd ' + tag, y, pr.detach().permute(0, 2, 3, 1), t, 1e-6),
+            _res('maxpool_bwd ' + tag, da_got, da_ref, t, 1e-6),
+            _res('avgpool_fwd ' + tag, p, x.double().mean((1, 2)), t, 1e-6),
+            _res('avgpool_bwd ' + tag, dxa, (dp.double() / (H * H))[:, None, None, :].expand(V, H, H, C), t, 1e-7)]
+
+
+def check_sup_head(rows, nclass, cpad, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    z = _rand((rows, cpad), dtype, g) * 3
+    bias = 0.1 * torch.randn(nclass, generator=g)
+    labels = torch.randint(0, nclass, (rows // 2,), generator=g).int()
+    lab2 = torch.cat([labels, labels]).long()
+    zr = (z.double()[:, :nclass] + bias.double()).requires_grad_(True)
+    loss = F.cross_entropy(zr, lab2)
+    loss.backward()
+    out = torch.zeros(2, device=DEV)
+    dl = ops.bias_softmax_xent(z.to(DEV), bias.to(DEV), labels.to(DEV), nclass, 1.0, out)
+    db = torch.zeros(nclass, device=DEV)
+    ops.colsum(dl, nclass, db)
+    torch.cuda.synchronize()
+    acc = (zr.argmax(1) == lab2).double().mean()
+    tag = '%dx%d(%d) %s' % (rows, nclass, cpad, str(dtype).split('.')[-1])
+    t = _tol(dtype)
+    return [_res('sup_loss ' + tag, out[0], loss.detach(), 1e-5),
+            _res('sup_acc ' + tag, out[1], acc, 0, 1e-6),
+            _res('sup_dlogits ' + tag, dl[:, :nclass], zr.grad, t, 1e-7),
+            _res('sup_dlogits_pad ' + tag, dl[:, nclass:], torch.zeros(rows, cpad - nclass), 0, 0),
+            _res('sup_dbias ' + tag, db, zr.grad.sum(0), 10 * t, 1e-6)]
