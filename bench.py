@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Benchmark of the SimCLR pretraining step on MI355X (BASELINE.json metric: images/sec).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one full pretraining step (tf2/run.py:557-622): two-view ResNet-50 1x forward +
+backward at 224 px, projection head, NT-Xent, linear-eval head, LARS -- on a synthetic batch that
+is resident in HBM before the timed region.  One "image" = one dataset image = two views
+(BASELINE.md).  Per-GPU batch is fixed at 512 images (BASELINE.json configs[1] at N=1,
+configs[2] = global 4096 at N=8) => weak scaling; `value` = global_batch * K / max-over-ranks time.
+
+The JSON line also carries:
+  roofline      -- the dominant kernel family measured LIVE with HIP events on the launch stream
+                   inside the timed region: algorithmic FLOPs (2*M*N*K per launch)
+                   / summed launch time, against the bf16 dense MFMA peak (2.5 PFLOP/s).
+  cpu_baseline  -- the CPU oracle (torch-CPU restatement of the TF2 reference; TensorFlow is not
+                   installed) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+FLOP_PER_IMAGE = 49.15e9    # 2 views x (fwd+dgrad+wgrad), encoder + head
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Time the oracle's full training step (same R50/224 step, small batch) on the host cores."""
+    from collections import OrderedDict
+    from oracle.model_torch import Config, init_model, train_step
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    cfg = Config(resnet_depth=50, image_size=224, num_classes=1000)
+    params, state = init_model(cfg, seed=2)
+    momenta = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+    b = 8
+    images = torch.rand(b, 224, 224, 6)
+    labels = torch.nn.functional.one_hot(torch.randint(0, 1000, (b,)), 1000).float()
+    train_step(cfg, params, state, momenta, images, labels, 0.1)       # warm-up (allocator, MKL init)
+    n, t0 = 0, time.time()
+    while True:
+        train_step(cfg, params, state, momenta, images, labels, 0.1)
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.6 or n >= 4:
+            break
+    dt = time.time() - t0
+    return dict(value=round(b * n / dt, 3), unit='images/s', cores=cores, kind='port',
+                sample='%d full train steps of the same ResNet-50 1x @224 step at batch %d '
+                       '(torch-CPU fp32 restatement of tf2/, %.1f s)' % (n, b, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--per_gpu_batch', type=int, default=512)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--resnet_depth', type=int, default=50)
+    ap.add_argument('--image_size', type=int, default=224)
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_kernel_events', action='store_true')
+    args = ap.parse_args()
+
+    from simclr_amd import model as model_lib
+    from simclr_amd import ops
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    from simclr_amd.run import init_distributed, make_single_step, synthetic_batches
+
+    strategy = init_distributed()
+    world = 1 if strategy is None else strategy.num_replicas_in_sync
+    rank = 0 if strategy is None else strategy.rank
+    assert world == args.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    global_batch = args.per_gpu_batch * world
+    FLAGS.reset()
+    FLAGS.update(resnet_depth=args.resnet_depth, width_multiplier=1, image_size=args.image_size,
+                 train_batch_size=global_batch, compute_dtype=args.dtype, use_blur=False,
+                 learning_rate=0.075, learning_rate_scaling='sqrt', weight_decay=1e-6,
+                 temperature=0.1, hidden_norm=True, global_bn=True, lineareval_while_pretraining=True)
+    RT.reset()
+    RT.strategy = strategy
+    RT.device = dev
+    num_classes = 1000
+    model = model_lib.Model(num_classes)
+    schedule = model_lib.WarmUpAndCosineDecay(FLAGS.learning_rate, 1281167)
+    optimizer = model_lib.build_optimizer(schedule)
+    optimizer.iterations = 1000   # past step 0 so the warm-up LR is non-zero (weights really move)
+    step_fn = make_single_step(model, optimizer, strategy)
+    data = synthetic_batches(args.per_gpu_batch, args.image_size, num_classes, dev, seed=rank)
+
+    def sync():
+        if strategy is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        f, l = next(data)
+        step_fn(f, l)
+    sync()
+    prof = None
+    if not args.no_kernel_events:
+        prof = ops.KernelProfiler()
+        ops.PROFILER = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        f, l = next(data)
+        step_fn(f, l)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILER = None
+    if strategy is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = global_batch * args.steps / elapsed
+    metrics = {k: v.result() for k, v in step_fn.metrics.items()}
+
+    if rank != 0:
+        return
+    peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
+    roofline = None
+    kernels = {}
+    if prof is not None:
+        summ = prof.summary()
+        for fam, d in summ.items():
+            kernels[fam] = dict(launches_per_step=d['launches'] // args.steps,
+                                ms_per_step=round(d['ms'] / args.steps, 3),
+                                tflops=round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2) if d['ms'] > 0 else None,
+                                alg_gbps=round(d['bytes'] / (d['ms'] * 1e-3) / 1e9, 1) if d['ms'] > 0 else None)
+        # dominant family = most GPU time; the fwd and dgrad launches are the same kernel template
+        fams = {'conv_igemm': [k for k in summ if k.startswith('conv_igemm')], 'conv_wgrad': ['conv_wgrad']}
+        best, best_ms = None, -1.0
+        for name, members in fams.items():
+            ms = sum(summ[m]['ms'] for m in members if m in summ)
+            if ms > best_ms:
+                best, best_ms = name, ms
+        members = [m for m in fams[best] if m in summ]
+        fl = sum(summ[m]['flops'] for m in members)
+        nl = sum(summ[m]['launches'] for m in members)
+        achieved = fl / (best_ms * 1e-3) / 1e12 if best_ms > 0 else 0.0
+        roofline = dict(bound='mfma', kernel=best, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
+                        frac=round(achieved / peak, 4), traffic=None,
+                        avg_launch_us=round(best_ms * 1e3 / max(nl, 1), 2),
+                        flops_per_launch_avg=fl / max(nl, 1), launches_per_step=nl // args.steps,
+                        ms_per_step=round(best_ms / args.steps, 3))
+    line = {
+        'metric': 'images/sec (whole node), ResNet-50 1x SimCLR pretraining step @224px',
+        'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+        'data': 'synthetic',
+        'config': {'workload': 'ResNet-%d 1x, %dx%d, 2 views/image, per-GPU batch %d, global batch %d, '
+                               'NT-Xent T=0.1 + linear-eval head + LARS, global BN, dp%d'
+                               % (args.resnet_depth, args.image_size, args.image_size, args.per_gpu_batch,
+                                  global_batch, world),
+                   'global_batch': global_batch, 'parallelism': 'dp%d' % world},
+        'step_mfma_frac': round(value * FLOP_PER_IMAGE / (world * peak * 1e12), 4)
+        if args.resnet_depth == 50 and args.image_size == 224 else None,
+        'roofline': roofline,
+        'kernels': kernels,
+        'train_metrics': {k: round(v, 5) for k, v in metrics.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline()
+    else:
+        line['cpu_baseline'] = None
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == '__main__':
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    main()
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -87,8 +87,13 @@ class Builder:
     order.  This keeps one definition of the layer sequence.
     """
 
-    def __init__(self, cfg, params=None, state=None, seed=0, randomize_bn=False, dtype=torch.float32):
+    def __init__(self, cfg, params=None, state=None, seed=0, randomize_bn=False, dtype=torch.float32,
+                 emulate_bf16=False):
         self.cfg = cfg
+        # emulate_bf16: round weights and every stored activation to bfloat16 (straight-through in
+        # backward) -- NOT reference behaviour; used only to calibrate how much drift a bf16-storage
+        # implementation is expected to show against the exact restatement.
+        self.q = (lambda t: t + (t.detach().bfloat16().to(t.dtype) - t.detach())) if emulate_bf16 else (lambda t: t)
         self.init = params is None
         self.params = OrderedDict() if params is None else params   # trainable
         self.state = OrderedDict() if state is None else state      # BN moving stats
@@ -140,7 +145,7 @@ class Builder:
         # strides>1: FixedPadding + VALID (:167-180,192-199); strides==1: SAME, which
         # for stride 1 pads (k-1)//2 before and the rest after -- the same numbers.
         x = F.pad(x, (beg, end, beg, end))
-        return F.conv2d(x, w.permute(3, 2, 0, 1), stride=strides)
+        return self.q(F.conv2d(x, self.q(w).permute(3, 2, 0, 1), stride=strides))
 
     def plain_conv1x1(self, x, filters):
         """Bare tf.keras.layers.Conv2D k=1 inside SK_Conv2D (tf2/resnet.py:243-256)."""
@@ -188,7 +193,8 @@ class Builder:
             y = y * gamma.view(shape)
         if beta is not None:
             y = y + beta.view(shape)
-        return F.relu(y) if relu else y
+        self._last_bn_pre_relu = y
+        return self.q(F.relu(y)) if relu else self.q(y)
 
     @staticmethod
     def _same_pad(size, k, s):
@@ -250,7 +256,7 @@ class Builder:
         x = self.conv2d_fixed_padding(x, filters, 3, 1)
         x = self.batch_norm_relu(x, relu=False, init_zero=True)
         self.scope.pop()
-        return F.relu(x + shortcut)
+        return self.q(F.relu(x + shortcut))
 
     def bottleneck_block(self, x, filters, strides, use_projection):
         """BottleneckBlock (tf2/resnet.py:385-487); DropBlock layers are identity."""
@@ -266,7 +272,7 @@ class Builder:
         x = self.conv2d_fixed_padding(x, 4 * filters, 1, 1)                  # :460-467
         x = self.batch_norm_relu(x, relu=False, init_zero=True)
         self.scope.pop()
-        return F.relu(x + shortcut)                                          # :487
+        return self.q(F.relu(x + shortcut))                                  # :487
 
     def resnet(self, x):
         """Resnet.call (tf2/resnet.py:683-699); x NHWC in, [B, C] out."""
@@ -301,7 +307,7 @@ class Builder:
                 x = block(x, f * w, 1, False)                                # :508-515
             self.scope.pop()
             self.endpoints['block_group%d' % (gi + 1)] = x
-        x = x.mean((2, 3))                                                   # :693-696
+        x = self.q(x.mean((2, 3)))                                           # :693-696
         self.endpoints['final_avg_pool'] = x
         self.scope.pop()
         return x
@@ -311,7 +317,7 @@ class Builder:
         self.scope.append(name)
         dense = self.namer('dense')
         w = self._dense_kernel(dense, x.shape[1], num_classes)
-        y = x @ w
+        y = self.q(x @ self.q(w))
         if use_bias and not use_bn:                                          # :146
             y = y + self._bias(dense, num_classes)
         if use_bn:
@@ -330,7 +336,7 @@ class Builder:
         for j in range(cfg.num_proj_layers):
             if j != cfg.num_proj_layers - 1:
                 y = self.linear_layer(hiddens[-1], hiddens[-1].shape[1], True, True, 'nl_%d' % j)
-                y = F.relu(y)                                                # :204-205
+                y = self.q(F.relu(y))                                        # :204-205
             else:
                 y = self.linear_layer(hiddens[-1], cfg.proj_out_dim, False, True, 'nl_%d' % j)
             hiddens.append(y)
@@ -341,7 +347,7 @@ class Builder:
         """Model.__call__ (tf2/model.py:241-280), train_mode='pretrain', use_blur=False."""
         self.training = training
         k = inputs.shape[3] // 3
-        feats = torch.cat(torch.split(inputs, 3, dim=3), 0)                  # :250-259
+        feats = self.q(torch.cat(torch.split(inputs, 3, dim=3), 0))          # :250-259
         self.scope.append('model')
         h = self.resnet(feats)                                               # :262
         proj, sup_in = self.projection_head(h)                               # :265-266
@@ -382,13 +388,13 @@ def torch_contrastive_loss(hidden, hidden_norm, temperature):
     return (loss_a + loss_b).mean(), lab, labels, hidden
 
 
-def single_step_losses(cfg, params, state, images, labels_onehot):
+def single_step_losses(cfg, params, state, images, labels_onehot, emulate_bf16=False):
     """Loss composition of tf2/run.py:577-617 for one replica (R=1).
 
     Returns dict with total loss tensor (differentiable), pieces, new BN state,
     the normalised embeddings and the endpoints.
     """
-    b = Builder(cfg, params=params, state=state)
+    b = Builder(cfg, params=params, state=state, emulate_bf16=emulate_bf16)
     proj, sup = b.model(images, training=True)
     con_loss, logits_con, labels_con, z = torch_contrastive_loss(proj, cfg.hidden_norm, cfg.temperature)
     loss = con_loss
@@ -412,12 +418,12 @@ def single_step_losses(cfg, params, state, images, labels_onehot):
     return out
 
 
-def train_step(cfg, params, state, momenta, images, labels_onehot, learning_rate):
+def train_step(cfg, params, state, momenta, images, labels_onehot, learning_rate, emulate_bf16=False):
     """One full tf2/run.py:557-622 step on CPU (R=1): forward, autograd backward,
     LARS (tf2/lars_optimizer.py:83-137 via torch ops, fp32).  Mutates nothing;
     returns (new_params, new_state, new_momenta, info)."""
     ps = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
-    out = single_step_losses(cfg, ps, state, images, labels_onehot)
+    out = single_step_losses(cfg, ps, state, images, labels_onehot, emulate_bf16=emulate_bf16)
     total = out['total_loss']                                                # / R with R = 1
     grads = torch.autograd.grad(total, list(ps.values()), allow_unused=True)
     exclude = ['batch_normalization', 'bias', 'head_supervised']             # tf2/model.py:39-41

@@ -1,0 +1,99 @@
+"""absl.flags-compatible shim carrying every flag of /root/reference/tf2/run.py:37-238.
+
+The reference reads a global `FLAGS` inside library code (tf2/resnet.py:50,56,...;
+tf2/model.py:31-41,...).  absl is not installed here, so this module provides the same
+spellings, defaults and `--name=value` / `--noname` command-line syntax behind a
+module-level `FLAGS` namespace.  TPU flags are accepted and ignored.
+"""
+import argparse
+
+_DEFS = [
+    # (name, default, type, help)                                      tf2/run.py line
+    ('learning_rate', 0.3, float, 'Initial learning rate per batch size of 256.'),      # :37
+    ('learning_rate_scaling', 'linear', str, "How to scale the learning rate: 'linear' or 'sqrt'."),  # :41
+    ('warmup_epochs', 10, float, 'Number of epochs of warmup.'),                         # :45
+    ('weight_decay', 1e-6, float, 'Amount of weight decay to use.'),                     # :49
+    ('batch_norm_decay', 0.9, float, 'Batch norm decay parameter.'),                     # :51
+    ('train_batch_size', 512, int, 'Batch size for training.'),                          # :55
+    ('train_split', 'train', str, 'Split for training.'),                                # :59
+    ('train_epochs', 100, int, 'Number of epochs to train for.'),                        # :63
+    ('train_steps', 0, int, 'Number of steps to train for. If provided, overrides train_epochs.'),  # :67
+    ('eval_steps', 0, int, 'Number of steps to eval for.'),                              # :71
+    ('eval_batch_size', 256, int, 'Batch size for eval.'),                               # :75
+    ('checkpoint_epochs', 1, int, 'Number of epochs between checkpoints/summaries.'),    # :79
+    ('checkpoint_steps', 0, int, 'Number of steps between checkpoints/summaries.'),      # :83
+    ('eval_split', 'validation', str, 'Split for evaluation.'),                          # :88
+    ('dataset', 'imagenet2012', str, 'Name of a dataset.'),                              # :92
+    ('cache_dataset', False, bool, 'Whether to cache the entire dataset in memory.'),    # :96
+    ('mode', 'train', str, "'train', 'eval' or 'train_then_eval'."),                     # :102
+    ('train_mode', 'pretrain', str, "'pretrain' or 'finetune'."),                        # :106
+    ('lineareval_while_pretraining', True, bool, 'Whether to finetune supervised head while pretraining.'),  # :110
+    ('checkpoint', None, str, 'Loading from the given checkpoint for fine-tuning.'),     # :113
+    ('zero_init_logits_layer', False, bool, 'If True, zero initialize layers after avg_pool.'),  # :118
+    ('fine_tune_after_block', -1, int, 'Layers after this block are fine-tuned.'),       # :122
+    ('master', None, str, 'Address/name of the TensorFlow master (ignored).'),           # :128
+    ('model_dir', None, str, 'Model directory for training.'),                           # :133
+    ('data_dir', None, str, 'Directory where dataset is stored.'),                       # :137
+    ('use_tpu', True, bool, 'Ignored (MI355X build).'),                                  # :141
+    ('tpu_name', None, str, 'Ignored.'),                                                 # :145
+    ('tpu_zone', None, str, 'Ignored.'),                                                 # :151
+    ('gcp_project', None, str, 'Ignored.'),                                              # :157
+    ('optimizer', 'lars', str, "'momentum', 'adam' or 'lars'."),                         # :163
+    ('momentum', 0.9, float, 'Momentum parameter.'),                                     # :167
+    ('eval_name', None, str, 'Name for eval.'),                                          # :171
+    ('keep_checkpoint_max', 5, int, 'Maximum number of checkpoints to keep.'),           # :175
+    ('keep_hub_module_max', 1, int, 'Maximum number of Hub modules to keep.'),           # :179
+    ('temperature', 0.1, float, 'Temperature parameter for contrastive loss.'),          # :183
+    ('hidden_norm', True, bool, 'Temperature parameter for contrastive loss.'),          # :187
+    ('proj_head_mode', 'nonlinear', str, "'none', 'linear', 'nonlinear'."),              # :191
+    ('proj_out_dim', 128, int, 'Number of head projection dimension.'),                  # :195
+    ('num_proj_layers', 3, int, 'Number of non-linear head layers.'),                    # :199
+    ('ft_proj_selector', 0, int, 'Which layer of the projection head to use during fine-tuning.'),  # :203
+    ('global_bn', True, bool, 'Whether to aggregate BN statistics across distributed cores.'),  # :208
+    ('width_multiplier', 1, int, 'Multiplier to change width of network.'),              # :212
+    ('resnet_depth', 50, int, 'Depth of ResNet.'),                                       # :216
+    ('sk_ratio', 0., float, 'If it is bigger than 0, it will enable SK.'),               # :220
+    ('se_ratio', 0., float, 'If it is bigger than 0, it will enable SE.'),               # :224
+    ('image_size', 224, int, 'Input image size.'),                                       # :228
+    ('color_jitter_strength', 1.0, float, 'The strength of color jittering.'),           # :232
+    ('use_blur', True, bool, 'Whether or not to use Gaussian blur for augmentation during pretraining.'),  # :236
+    # build-specific (not in the reference)
+    ('compute_dtype', 'bf16', str, "MI355X build: activation/compute dtype, 'bf16' (speed) or 'f32' (parity)."),
+]
+
+
+class _Flags:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        for name, default, _, _ in _DEFS:
+            setattr(self, name, default)
+
+    def flag_values_dict(self):
+        return {name: getattr(self, name) for name, _, _, _ in _DEFS}
+
+    def update(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError('Unknown flag %r' % k)
+            setattr(self, k, v)
+        return self
+
+    def parse(self, argv):
+        """absl-style parsing: --name=value, --name value, --flag / --noflag for booleans."""
+        p = argparse.ArgumentParser(allow_abbrev=False)
+        for name, default, typ, hlp in _DEFS:
+            if typ is bool:
+                p.add_argument('--' + name, nargs='?', const=True, default=default,
+                               type=lambda s: str(s).lower() in ('1', 'true', 't', 'yes', 'y'), help=hlp)
+                p.add_argument('--no' + name, dest=name, action='store_false', help=argparse.SUPPRESS)
+            else:
+                p.add_argument('--' + name, default=default, type=typ, help=hlp)
+        ns = p.parse_args(argv)
+        for name, _, _, _ in _DEFS:
+            setattr(self, name, getattr(ns, name))
+        return self
+
+
+FLAGS = _Flags()

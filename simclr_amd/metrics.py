@@ -1,0 +1,70 @@
+"""Training metrics -- mirror of /root/reference/tf2/metrics.py for the pretraining step.
+
+`Mean` stands in for tf.keras.metrics.Mean (running mean, `update_state` / `result` /
+`reset_states`); values stay on the device until `result()` so the step never syncs.
+"""
+import logging
+
+import torch
+
+
+class Mean:
+    def __init__(self, name):
+        self.name = name
+        self.reset_states()
+
+    def reset_states(self):
+        self._sum = None
+        self._count = 0
+
+    def update_state(self, value):
+        if hasattr(value, 'value'):
+            value = value.value
+        if not torch.is_tensor(value):
+            value = torch.tensor(float(value))
+        v = value.detach().reshape(-1)[:1].clone()
+        self._sum = v if self._sum is None else self._sum + v.to(self._sum.device)
+        self._count += 1
+
+    def result(self):
+        if self._count == 0:
+            return 0.0
+        return float(self._sum.item()) / self._count
+
+
+def update_pretrain_metrics_train(contrast_loss, contrast_acc, contrast_entropy, loss, logits_con, labels_con):
+    """Updated pretraining metrics (tf2/metrics.py:23-36).  The accuracy (argmax(labels) ==
+    argmax(logits_ab), :28-31) and the entropy of softmax(logits_ab) (:33-35) come fused out of
+    the loss kernels when `logits_con` is the lazy handle."""
+    contrast_loss.update_state(loss)
+    if hasattr(logits_con, 'contrast_acc'):
+        contrast_acc.update_state(logits_con.contrast_acc)
+        contrast_entropy.update_state(logits_con.contrast_entropy)
+        return
+    acc = (labels_con.argmax(1) == logits_con.argmax(1)).float().mean()
+    contrast_acc.update_state(acc)
+    p = torch.softmax(logits_con, -1)
+    contrast_entropy.update_state(-(p * torch.log(p + 1e-8)).sum(-1).mean())
+
+
+def update_finetune_metrics_train(supervised_loss_metric, supervised_acc_metric, loss, labels, logits):
+    """tf2/metrics.py:49-55."""
+    supervised_loss_metric.update_state(loss)
+    if hasattr(loss, 'acc'):
+        supervised_acc_metric.update_state(loss.acc)
+        return
+    acc = (labels.argmax(1) == logits.argmax(1)).float().mean()
+    supervised_acc_metric.update_state(acc)
+
+
+def _float_metric_value(metric):
+    return float(metric.result())
+
+
+def log_and_write_metrics_to_summary(all_metrics, global_step, writer=None):
+    """tf2/metrics.py:70-74: log every metric; `writer` (optional) is a callable(name, value, step)."""
+    for metric in all_metrics:
+        metric_value = _float_metric_value(metric)
+        logging.info('Step: [%d] %s = %f', global_step, metric.name, metric_value)
+        if writer is not None:
+            writer(metric.name, metric_value, global_step)

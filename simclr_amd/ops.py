@@ -13,6 +13,42 @@ from ._lib import DT_BF16, DT_F32, lib
 NSLOT = 32  # partial-statistics slots (spreads atomic contention; summed by bn_reduce_slots)
 
 
+class KernelProfiler:
+    """Live per-launch timing with HIP events on the launch stream (torch's current stream is the
+    stream every kernel here is enqueued on).  Used by bench.py for the roofline object."""
+
+    def __init__(self):
+        self.records = []   # (family, flops, bytes, start_event, end_event)
+
+    def launch(self, family, flops, nbytes, fn):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.records.append((family, flops, nbytes, a, b))
+        return r
+
+    def summary(self):
+        out = {}
+        for fam, fl, by, a, b in self.records:
+            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d['launches'] += 1
+            d['ms'] += a.elapsed_time(b)
+            d['flops'] += fl
+            d['bytes'] += by
+        return out
+
+
+PROFILER = None
+
+
+def _launch(family, flops, nbytes, fn):
+    if PROFILER is None:
+        return fn()
+    return PROFILER.launch(family, flops, nbytes, fn)
+
+
 def dt(t):
     if t.dtype == torch.float32:
         return DT_F32
@@ -103,8 +139,11 @@ def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None):
     Cout = w_t.shape[0]
     if out is None:
         out = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
-    lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), NSLOT if stats is not None else 0, V, IH, IW, Cin,
-                     OH, OW, Cout, KH, KW, stride, pad, dt(x), _s())
+    M, K = V * OH * OW, KH * KW * Cin
+    esz = x.element_size()
+    _launch('conv_igemm_fwd', 2.0 * M * K * Cout, esz * (V * IH * IW * Cin + M * Cout + K * Cout),
+            lambda: lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), NSLOT if stats is not None else 0, V,
+                                     IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
     return out
 
 
@@ -114,8 +153,11 @@ def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=Fals
     if out is None:
         assert not accumulate
         out = torch.empty(V, IH, IW, Cin, device=dy.device, dtype=dy.dtype)
-    lib().conv2d_dgrad(_p(dy), _p(w_d), _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout, KH, KW,
-                       stride, pad, dt(dy), _s())
+    M, K = V * IH * IW, KH * KW * Cout
+    esz = dy.element_size()
+    _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + M * Cin + K * Cin),
+            lambda: lib().conv2d_dgrad(_p(dy), _p(w_d), _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout,
+                                       KH, KW, stride, pad, dt(dy), _s()))
     return out
 
 
@@ -142,8 +184,11 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad, Cin=None, pixpitch=None, out=None, 
         out = torch.empty(KH * KW * Cin, Cout, device=x.device, dtype=torch.float32)
     nbytes = lib().conv2d_wgrad_workspace_bytes(V, OH, OW, Cin, Cout, KH, KW, dt(x))
     ws = _workspace(nbytes, x.device)
-    lib().conv2d_wgrad(_p(x), _p(dy), _p(out), int(accumulate), _p(ws), V, IH, IW, Cin, pixpitch, OH, OW,
-                       Cout, KH, KW, stride, pad, dt(x), _s())
+    M, K = V * OH * OW, KH * KW * Cin
+    esz = x.element_size()
+    _launch('conv_wgrad', 2.0 * M * K * Cout, esz * (V * IH * IW * pixpitch + M * Cout) + 4 * K * Cout,
+            lambda: lib().conv2d_wgrad(_p(x), _p(dy), _p(out), int(accumulate), _p(ws), V, IH, IW, Cin, pixpitch,
+                                       OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
     return out
 
 
@@ -174,8 +219,11 @@ def stem_conv_fwd(xp, w_s, geo, stride, stats=None):
     V = xp.shape[0]
     Cout = w_s.shape[0]
     y = torch.empty(V, geo['OH'], geo['OW'], Cout, device=xp.device, dtype=xp.dtype)
-    lib().stem_conv_fwd(_p(xp), _p(w_s), _p(y), _p(stats), NSLOT if stats is not None else 0, V, geo['HP'],
-                        geo['WP'], geo['OH'], geo['OW'], Cout, geo['KHP'], geo['KWP'], stride, dt(xp), _s())
+    M = V * geo['OH'] * geo['OW']
+    _launch('stem_conv_fwd', 2.0 * M * 147 * Cout, xp.element_size() * (xp.numel() + M * Cout),
+            lambda: lib().stem_conv_fwd(_p(xp), _p(w_s), _p(y), _p(stats), NSLOT if stats is not None else 0, V,
+                                        geo['HP'], geo['WP'], geo['OH'], geo['OW'], Cout, geo['KHP'], geo['KWP'],
+                                        stride, dt(xp), _s()))
     return y
 
 

@@ -1,0 +1,536 @@
+"""ResNet encoder -- drop-in mirror of /root/reference/tf2/resnet.py on the HIP kernels.
+
+Same public surface as the reference module: `resnet(resnet_depth, width_multiplier,
+cifar_stem, data_format, dropblock_keep_probs, dropblock_size)` returns a `Resnet` whose
+`__call__(inputs, training)` maps NHWC images to [B, 2048*w] (512*w for depth 18/34);
+classes `BatchNormRelu`, `Conv2dFixedPadding`, `ResidualBlock`, `BottleneckBlock`,
+`BlockGroup` keep the reference's constructor arguments.  There is no autodiff here:
+every layer also has a hand-written `backward` (what `tape.gradient`, tf2/run.py:621,
+derives), driven in reverse by `Resnet.backward`.
+
+MI355X-first differences (numerically equivalent to the reference graph):
+  * conv epilogues emit the BatchNorm statistics, so BN never re-reads its input for them;
+  * the block tail `relu(bn(x) + shortcut)` (resnet.py:382,487) and the projection
+    shortcut's BN apply are one fused elementwise pass;
+  * stem BN + ReLU + max-pool (resnet.py:602-611) are one pass over the stem output;
+  * the 3-channel input is packed once (pad + view split, tf2/model.py:250-259) so the
+    stem conv needs no bounds checks.
+Not built in this round (fail loudly): SK (sk_ratio>0, resnet.py:217-277), SE
+(se_ratio>0, :280-311), DropBlock (:81-157, unreachable in the reference too),
+channels_first.
+"""
+import math
+
+import torch
+
+from . import ops
+from .comm import num_replicas
+from .flags import FLAGS
+from .lars_optimizer import Variable
+
+BATCH_NORM_EPSILON = 1e-5  # tf2/resnet.py:28
+
+
+# --------------------------------------------------------------------------- runtime context
+class _Runtime:
+    """Process-wide build context (the stand-in for Keras name scopes + tf.distribute scope)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.counters = {}
+        self.scope = []
+        self.strategy = None
+        self.device = 'cuda'
+        self.seed = 0
+        self.weights_version = 0     # bumped by the optimizer step; compute copies refresh lazily
+
+    def unique(self, base):
+        i = self.counters.get(base, 0)
+        self.counters[base] = i + 1
+        return base if i == 0 else '%s_%d' % (base, i)
+
+    def path(self, *leaves):
+        return '/'.join(self.scope + list(leaves))
+
+    @property
+    def dtype(self):
+        return torch.bfloat16 if FLAGS.compute_dtype == 'bf16' else torch.float32
+
+
+RT = _Runtime()
+
+
+class scope:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        RT.scope.append(self.name)
+
+    def __exit__(self, *a):
+        RT.scope.pop()
+
+
+class Act:
+    """An activation tensor plus (optionally) the fused per-channel statistics partials."""
+    __slots__ = ('t', 'stats')
+
+    def __init__(self, t, stats=None):
+        self.t = t
+        self.stats = stats
+
+
+class PackedInput:
+    """The k views of the input batch, packed by simclr_pack_views for the stem conv."""
+
+    def __init__(self, images, num_views, kernel_size, strides, dtype):
+        b, H, W, _ = images.shape
+        self.geo = ops.stem_geometry(H, W, kernel_size, kernel_size, strides)
+        self.H, self.W = H, W
+        self.xp = ops.pack_views(images, num_views, self.geo, dtype)
+        self.V = num_views * b
+
+
+class Layer:
+    trainable = True
+
+    def sublayers(self):
+        out = []
+        for v in self.__dict__.values():
+            if isinstance(v, Layer):
+                out.append(v)
+            elif isinstance(v, (list, tuple)):
+                out.extend(x for x in v if isinstance(x, Layer))
+        return out
+
+    @property
+    def variables(self):
+        vs = [v for v in self.__dict__.values() if isinstance(v, Variable)]
+        for l in self.sublayers():
+            vs.extend(l.variables)
+        return vs
+
+    @property
+    def trainable_variables(self):
+        return [v for v in self.variables if v.trainable]
+
+
+def _variance_scaling(shape, fan_in, gen):
+    """tf.keras.initializers.VarianceScaling() defaults (tf2/resnet.py:201): truncated normal,
+    stddev = sqrt(1/fan_in)/.87962566103423978, resampled outside 2 sigma."""
+    std = math.sqrt(1.0 / fan_in) / .87962566103423978
+    w = torch.empty(shape, dtype=torch.float32)
+    torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+    return w * std
+
+
+def _gen():
+    RT.seed += 1
+    return torch.Generator().manual_seed(RT.seed)
+
+
+# --------------------------------------------------------------------------- BatchNormRelu
+class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
+    def __init__(self, relu=True, init_zero=False, center=True, scale=True,
+                 data_format='channels_last', **kwargs):
+        if data_format != 'channels_last':
+            raise ValueError('MI355X build supports channels_last only')
+        self.relu = relu
+        self.init_zero = init_zero
+        self.center = center
+        self.scale = scale
+        self.trainable = kwargs.get('trainable', True)
+        outer = RT.unique('batch_norm_relu')
+        bn = RT.unique('sync_batch_normalization' if FLAGS.global_bn else 'batch_normalization')
+        self._base = RT.path(outer, bn)
+        self.gamma = self.beta = self.moving_mean = self.moving_variance = None
+        self.saved = None
+
+    def build(self, C):
+        dev = RT.device
+        if self.scale:
+            g = torch.zeros(C) if self.init_zero else torch.ones(C)     # :42-45
+            self.gamma = Variable(self._base + '/gamma:0', g.to(dev), self.trainable)
+        if self.center:
+            self.beta = Variable(self._base + '/beta:0', torch.zeros(C, device=dev), self.trainable)
+        self.moving_mean = Variable(self._base + '/moving_mean:0', torch.zeros(C, device=dev), False)
+        self.moving_variance = Variable(self._base + '/moving_variance:0', torch.ones(C, device=dev), False)
+
+    def prepare(self, inputs, training):
+        """Statistics -> (mean, rstd, scale, shift); moving-average update when training."""
+        x = inputs.t
+        C = x.shape[-1]
+        if self.moving_mean is None:
+            self.build(C)
+        g = self.gamma.value if self.gamma is not None else None
+        b = self.beta.value if self.beta is not None else None
+        rows = x.numel() // C
+        if training:
+            if inputs.stats is None:
+                raise NotImplementedError('BatchNormRelu input must come from a conv/dense epilogue')
+            sums = ops.bn_reduce_slots(inputs.stats)
+            R = num_replicas(RT.strategy)
+            count = rows
+            if FLAGS.global_bn and R > 1:            # SyncBatchNormalization, :50-60
+                RT.strategy.all_reduce_sum(sums)
+                count = rows * R
+            mean, rstd, scale, shift = ops.bn_finalize(sums, count, g, b, self.moving_mean.value,
+                                                       self.moving_variance.value, FLAGS.batch_norm_decay,
+                                                       BATCH_NORM_EPSILON)
+        else:
+            mean = self.moving_mean.value
+            rstd = torch.rsqrt(self.moving_variance.value + BATCH_NORM_EPSILON)
+            scale = rstd if g is None else g * rstd
+            shift = -mean * scale if b is None else b - mean * scale
+            count = rows
+        self.saved = dict(x=x, mean=mean, rstd=rstd, scale=scale, shift=shift, count=count, y=None)
+        return scale, shift
+
+    def __call__(self, inputs, training, relu=None, add=None, add_bn=None):
+        """BN (+ReLU).  `add` (a tensor) / `add_bn` ((scale, shift) of a projection shortcut) fuse
+        the residual tail relu(bn(x)+shortcut) of resnet.py:382,487 into the same pass."""
+        relu = self.relu if relu is None else relu
+        scale, shift = self.prepare(inputs, training)
+        rs, rb = add_bn if add_bn is not None else (None, None)
+        y = ops.bn_apply(inputs.t, scale, shift, relu, res=add, rscale=rs, rshift=rb)
+        self.saved['y'] = y
+        self.saved['masked'] = bool(relu)
+        return Act(y)
+
+    def backward(self, dy, mask_src=None, mask_mode=None, want_masked=False):
+        """dy: gradient wrt this layer's (activated) output.  Returns (dx, dy_masked)."""
+        s = self.saved
+        if mask_mode is None:
+            mask_mode = 1 if s.get('masked') else 0
+            mask_src = s['y'] if mask_mode == 1 else None
+        x = s['x']
+        part = ops.bn_bwd_reduce(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], mask_mode)
+        local = ops.bn_reduce_slots(part)
+        glob = local
+        R = num_replicas(RT.strategy)
+        if FLAGS.global_bn and R > 1:
+            glob = RT.strategy.all_reduce_sum(local.clone())
+        dgamma = self.gamma.ensure_grad() if self.gamma is not None and self.gamma.trainable else None
+        dbeta = self.beta.ensure_grad() if self.beta is not None and self.beta.trainable else None
+        c1, c2 = ops.bn_bwd_finalize(local, glob, s['count'], dgamma, dbeta)
+        dx, dmasked = ops.bn_bwd_apply(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2,
+                                       mask_mode, want_masked=want_masked)
+        self.saved = None
+        return dx, dmasked
+
+
+# --------------------------------------------------------------------------- convolution
+class FixedPadding(Layer):  # tf2/resnet.py:160-180 -- folded into the conv kernels' gather
+    def __init__(self, kernel_size, data_format='channels_last', **kwargs):
+        self.kernel_size = kernel_size
+
+
+class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
+    def __init__(self, filters, kernel_size, strides, data_format='channels_last', **kwargs):
+        if data_format != 'channels_last':
+            raise ValueError('MI355X build supports channels_last only')
+        self.filters = filters
+        self.kernel_size = kernel_size
+        self.strides = strides
+        self.trainable = kwargs.get('trainable', True)
+        outer = RT.unique('conv2d_fixed_padding')
+        inner = RT.unique('conv2d')
+        self._name = RT.path(outer, inner, 'kernel:0')
+        self.kernel = None
+        self._version = -1
+        self.saved = None
+
+    def build(self, cin):
+        k = self.kernel_size
+        w = _variance_scaling((k, k, cin, self.filters), k * k * cin, _gen())
+        self.kernel = Variable(self._name, w.to(RT.device), self.trainable)
+        self.cin = cin
+
+    def _refresh(self, stem_geo=None):
+        if self._version == RT.weights_version and getattr(self, '_dtype', None) == RT.dtype:
+            return
+        w = self.kernel.value
+        if stem_geo is not None:
+            self.w_s = ops.prep_weights(w, 2, RT.dtype, stem_geo['KHP'], stem_geo['KWP'])
+        else:
+            self.w_t = ops.prep_weights(w, 0, RT.dtype)
+            self.w_d = ops.prep_weights(w, 1, RT.dtype)
+        self._version = RT.weights_version
+        self._dtype = RT.dtype
+
+    def __call__(self, inputs, training, want_stats=True):
+        k, s = self.kernel_size, self.strides
+        if isinstance(inputs, PackedInput):
+            if self.kernel is None:
+                self.build(3)
+            self._refresh(inputs.geo)
+            stats = ops.new_stats(self.filters, RT.device) if (want_stats and training) else None
+            y = ops.stem_conv_fwd(inputs.xp, self.w_s, inputs.geo, s, stats=stats)
+            self.saved = dict(packed=inputs)
+            return Act(y, stats)
+        x = inputs.t
+        V, H, W, cin = x.shape
+        if self.kernel is None:
+            self.build(cin)
+        self._refresh()
+        pad = (k - 1) // 2                                  # FixedPadding / SAME at stride 1
+        OH = (H + (k - 1) - k) // s + 1
+        OW = (W + (k - 1) - k) // s + 1
+        stats = ops.new_stats(self.filters, RT.device) if (want_stats and training) else None
+        y = ops.conv2d_fwd(x, self.w_t, k, k, s, pad, OH, OW, stats=stats)
+        self.saved = dict(x=x, H=H, W=W, pad=pad)
+        return Act(y, stats)
+
+    def backward(self, dy, need_dx=True, dx_out=None, accumulate=False):
+        k, s = self.kernel_size, self.strides
+        sv = self.saved
+        self.saved = None
+        train_w = self.kernel.trainable
+        if 'packed' in sv:
+            if train_w:
+                pk = sv['packed']
+                g = self.kernel.ensure_grad()
+                ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, out=g)
+            return None
+        if train_w:
+            g = self.kernel.ensure_grad()
+            ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'], out=g.view(-1, self.filters))
+        if not need_dx:
+            return None
+        return ops.conv2d_dgrad(dy, self.w_d, k, k, s, sv['pad'], sv['H'], sv['W'], out=dx_out,
+                                accumulate=accumulate)
+
+
+class IdentityLayer(Layer):  # tf2/resnet.py:211-214
+    def __init__(self, name=None, **kwargs):
+        self.name = name
+
+    def __call__(self, inputs, training):
+        return inputs
+
+
+def _no_dropblock(keep_prob, size):
+    if keep_prob is not None and keep_prob != 1.0:
+        raise NotImplementedError('DropBlock (tf2/resnet.py:81-157) is not part of the hot path')
+
+
+# --------------------------------------------------------------------------- blocks
+class _Shortcut(Layer):
+    """Projection shortcut: Conv2dFixedPadding 1x1 (stride s) + BatchNormRelu(relu=False)
+    (tf2/resnet.py:339-349, 409-423).  The BN *apply* is deferred into the block's fused tail."""
+
+    def __init__(self, filters_out, strides, data_format):
+        if FLAGS.sk_ratio > 0:
+            raise NotImplementedError('ResNet-D shortcut (sk_ratio>0, tf2/resnet.py:330-338) not built yet')
+        self.conv = Conv2dFixedPadding(filters=filters_out, kernel_size=1, strides=strides,
+                                       data_format=data_format)
+        self.bn = BatchNormRelu(relu=False, data_format=data_format)
+
+    def __call__(self, inputs, training):
+        raw = self.conv(inputs, training)
+        scale, shift = self.bn.prepare(raw, training)
+        return raw.t, (scale, shift)
+
+    def backward(self, d_sum):
+        d_raw, _ = self.bn.backward(d_sum, mask_mode=0)
+        return self.conv.backward(d_raw)
+
+
+class ResidualBlock(Layer):  # tf2/resnet.py:314-382
+    def __init__(self, filters, strides, use_projection=False, data_format='channels_last',
+                 dropblock_keep_prob=None, dropblock_size=None, **kwargs):
+        del dropblock_keep_prob, dropblock_size          # :323-324
+        if FLAGS.se_ratio > 0:
+            raise NotImplementedError('SE_Layer (tf2/resnet.py:280-311) not built')
+        with scope(RT.unique('residual_block')):
+            self.shortcut = _Shortcut(filters, strides, data_format) if use_projection else None
+            self.conv1 = Conv2dFixedPadding(filters=filters, kernel_size=3, strides=strides, data_format=data_format)
+            self.bn1 = BatchNormRelu(data_format=data_format)
+            self.conv2 = Conv2dFixedPadding(filters=filters, kernel_size=3, strides=1, data_format=data_format)
+            self.bn2 = BatchNormRelu(relu=False, init_zero=True, data_format=data_format)
+
+    def __call__(self, inputs, training):
+        if self.shortcut is not None:
+            sc, sc_bn = self.shortcut(inputs, training)
+        else:
+            sc, sc_bn = inputs.t, None
+        h = self.bn1(self.conv1(inputs, training), training)
+        h = self.conv2(h, training)
+        out = self.bn2(h, training, relu=True, add=sc, add_bn=sc_bn)     # relu(inputs + shortcut), :382
+        self.out = out.t
+        return out
+
+    def backward(self, dout):
+        dh, dsum = self.bn2.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
+        self.out = None
+        dx = self.shortcut.backward(dsum) if self.shortcut is not None else dsum
+        da = self.conv2.backward(dh)
+        dh1, _ = self.bn1.backward(da)
+        self.conv1.backward(dh1, dx_out=dx, accumulate=True)
+        return dx
+
+
+class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
+    def __init__(self, filters, strides, use_projection=False, data_format='channels_last',
+                 dropblock_keep_prob=None, dropblock_size=None, **kwargs):
+        _no_dropblock(dropblock_keep_prob, dropblock_size)
+        if FLAGS.se_ratio > 0:
+            raise NotImplementedError('SE_Layer (tf2/resnet.py:280-311) not built')
+        if FLAGS.sk_ratio > 0:
+            raise NotImplementedError('SK_Conv2D (tf2/resnet.py:217-277) not built yet')
+        with scope(RT.unique('bottleneck_block')):
+            self.shortcut = _Shortcut(4 * filters, strides, data_format) if use_projection else None
+            self.conv1 = Conv2dFixedPadding(filters=filters, kernel_size=1, strides=1, data_format=data_format)
+            self.bn1 = BatchNormRelu(data_format=data_format)
+            self.conv2 = Conv2dFixedPadding(filters=filters, kernel_size=3, strides=strides, data_format=data_format)
+            self.bn2 = BatchNormRelu(data_format=data_format)
+            self.conv3 = Conv2dFixedPadding(filters=4 * filters, kernel_size=1, strides=1, data_format=data_format)
+            self.bn3 = BatchNormRelu(relu=False, init_zero=True, data_format=data_format)
+
+    def __call__(self, inputs, training):
+        if self.shortcut is not None:
+            sc, sc_bn = self.shortcut(inputs, training)
+        else:
+            sc, sc_bn = inputs.t, None
+        h = self.bn1(self.conv1(inputs, training), training)
+        h = self.bn2(self.conv2(h, training), training)
+        h = self.conv3(h, training)
+        out = self.bn3(h, training, relu=True, add=sc, add_bn=sc_bn)     # relu(inputs + shortcut), :487
+        self.out = out.t
+        return out
+
+    def backward(self, dout):
+        dh3, dsum = self.bn3.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
+        self.out = None
+        dx = self.shortcut.backward(dsum) if self.shortcut is not None else dsum
+        da2 = self.conv3.backward(dh3)
+        dh2, _ = self.bn2.backward(da2)
+        da1 = self.conv2.backward(dh2)
+        dh1, _ = self.bn1.backward(da1)
+        self.conv1.backward(dh1, dx_out=dx, accumulate=True)
+        return dx
+
+
+class BlockGroup(Layer):  # tf2/resnet.py:490-526
+    def __init__(self, filters, block_fn, blocks, strides, data_format='channels_last',
+                 dropblock_keep_prob=None, dropblock_size=None, **kwargs):
+        self._name = kwargs.get('name')
+        with scope(self._name):
+            self.layers = [block_fn(filters, strides, use_projection=True, data_format=data_format,
+                                    dropblock_keep_prob=dropblock_keep_prob, dropblock_size=dropblock_size)]
+            for _ in range(1, blocks):
+                self.layers.append(block_fn(filters, 1, data_format=data_format,
+                                            dropblock_keep_prob=dropblock_keep_prob,
+                                            dropblock_size=dropblock_size))
+
+    def __call__(self, inputs, training):
+        for layer in self.layers:
+            inputs = layer(inputs, training)
+        return inputs
+
+    def backward(self, d):
+        for layer in reversed(self.layers):
+            d = layer.backward(d)
+        return d
+
+
+class Resnet(Layer):  # tf2/resnet.py:529-699
+    def __init__(self, block_fn, layers, width_multiplier, cifar_stem=False, data_format='channels_last',
+                 dropblock_keep_probs=None, dropblock_size=None, **kwargs):
+        self.data_format = data_format
+        if dropblock_keep_probs is None:
+            dropblock_keep_probs = [None] * 4
+        if not isinstance(dropblock_keep_probs, list) or len(dropblock_keep_probs) != 4:
+            raise ValueError('dropblock_keep_probs is not valid:', dropblock_keep_probs)   # :546-547
+        if FLAGS.train_mode == 'finetune' and FLAGS.fine_tune_after_block != -1:
+            raise NotImplementedError('layer freezing (fine_tune_after_block) is outside the pretraining hot path')
+        if FLAGS.sk_ratio > 0:
+            raise NotImplementedError('ResNet-D stem / SK (sk_ratio>0, tf2/resnet.py:566-591) not built yet')
+        self.cifar_stem = cifar_stem
+        self.endpoints = {}
+        with scope('resnet'):
+            if cifar_stem:                                                       # :551-564
+                self.stem_conv = Conv2dFixedPadding(filters=64 * width_multiplier, kernel_size=3, strides=1,
+                                                    data_format=data_format)
+            else:                                                                # :593-599
+                self.stem_conv = Conv2dFixedPadding(filters=64 * width_multiplier, kernel_size=7, strides=2,
+                                                    data_format=data_format)
+            self.stem_bn = BatchNormRelu(data_format=data_format)                # :602-603
+            self.block_groups = []
+            for i, (f, s) in enumerate(zip([64, 128, 256, 512], [1, 2, 2, 2])):  # :620-668
+                self.block_groups.append(BlockGroup(filters=f * width_multiplier, block_fn=block_fn,
+                                                    blocks=layers[i], strides=s, name='block_group%d' % (i + 1),
+                                                    data_format=data_format,
+                                                    dropblock_keep_prob=dropblock_keep_probs[i],
+                                                    dropblock_size=dropblock_size))
+
+    @property
+    def stem_kernel_stride(self):
+        return (3, 1) if self.cifar_stem else (7, 2)
+
+    def __call__(self, inputs, training):
+        """inputs: PackedInput (from Model) or an NHWC float32 tensor [B,H,W,3]."""
+        if not isinstance(inputs, PackedInput):
+            k, s = self.stem_kernel_stride
+            inputs = PackedInput(inputs.contiguous(), 1, k, s, RT.dtype)
+        raw = self.stem_conv(inputs, training)
+        self.endpoints['initial_conv'] = raw.t
+        if self.cifar_stem:
+            x = self.stem_bn(raw, training)
+            self._pool = None
+        else:                                                                    # BN+ReLU+maxpool, :602-611
+            scale, shift = self.stem_bn.prepare(raw, training)
+            y, arg = ops.bnrelu_maxpool_fwd(raw.t, scale, shift, 3, 2)
+            self._pool = dict(arg=arg, H=raw.t.shape[1], W=raw.t.shape[2])
+            x = Act(y)
+        self.endpoints['initial_max_pool'] = x.t
+        for i, g in enumerate(self.block_groups):
+            x = g(x, training)
+            self.endpoints['block_group%d' % (i + 1)] = x.t
+        self._final = x.t
+        out = ops.global_avgpool_fwd(x.t)                                        # reduce_mean [1,2], :693-696
+        self.endpoints['final_avg_pool'] = out
+        return out
+
+    def backward(self, dh, on_stage=None):
+        """dh: [V, C] gradient wrt the pooled features.  on_stage(i) is called when block group
+        i (4..1) has finished its backward, and on_stage(0) after the stem (gradient bucketing)."""
+        _, H, W, _ = self._final.shape
+        d = ops.global_avgpool_bwd(dh, H, W)
+        self._final = None
+        for i, g in reversed(list(enumerate(self.block_groups))):
+            d = g.backward(d)
+            if on_stage is not None:
+                on_stage(i + 1)
+        if self._pool is not None:
+            d = ops.maxpool_bwd(d, self._pool['arg'], self._pool['H'], self._pool['W'], 3, 2)
+            draw, _ = self.stem_bn.backward(d, mask_mode=2)      # ReLU mask recomputed from x*scale+shift
+            self._pool = None
+        else:
+            draw, _ = self.stem_bn.backward(d)
+        self.stem_conv.backward(draw, need_dx=False)
+        if on_stage is not None:
+            on_stage(0)
+        self.endpoints = {}
+        return None
+
+
+def resnet(resnet_depth, width_multiplier, cifar_stem=False, data_format='channels_last',
+           dropblock_keep_probs=None, dropblock_size=None):
+    """Returns the ResNet model for a given size (tf2/resnet.py:702-747)."""
+    model_params = {
+        18: {'block': ResidualBlock, 'layers': [2, 2, 2, 2]},
+        34: {'block': ResidualBlock, 'layers': [3, 4, 6, 3]},
+        50: {'block': BottleneckBlock, 'layers': [3, 4, 6, 3]},
+        101: {'block': BottleneckBlock, 'layers': [3, 4, 23, 3]},
+        152: {'block': BottleneckBlock, 'layers': [3, 8, 36, 3]},
+        200: {'block': BottleneckBlock, 'layers': [3, 24, 36, 3]},
+    }
+    if resnet_depth not in model_params:
+        raise ValueError('Not a valid resnet_depth:', resnet_depth)
+    params = model_params[resnet_depth]
+    return Resnet(params['block'], params['layers'], width_multiplier, cifar_stem=cifar_stem,
+                  dropblock_keep_probs=dropblock_keep_probs, dropblock_size=dropblock_size,
+                  data_format=data_format)

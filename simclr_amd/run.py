@@ -1,0 +1,201 @@
+"""The pretraining step and driver -- mirror of /root/reference/tf2/run.py for the hot path.
+
+`make_single_step` restates `single_step` (tf2/run.py:557-622) line for line on the HIP
+kernels: model forward, contrastive + supervised losses, metrics, weight decay, loss / R,
+backward (hand-written, replaces tape.gradient :621), cross-replica gradient SUM (implicit in
+apply_gradients :614-622; here a bucketed RCCL all-reduce overlapped with the rest of the
+backward pass), LARS.  `main` accepts the reference's flags (simclr_amd/flags.py); the tfds
+input pipeline, checkpoint manager, eval loop and SavedModel export (run.py:241-553) are out of
+scope -- `--dataset=synthetic` feeds random two-view batches of the right shape.
+"""
+import json
+import logging
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import metrics
+from . import model as model_lib
+from . import objective as obj_lib
+from .comm import Strategy, num_replicas
+from .flags import FLAGS
+from .resnet import RT
+
+
+def build_metrics():
+    """The metric set of tf2/run.py:534-549."""
+    m = {}
+    names = ['train/weight_decay', 'train/total_loss']
+    if FLAGS.train_mode == 'pretrain':
+        names += ['train/contrast_loss', 'train/contrast_acc', 'train/contrast_entropy']
+    if FLAGS.train_mode == 'finetune' or FLAGS.lineareval_while_pretraining:
+        names += ['train/supervised_loss', 'train/supervised_acc']
+    for n in names:
+        m[n] = metrics.Mean(n)
+    return m
+
+
+class GradSync:
+    """Collective B: SUM of every trainable gradient across replicas (tf2/run.py:614-622).
+
+    Gradients live in ONE flat fp32 buffer ordered last-layer-first, cut into buckets at block
+    group boundaries; each bucket's all-reduce is issued asynchronously as soon as the backward
+    pass has produced it, so xGMI traffic overlaps the remaining dgrad/wgrad kernels."""
+
+    def __init__(self, model, strategy):
+        self.strategy = strategy
+        self.flat = model._flat_grads
+        order, offs = model._flat_order, model._flat_offsets
+        marks = ['block_group4', 'block_group3', 'block_group2', 'block_group1']
+        cuts = [0]
+        for mk in marks:                      # bucket k ends where block group (4-k) ends
+            last = max(i for i, v in enumerate(order) if mk in v.name)
+            end = offs[last + 1] if last + 1 < len(order) else self.flat.numel()
+            cuts.append(end)
+        cuts.append(self.flat.numel())
+        self.ranges = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        self.stage_to_bucket = {4: 0, 3: 1, 2: 2, 1: 3}
+        self.works = []
+
+    def on_stage(self, stage):
+        """Called by the backward pass after block group `stage` (4..1) is done; 0 = stem done."""
+        if self.strategy is None or self.strategy.num_replicas_in_sync <= 1:
+            return
+        if stage == 0:
+            idx = len(self.ranges) - 1 if len(self.ranges) > 4 else None
+        else:
+            idx = self.stage_to_bucket.get(stage)
+        if idx is None or idx >= len(self.ranges):
+            return
+        a, b = self.ranges[idx]
+        self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.strategy.group,
+                                          async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def make_single_step(model, optimizer, strategy, all_metrics=None):
+    """Returns single_step(features, labels) -- tf2/run.py:557-622."""
+    m = all_metrics if all_metrics is not None else build_metrics()
+    state = {'sync': None}
+    RT.strategy = strategy
+
+    def single_step(features, labels):
+        projection_head_outputs, supervised_head_outputs = model(features, training=True)   # :577-578
+        R = num_replicas(strategy)
+        con_loss = sup_loss = None
+        if projection_head_outputs is not None:
+            outputs = projection_head_outputs
+            con_loss, logits_con, labels_con = obj_lib.add_contrastive_loss(                # :582-586
+                outputs, hidden_norm=FLAGS.hidden_norm, temperature=FLAGS.temperature, strategy=strategy)
+        if supervised_head_outputs is not None:
+            l = labels['labels'] if isinstance(labels, dict) else labels
+            # labels are reused for both views (tf2/run.py:599-600: l = concat([l, l], 0))
+            sup_loss = obj_lib.add_supervised_loss(labels=l, logits=supervised_head_outputs)   # :601
+        weight_decay = model_lib.add_weight_decay(model, adjust_per_optimizer=True)         # :609-610
+
+        # ---- backward of (loss / R): tf2/run.py:617-621 ----
+        if model._flat_grads is None:
+            model.allocate_flat_grads()
+            state['sync'] = GradSync(model, strategy)
+        sync = state['sync']
+        model._wd_grad_scale = 1.0 / R
+        d_proj = con_loss.backward(1.0 / R) if con_loss is not None else None
+        d_sup = sup_loss.backward() if sup_loss is not None else None
+        model.backward(d_proj, d_sup, on_stage=sync.on_stage)
+        sync.wait()
+        optimizer.apply_gradients([(v.grad, v) for v in model._flat_order])                # :622
+        RT.weights_version += 1
+
+        # ---- metrics (device scalars, no sync): tf2/run.py:587-613 ----
+        if con_loss is not None:
+            metrics.update_pretrain_metrics_train(m['train/contrast_loss'], m['train/contrast_acc'],
+                                                  m['train/contrast_entropy'], con_loss, logits_con, labels_con)
+        if sup_loss is not None:
+            metrics.update_finetune_metrics_train(m['train/supervised_loss'], m['train/supervised_acc'],
+                                                  sup_loss, None, None)
+        wd_t = weight_decay if torch.is_tensor(weight_decay) else torch.tensor(float(weight_decay))
+        m['train/weight_decay'].update_state(wd_t)
+        total = wd_t.reshape(-1)[:1].to(features.device)
+        if con_loss is not None:
+            total = total + con_loss.value
+        if sup_loss is not None:
+            total = total + sup_loss.value
+        m['train/total_loss'].update_state(total)
+        return dict(con_loss=con_loss, sup_loss=sup_loss, weight_decay=weight_decay, total_loss=total)
+
+    single_step.metrics = m
+    return single_step
+
+
+def synthetic_batches(batch, image_size, num_classes, device, seed=0, pool=2):
+    """i.i.d. U[0,1) two-view batches [b, H, W, 6] + one-hot labels."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    feats = [torch.rand(batch, image_size, image_size, 6, generator=g).to(device) for _ in range(pool)]
+    labs = [torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes)
+            .float().to(device) for _ in range(pool)]
+    i = 0
+    while True:
+        yield feats[i % pool], {'labels': labs[i % pool]}
+        i += 1
+
+
+def init_distributed():
+    """One process per GPU (torchrun): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return None
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    return Strategy()
+
+
+def main(argv):
+    FLAGS.parse(argv)
+    logging.basicConfig(level=logging.INFO)
+    strategy = init_distributed()
+    R = num_replicas(strategy)
+    if FLAGS.dataset != 'synthetic':
+        raise NotImplementedError('only --dataset=synthetic is available offline (no tfds); '
+                                  'feed real data through make_single_step from your own pipeline')
+    num_classes = 10 if FLAGS.image_size <= 32 else 1000
+    num_train_examples = 50000 if FLAGS.image_size <= 32 else 1281167
+    train_steps = model_lib.get_train_steps(num_train_examples)
+    RT.reset()
+    RT.strategy = strategy
+    RT.device = torch.device('cuda', torch.cuda.current_device())
+    model = model_lib.Model(num_classes)
+    learning_rate = model_lib.WarmUpAndCosineDecay(FLAGS.learning_rate, num_train_examples)
+    optimizer = model_lib.build_optimizer(learning_rate)
+    step_fn = make_single_step(model, optimizer, strategy)
+    per_replica = FLAGS.train_batch_size // R                                   # tf2/data.py:45
+    data = synthetic_batches(per_replica, FLAGS.image_size, num_classes, RT.device,
+                             seed=(0 if strategy is None else strategy.rank))
+    log_every = FLAGS.checkpoint_steps or 10
+    t0 = time.time()
+    for step in range(train_steps):
+        features, labels = next(data)
+        step_fn(features, labels)
+        if (step + 1) % log_every == 0:
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            t0 = time.time()
+            if strategy is None or strategy.rank == 0:
+                vals = {k: v.result() for k, v in step_fn.metrics.items()}
+                vals.update(step=step + 1, images_per_sec=FLAGS.train_batch_size * log_every / dt,
+                            learning_rate=learning_rate(step))
+                print(json.dumps(vals), flush=True)
+            for v in step_fn.metrics.values():
+                v.reset_states()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

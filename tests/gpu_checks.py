@@ -43,7 +43,8 @@ def check_probes():
     a = torch.randn(16, 32, generator=g).bfloat16()
     b = torch.randn(32, 16, generator=g).bfloat16()   # asymmetric on purpose
     o = torch.zeros(64 * 4, device=DEV)
-    lib().probe(0, ops._p(a.to(DEV).view(torch.int16)), ops._p(b.to(DEV).view(torch.int16)), ops._p(o), ops._s())
+    ad, bd = a.to(DEV).view(torch.int16), b.to(DEV).view(torch.int16)   # keep alive across the launch
+    lib().probe(0, ops._p(ad), ops._p(bd), ops._p(o), ops._s())
     d = o.cpu().view(64, 4)
     ref = a.double() @ b.double()
     got = torch.zeros(16, 16, dtype=torch.float64)
@@ -54,7 +55,8 @@ def check_probes():
     a = torch.randn(16, 4, generator=g)
     b = torch.randn(4, 16, generator=g)
     o = torch.zeros(64 * 4, device=DEV)
-    lib().probe(1, ops._p(a.to(DEV)), ops._p(b.to(DEV)), ops._p(o), ops._s())
+    ad, bd = a.to(DEV), b.to(DEV)
+    lib().probe(1, ops._p(ad), ops._p(bd), ops._p(o), ops._s())
     d = o.cpu().view(64, 4)
     got = torch.zeros(16, 16, dtype=torch.float64)
     for l in range(64):
@@ -71,7 +73,9 @@ def probe_ds_read_tr16():
     lanes = torch.arange(64)
     addr = ((lanes >> 4) * 64 + ((lanes & 15) >> 2) * 16 + (lanes & 3) * 4).int()
     o = torch.zeros(256, dtype=torch.int16, device=DEV)
-    lib().probe(2, ops._p(src.to(DEV)), ops._p(addr.to(DEV)), ops._p(o), ops._s())
+    sd, ad = src.to(DEV), addr.to(DEV)
+    lib().probe(2, ops._p(sd), ops._p(ad), ops._p(o), ops._s())
+    torch.cuda.synchronize()
     return o.cpu().view(64, 4)
 
 
@@ -371,3 +375,130 @@ def check_sup_head(rows, nclass, cpad, dtype, seed=0):
             _res('sup_dlogits ' + tag, dl[:, :nclass], zr.grad, t, 1e-7),
             _res('sup_dlogits_pad ' + tag, dl[:, nclass:], torch.zeros(rows, cpad - nclass), 0, 0),
             _res('sup_dbias ' + tag, db, zr.grad.sum(0), 10 * t, 1e-6)]
+
+
+# ------------------------------------------------------------------ end-to-end training step
+def _flat(d, keys, like):
+    return torch.cat([(d[k] if d[k] is not None else torch.zeros_like(like[k])).double().reshape(-1).cpu() for k in keys])
+
+
+def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_classes=10, seed=0,
+                     weight_decay=1e-4, lr=0.1, steps=1, randomize_bn=True):
+    """Full pretraining steps: HIP path vs the torch-CPU oracle restating tf2/run.py:557-622 on
+    identical weights and inputs.
+
+    Ground truth is the oracle in float64.  ReLU sign flips and small-batch BatchNorm make the step
+    ill-conditioned, so the tolerance of every quantity is CALIBRATED by the error the reference
+    arithmetic itself shows at the same precision: the oracle run in float32 (f32 mode) or with
+    bf16 rounding of weights/activations emulated (bf16 mode), each against float64:
+        tol = CAL * err(oracle@precision vs f64) + floor.
+    Steps after the first are teacher-forced (weights/momenta re-synchronised from the oracle) so
+    each step is an independent parity case that also exercises the weight-refresh logic."""
+    from collections import OrderedDict
+    from oracle.model_torch import Config, init_model, train_step
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    from simclr_amd.run import make_single_step
+
+    CAL = 4.0
+    cfg = Config(resnet_depth=depth, image_size=image_size, num_classes=num_classes, weight_decay=weight_decay)
+    params, state = init_model(cfg, seed=seed, randomize_bn=randomize_bn)
+    momenta = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+    g = torch.Generator().manual_seed(seed + 1)
+    FLAGS.reset()
+    FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype=compute_dtype, use_blur=False,
+                 weight_decay=weight_decay, train_batch_size=batch)
+    RT.reset()
+    RT.device = torch.device(DEV)
+    model = model_lib.Model(num_classes)
+    with torch.no_grad():
+        model(torch.zeros(2, image_size, image_size, 6, device=DEV), training=True)   # builds the variables
+    res = []
+    names_model = [v.name for v in model.variables]
+    names_oracle = list(params.keys()) + list(state.keys())
+    missing = sorted(set(names_oracle) - set(names_model))
+    extra = sorted(set(names_model) - set(names_oracle))
+    tag = 'R%d %dpx b%d %s%s' % (depth, image_size, batch, compute_dtype, '' if randomize_bn else ' refinit')
+    res.append(dict(name='step_var_names ' + tag, err=float(len(missing) + len(extra)), tol=0.0, scale=0.0,
+                    ok=not missing and not extra, nbad=len(missing) + len(extra), numel=len(names_oracle),
+                    missing=missing[:5], extra=extra[:5]))
+    if missing or extra:
+        return res
+    optimizer = model_lib.build_optimizer(lr)
+    step_fn = make_single_step(model, optimizer, None)
+    keys = list(params.keys())
+    emu = compute_dtype == 'bf16'
+
+    def entry(name, err, ref_err, floor, **kw):
+        tol = CAL * ref_err + floor
+        d = dict(name=name, err=float(err), tol=float(tol), scale=float(ref_err), ok=bool(err <= tol), nbad=0, numel=1)
+        d.update(kw)
+        return d
+
+    for s_i in range(steps):
+        # (re)load weights, BN state and momenta from the oracle
+        allv = dict(params); allv.update(state)
+        for v in model.variables:
+            assert tuple(v.value.shape) == tuple(allv[v.name].shape), (v.name, v.value.shape, allv[v.name].shape)
+            v.value.copy_(allv[v.name].to(DEV))
+        if s_i > 0:
+            for v in model._flat_order:
+                optimizer.get_slot(v, 'Momentum').copy_(momenta[v.name].to(DEV))
+        RT.weights_version += 1
+        images = torch.rand(batch, image_size, image_size, 6, generator=g)
+        labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes).float()
+        p64 = OrderedDict((k, v.double()) for k, v in params.items())
+        s64 = OrderedDict((k, v.double()) for k, v in state.items())
+        m64 = OrderedDict((k, v.double()) for k, v in momenta.items())
+        np64, ns64, nm64, t64 = train_step(cfg, p64, s64, m64, images.double(), labels.double(), lr)
+        np32, ns32, nm32, t32 = train_step(cfg, params, state, momenta, images, labels, lr, emulate_bf16=emu)
+        out = step_fn(images.to(DEV), {'labels': labels.to(DEV)})
+        torch.cuda.synchronize()
+        st = ' step%d' % s_i
+
+        def rel(a, b):
+            return float((a.double().cpu() - b.double()).abs().max()) / (float(b.double().abs().max()) + 1e-30)
+
+        for nm_, mine, k in (('con_loss', out['con_loss'].value, 'con_loss'), ('sup_loss', out['sup_loss'].value, 'sup_loss'),
+                             ('total_loss', out['total_loss'], 'total_loss')):
+            res.append(entry('step_%s %s%s' % (nm_, tag, st), rel(mine.reshape(-1)[0], t64[k].detach()),
+                             rel(t32[k].detach(), t64[k].detach()), 1e-5 if not emu else 1e-2,
+                             value=float(mine.reshape(-1)[0]), ref=float(t64[k])))
+        z_err = float((out['con_loss'].normalized.double().cpu() - t64['z'].detach()).abs().max())
+        z_ref = float((t32['z'].detach().double() - t64['z'].detach()).abs().max())
+        res.append(entry('step_embeddings_abs %s%s' % (tag, st), z_err, z_ref, 2e-6 if not emu else 1e-2))
+        g64 = _flat(t64['grads'], keys, p64)
+        g32 = _flat(t32['grads'], keys, params)
+        gm = torch.cat([{v.name: v for v in model._flat_order}[k].grad.double().reshape(-1).cpu() for k in keys])
+        cos_m = float((gm * g64).sum() / gm.norm() / g64.norm())
+        cos_r = float((g32 * g64).sum() / g32.norm() / g64.norm())
+        res.append(entry('step_grad_1-cos %s%s' % (tag, st), 1 - cos_m, 1 - cos_r, 1e-6 if not emu else 1e-2))
+        res.append(entry('step_grad_relnorm %s%s' % (tag, st), float((gm - g64).norm() / g64.norm()),
+                         float((g32 - g64).norm() / g64.norm()), 1e-5 if not emu else 5e-2))
+        worst_m, worst_r, wn = 0.0, 0.0, ''
+        byname = {v.name: v for v in model._flat_order}
+        for k in keys:
+            ref = t64['grads'][k]
+            if ref is None or float(ref.abs().max()) < 1e-12:
+                continue
+            em, er = rel(byname[k].grad, ref), rel(t32['grads'][k], ref)
+            if em > worst_m:
+                worst_m, wn = em, k
+            worst_r = max(worst_r, er)
+        res.append(entry('step_grad_worst_tensor_rel %s%s' % (tag, st), worst_m, worst_r, 1e-4 if not emu else 1e-1,
+                         worst=wn))
+        pm = max(rel(byname[k].value, np64[k]) for k in keys)
+        pr = max(rel(np32[k], np64[k]) for k in keys)
+        res.append(entry('step_new_params_worst_rel %s%s' % (tag, st), pm, pr, 1e-6 if not emu else 1e-2))
+        mvm = max(rel(optimizer.get_slot(byname[k], 'Momentum'), nm64[k]) for k in keys
+                  if float(nm64[k].abs().max()) > 1e-12)
+        mvr = max(rel(nm32[k], nm64[k]) for k in keys if float(nm64[k].abs().max()) > 1e-12)
+        res.append(entry('step_momentum_worst_rel %s%s' % (tag, st), mvm, mvr, 1e-4 if not emu else 1e-1))
+        bm = max(rel(v.value, ns64[v.name]) for v in model.variables if v.name in ns64)
+        br = max(rel(ns32[k], ns64[k]) for k in ns64)
+        res.append(entry('step_bn_moving_worst_rel %s%s' % (tag, st), bm, br, 1e-5 if not emu else 1e-2))
+        params = OrderedDict((k, v.float()) for k, v in np64.items())
+        state = OrderedDict((k, v.float()) for k, v in ns64.items())
+        momenta = OrderedDict((k, v.float()) for k, v in nm64.items())
+    return res
