@@ -158,3 +158,44 @@ def contrastive_loss_and_grad(all_hiddens, hidden_norm=True, temperature=1.0):
             gh = gz
         grads.append(gh)
     return losses, grads
+
+
+def replica_partials(all_hiddens, r, hidden_norm=True, temperature=1.0):
+    """What ONE replica's loss kernel produces before any collective (float64):
+    (loss_r, z_r, inv_r, dz_local [2n,D], dz_all [2N,D]) with dz_* = d(loss_r / R) / d(normalised
+    rows): dz_local through the replica's own (query) rows, dz_all through the gathered rows in
+    [z1_all; z2_all] order.  Summing dz_all over replicas and slicing the replica's slot is the
+    transpose of tf2/objective.py:114-122 (all_reduce SUM); used to test simclr_amd/comm.py."""
+    R = len(all_hiddens)
+    hs = [np.asarray(h, dtype=np.float64) for h in all_hiddens]
+    n = hs[0].shape[0] // 2
+    N = R * n
+    if hidden_norm:
+        inv = [1.0 / np.sqrt(np.maximum(np.sum(h * h, -1, keepdims=True), 1e-12)) for h in hs]
+        zs = [h * i for h, i in zip(hs, inv)]
+    else:
+        inv = [np.ones((2 * n, 1)) for _ in hs]
+        zs = hs
+    z1 = np.concatenate([z[:n] for z in zs], 0)
+    z2 = np.concatenate([z[n:] for z in zs], 0)
+    rows = slice(r * n, (r + 1) * n)
+    q1, q2 = z1[rows], z2[rows]
+    idx = np.arange(n) + r * n
+    mask = np.zeros((n, N)); mask[np.arange(n), idx] = 1.0
+    onehot = np.zeros((n, 2 * N)); onehot[np.arange(n), idx] = 1.0
+    la = np.concatenate([q1 @ z2.T / temperature, q1 @ z1.T / temperature - mask * LARGE_NUM], 1)
+    lb = np.concatenate([q2 @ z1.T / temperature, q2 @ z2.T / temperature - mask * LARGE_NUM], 1)
+    loss = np.mean(_softmax_xent(onehot, la) + _softmax_xent(onehot, lb))
+
+    def dsoft(l):
+        m = l.max(1, keepdims=True)
+        p = np.exp(l - m)
+        p /= p.sum(1, keepdims=True)
+        return (p - onehot) / n / R
+    da, db = dsoft(la), dsoft(lb)
+    dab, daa, dba, dbb = da[:, :N], da[:, N:], db[:, :N], db[:, N:]
+    dq1 = (dab @ z2 + daa @ z1) / temperature
+    dq2 = (dba @ z1 + dbb @ z2) / temperature
+    dk1 = (daa.T @ q1 + dba.T @ q2) / temperature
+    dk2 = (dab.T @ q1 + dbb.T @ q2) / temperature
+    return loss, zs[r], inv[r], np.concatenate([dq1, dq2], 0), np.concatenate([dk1, dk2], 0)

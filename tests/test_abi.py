@@ -1,0 +1,102 @@
+"""CPU tests of the C-ABI boundary and the host-side logic (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from simclr_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    sig = _lib.parse_header()
+    assert len(sig) >= 30
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sig:
+        assert hasattr(dll, name), 'libsimclr_hip.so does not export %s' % name
+    L = _lib.lib()
+    assert L.abi_version() == 1 and L.lars_chunk_elems() == 8192
+    assert L.ntxent_workspace_bytes(512, 512, 128) > 0
+    assert L.conv2d_wgrad_workspace_bytes(8, 56, 56, 64, 64, 3, 3, _lib.DT_BF16) > 0
+
+
+def test_no_undeclared_exports():
+    """Every exported simclr_* symbol is declared in the header (the header is the whole boundary)."""
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r'\bT (simclr_\w+)', out))
+    declared = set(_lib.parse_header())
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+
+
+def test_bad_arguments_return_error_codes():
+    L = _lib.lib()
+    with pytest.raises(_lib.SimclrHipError, match='D must be 64/128/256'):
+        L.ntxent_fwd(None, None, 4, 4, 100, 0, ctypes.c_float(0.1), None, None, None, None)
+    with pytest.raises(_lib.SimclrHipError, match='multiple of'):
+        L.conv2d_fwd(None, None, None, None, 0, 1, 8, 8, 3, 8, 8, 64, 3, 3, 1, 1, _lib.DT_BF16, None)
+    with pytest.raises(_lib.SimclrHipError, match='empty tensor list'):
+        L.lars_multi_tensor(None, 0, None, 0, None, ctypes.c_float(0.1), ctypes.c_float(0.9),
+                            ctypes.c_float(0.0), ctypes.c_float(0.001), 1, 0, None, None)
+
+
+def test_product_path_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'simclr_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+
+
+def test_flags_match_reference_defaults():
+    from simclr_amd.flags import FLAGS
+    FLAGS.reset()
+    d = FLAGS.flag_values_dict()
+    ref = dict(learning_rate=0.3, learning_rate_scaling='linear', warmup_epochs=10, weight_decay=1e-6,
+               batch_norm_decay=0.9, train_batch_size=512, train_epochs=100, temperature=0.1, hidden_norm=True,
+               proj_head_mode='nonlinear', proj_out_dim=128, num_proj_layers=3, global_bn=True, width_multiplier=1,
+               resnet_depth=50, sk_ratio=0.0, image_size=224, use_blur=True, optimizer='lars', momentum=0.9,
+               lineareval_while_pretraining=True, train_mode='pretrain')
+    for k, v in ref.items():
+        assert d[k] == v, k
+    FLAGS.parse(['--train_batch_size=4096', '--nouse_blur', '--hidden_norm=False', '--resnet_depth', '18'])
+    assert FLAGS.train_batch_size == 4096 and FLAGS.use_blur is False and FLAGS.hidden_norm is False
+    assert FLAGS.resnet_depth == 18
+    FLAGS.reset()
+
+
+def test_schedule_and_lars_rules_match_oracle():
+    from oracle import lars as olars
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    FLAGS.reset()
+    FLAGS.update(train_batch_size=4096, learning_rate_scaling='sqrt')
+    sched = model_lib.WarmUpAndCosineDecay(0.075, 1281167)
+    for s in (0, 1, 500, 3126, 3127, 3128, 10000, 31279, 40000):
+        assert sched(s) == pytest.approx(olars.warmup_and_cosine_decay(
+            s, 0.075, 1281167, train_batch_size=4096, learning_rate_scaling='sqrt'), abs=1e-12)
+    assert model_lib.get_train_steps(1281167) == olars.get_train_steps(1281167, 0, 100, 4096)
+    opt = model_lib.build_optimizer(0.1)
+    ex = ['batch_normalization', 'bias', 'head_supervised']
+    for name in ['a/conv2d/kernel:0', 'a/sync_batch_normalization_2/beta:0', 'head_supervised/x/dense/kernel:0',
+                 'proj/dense/bias:0']:
+        assert opt._use_weight_decay(name) == olars.use_weight_decay(name, FLAGS.weight_decay, ex)
+        assert opt._do_layer_adaptation(name) == olars.do_layer_adaptation(name, ex)
+    FLAGS.reset()
+
+
+def test_model_constructs_on_cpu_and_names_layers():
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    FLAGS.reset(); FLAGS.update(use_blur=False)
+    RT.reset()
+    m = model_lib.Model(1000)
+    assert RT.counters['conv2d'] == 53 and RT.counters['sync_batch_normalization'] == 56
+    assert RT.counters['bottleneck_block'] == 16 and RT.counters['dense'] == 4
+    FLAGS.update(sk_ratio=0.0625); RT.reset()
+    with pytest.raises(NotImplementedError):
+        model_lib.Model(1000)
+    FLAGS.reset(); RT.reset()

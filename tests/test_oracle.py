@@ -1,0 +1,191 @@
+"""CPU tests: the oracle against closed forms, golden vectors, the reference's structural known
+answers, and float64 self-consistency (analytic gradient == autograd; sharded == global batch)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lars as olars
+from oracle import ntxent as ont
+from oracle.model_torch import Config, init_model, torch_contrastive_loss, train_step
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+# ---- closed-form known answers -----------------------------------------------
+@pytest.mark.parametrize('n', [4, 16, 64])
+def test_ntxent_identical_rows(n):
+    loss, _, _ = ont.add_contrastive_loss(np.ones((2 * n, 32)), True, 0.1)
+    assert abs(loss - 2 * np.log(2 * n - 1)) < 1e-12
+
+
+@pytest.mark.parametrize('T', [0.1, 0.5, 1.0])
+def test_ntxent_orthogonal_onehot(T):
+    n = 16
+    e = np.eye(n, 32)
+    loss, _, _ = ont.add_contrastive_loss(np.concatenate([e, e]), True, T)
+    closed = 2 * (np.log(np.exp(1 / T) + (2 * n - 2)) - 1 / T)
+    assert abs(loss - closed) < 1e-12
+
+
+def test_ntxent_tiny_by_hand():
+    # hidden_norm=False, T=1, n=1: logits_ab=[h1.h2], logits_aa masked -> loss = 2*(lse([s, -1e9]) - s) = 0
+    h = np.array([[1.0, 2.0], [3.0, -1.0]])
+    loss, lab, labels = ont.add_contrastive_loss(h, False, 1.0)
+    assert abs(loss) < 1e-9 and lab.shape == (1, 1) and labels.shape == (1, 2)
+    # n=2 by hand
+    h = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0], [0.0, 2.0]])
+    h1, h2 = h[:2], h[2:]
+    def xent(row_logits, pos):
+        return np.log(np.sum(np.exp(row_logits))) - row_logits[pos]
+    la = [xent(np.array([h1[i] @ h2[0], h1[i] @ h2[1], h1[i] @ h1[1 - i]]), i) for i in range(2)]
+    lb = [xent(np.array([h2[i] @ h1[0], h2[i] @ h1[1], h2[i] @ h2[1 - i]]), i) for i in range(2)]
+    loss, _, _ = ont.add_contrastive_loss(h, False, 1.0)
+    assert abs(loss - np.mean(np.array(la) + np.array(lb))) < 1e-9
+
+
+def test_ntxent_permutation_invariance():
+    g = np.random.default_rng(0)
+    n = 8
+    h = g.standard_normal((2 * n, 16))
+    p = g.permutation(n)
+    hp = np.concatenate([h[:n][p], h[n:][p]])
+    assert abs(ont.add_contrastive_loss(h, True, 0.1)[0] - ont.add_contrastive_loss(hp, True, 0.1)[0]) < 1e-12
+
+
+# ---- float64 self-consistency ---------------------------------------------------------------------
+def test_analytic_grad_matches_autograd():
+    g = np.random.default_rng(1)
+    h = g.standard_normal((24, 32))
+    losses, grads = ont.contrastive_loss_and_grad([h], True, 0.2)
+    ht = torch.tensor(h, requires_grad=True)
+    l, _, _, _ = torch_contrastive_loss(ht, True, 0.2)
+    l.backward()
+    assert abs(losses[0] - float(l.detach())) < 1e-12
+    assert np.abs(grads[0] - ht.grad.numpy()).max() < 1e-14
+
+
+@pytest.mark.parametrize('R', [1, 2, 4, 8])
+def test_sharded_equals_global_batch(R):
+    """R replicas with differentiable concat + loss/R + gradient SUM == 1 replica on the global
+    batch (tf2/objective.py:60-69, tf2/run.py:617-622)."""
+    g = np.random.default_rng(2)
+    n = 4
+    hs = [g.standard_normal((2 * n, 16)) for _ in range(R)]
+    losses, grads = ont.contrastive_loss_and_grad(hs, True, 0.1)
+    glob = np.concatenate([x[:n] for x in hs] + [x[n:] for x in hs])
+    lg, gg = ont.contrastive_loss_and_grad([glob], True, 0.1)
+    assert abs(np.mean(losses) - lg[0]) < 1e-12
+    N = R * n
+    for r in range(R):
+        ref = np.concatenate([gg[0][r * n:(r + 1) * n], gg[0][N + r * n:N + (r + 1) * n]])
+        assert np.abs(grads[r] - ref).max() < 1e-14
+        lr, _, _ = ont.add_contrastive_loss(hs[r], True, 0.1, all_hiddens=hs if R > 1 else None, replica_id=r)
+        assert abs(lr - losses[r]) < 1e-12
+
+
+def test_cross_replica_concat_is_concat():
+    ts = [np.full((2, 3), float(i)) for i in range(4)]
+    assert np.array_equal(ont.tpu_cross_replica_concat(ts), np.concatenate(ts))
+    assert ont.tpu_cross_replica_concat(ts[:1]) is ts[0]
+
+
+# ---- golden vectors ----------------------------------------------------------------------------------
+def test_ntxent_golden():
+    z = np.load(os.path.join(GOLD, 'ntxent_golden.npz'))
+    for name in 'abcd':
+        n, R, D, T, norm = z[name + '_meta']
+        hs = list(z[name + '_hidden'])
+        losses, grads = ont.contrastive_loss_and_grad(hs, bool(norm), float(T))
+        assert np.abs(np.array(losses) - z[name + '_loss']).max() < 1e-12
+        assert np.abs(np.stack(grads) - z[name + '_grad']).max() < 1e-13
+
+
+def test_lars_golden_and_rules():
+    z = np.load(os.path.join(GOLD, 'lars_golden.npz'))
+    names = open(os.path.join(GOLD, 'lars_names.txt')).read().split()
+    ex = ['batch_normalization', 'bias', 'head_supervised']
+    for i, name in enumerate(names):
+        w, g, v = z['t%d_in' % i]
+        for classic in (True, False):
+            for nest in (False, True):
+                nw, nv = olars.lars_apply(name, w, g, v, 0.3, momentum=0.9, use_nesterov=nest, weight_decay=1e-4,
+                                          exclude_from_weight_decay=ex, classic_momentum=classic)
+                key = 't%d_c%d_n%d' % (i, classic, nest)
+                assert np.abs(nw - z[key + '_w']).max() < 1e-15
+                assert np.abs(nv - z[key + '_v']).max() < 1e-15
+    # exclusion rules (tf2/lars_optimizer.py:139-157, tf2/model.py:36-42); re.search = substring
+    assert not olars.use_weight_decay('x/sync_batch_normalization_3/gamma:0', 1e-4, ex)
+    assert not olars.use_weight_decay('head_supervised/linear_layer/dense/kernel:0', 1e-4, ex)
+    assert olars.use_weight_decay('resnet/conv2d_1/kernel:0', 1e-4, ex)
+    assert not olars.use_weight_decay('resnet/conv2d_1/kernel:0', 0.0, ex)
+    assert not olars.do_layer_adaptation('dense/bias:0', ex)
+    # ||w|| = 0 or ||g|| = 0 -> trust ratio 1 (plain momentum step)
+    w = np.zeros(5); g = np.ones(5); v = np.zeros(5)
+    nw, nv = olars.lars_apply('k/kernel:0', w, g, v, 0.5, weight_decay=0.0, exclude_from_weight_decay=ex)
+    assert np.allclose(nv, 0.5 * g) and np.allclose(nw, -0.5 * g)
+    nw, nv = olars.lars_apply('k/kernel:0', np.ones(5), np.zeros(5), v, 0.5, weight_decay=0.0,
+                              exclude_from_weight_decay=ex)
+    assert np.allclose(nw, 1.0)
+
+
+def test_lr_schedule():
+    kw = dict(warmup_epochs=10, train_batch_size=4096, learning_rate_scaling='linear', train_epochs=100)
+    f = lambda s: olars.warmup_and_cosine_decay(s, 0.3, 1281167, **kw)
+    warm = int(round(10 * 1281167 // 4096))
+    assert warm == 3127 and f(0) == 0.0
+    assert abs(f(warm) - 0.3 * 4096 / 256) < 1e-12
+    total = 1281167 * 100 // 4096 + 1
+    assert abs(f(total)) < 1e-9 and f(warm // 2) == pytest.approx(0.5 * (warm // 2 * 2) / warm * 4.8, rel=1e-3)
+    assert olars.warmup_and_cosine_decay(10 ** 6, 0.075, 1281167, train_batch_size=4096,
+                                         learning_rate_scaling='sqrt') == 0.0
+    assert olars.get_train_steps(1000, 7, 100, 10) == 7
+
+
+# ---- structural known answers published by the reference ------------------------------------------------
+@pytest.mark.parametrize('depth,width,sk,millions', [
+    (50, 1, 0.0, 23.56),      # README.md:21  "24", colabs/load_and_inference.ipynb:406 "23.56M"
+    (50, 1, 0.0625, 35.28),   # README.md:22  "35"
+    (50, 2, 0.0, 94.01),      # README.md:23  "94"
+])
+def test_param_counts_match_readme(depth, width, sk, millions):
+    cfg = Config(resnet_depth=depth, width_multiplier=width, sk_ratio=sk, image_size=64,
+                 lineareval_while_pretraining=False, proj_head_mode='none')
+    p, s = init_model(cfg)
+    n = sum(v.numel() for v in p.values()) + sum(v.numel() for v in s.values())
+    assert round(n / 1e6, 2) == millions
+
+
+def test_endpoint_shapes_r50():
+    """tf2/colabs/finetuning.ipynb:909 (scaled to 64 px: /3.5)."""
+    from oracle.model_torch import Builder
+    cfg = Config(resnet_depth=50, image_size=64, lineareval_while_pretraining=False)
+    p, s = init_model(cfg)
+    b = Builder(cfg, params=p, state=s)
+    with torch.no_grad():
+        b.model(torch.rand(1, 64, 64, 6))
+    shp = {k: tuple(v.shape) for k, v in b.endpoints.items()}
+    assert shp['initial_conv'] == (2, 64, 32, 32) and shp['initial_max_pool'] == (2, 64, 16, 16)
+    assert shp['block_group1'] == (2, 256, 16, 16) and shp['block_group4'] == (2, 2048, 2, 2)
+    assert shp['final_avg_pool'] == (2, 2048)
+    k = [n for n in p if n.endswith('kernel:0')]
+    assert tuple(p[k[0]].shape) == (7, 7, 3, 64)                       # HWIO
+    assert tuple(p['model/projection_head/nl_2/dense_2/kernel:0'].shape) == (2048, 128)   # [in, out]
+
+
+def test_train_step_runs_and_updates_bn():
+    from collections import OrderedDict
+    cfg = Config(resnet_depth=18, image_size=32, num_classes=10)
+    p, s = init_model(cfg, randomize_bn=True)
+    m = OrderedDict((k, torch.zeros_like(v)) for k, v in p.items())
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(4, 32, 32, 6, generator=g)
+    y = torch.nn.functional.one_hot(torch.randint(0, 10, (4,), generator=g), 10).float()
+    np_, ns, nm, info = train_step(cfg, p, s, m, x, y, 0.1)
+    assert torch.isfinite(info['total_loss'])
+    # sup-head gradient never reaches the encoder (stop_gradient, tf2/model.py:276-277):
+    k = 'model/head_supervised/linear_layer/dense_3/kernel:0'
+    assert info['grads'][k].abs().max() > 0
+    mm = [n for n in s if 'moving_mean' in n][0]
+    assert not torch.equal(ns[mm], s[mm])
