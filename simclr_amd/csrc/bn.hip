@@ -50,48 +50,68 @@ __global__ void bn_finalize(const double* __restrict__ sums, double count, int C
   if (moving_var) moving_var[c] = moving_var[c] * decay + (float)var * (1.f - decay);
 }
 
+// per-channel parameter vector for this thread's fixed channel chunk (16-byte loads)
+template <int EPC>
+__device__ __forceinline__ void load_params(const float* __restrict__ p, int c0, float* out) {
+#pragma unroll
+  for (int e = 0; e < EPC; e += 4) {
+    const float4 v = *(const float4*)(p + c0 + e);
+    out[e] = v.x; out[e + 1] = v.y; out[e + 2] = v.z; out[e + 3] = v.w;
+  }
+}
+
 // y = act(x*scale + shift [+ r] [+ r*rscale + rshift])
-template <typename T>
-__global__ void bn_apply(const T* __restrict__ x, const float* __restrict__ scale,
+// Every thread owns ONE channel chunk (grid*256 is a multiple of chunks-per-row), so the
+// per-channel parameters are loaded once; rows are walked 4 at a time to keep 4-8 16-byte
+// loads in flight per lane.
+template <typename T, int RES>   // RES: 0 none, 1 plain residual, 2 residual with its own BN
+__global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const float* __restrict__ scale,
                          const float* __restrict__ shift, const T* __restrict__ res,
                          const float* __restrict__ rscale, const float* __restrict__ rshift,
-                         T* __restrict__ y, long long nchunks, int C, int relu) {
+                         T* __restrict__ y, long long rows, int C, int relu) {
   constexpr int EPC = Elem<T>::EPC;
+  constexpr int U = 4;
   const int cpr = C / EPC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cpr) * EPC;
-    float v[EPC], r[EPC];
-    chunk_to_f32<T>(*(const u32x4*)(x + i * EPC), v);
-    if (res) chunk_to_f32<T>(*(const u32x4*)(res + i * EPC), r);
+  const long long gtid = blockIdx.x * 256ll + threadIdx.x;
+  const long long rstride = (gridDim.x * 256ll) / cpr;
+  const int cc = (int)(gtid % cpr);
+  const int c0 = cc * EPC;
+  float sc[EPC], sh[EPC], rsc[EPC], rsh[EPC];
+  load_params<EPC>(scale, c0, sc);
+  load_params<EPC>(shift, c0, sh);
+  if (RES == 2) { load_params<EPC>(rscale, c0, rsc); load_params<EPC>(rshift, c0, rsh); }
+  long long r = gtid / cpr;
+  for (; r < rows; r += U * rstride) {
+    u32x4 xv[U], rv[U];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      float o = fmaf(v[e], scale[c0 + e], shift[c0 + e]);
-      if (res) o += rscale ? fmaf(r[e], rscale[c0 + e], rshift[c0 + e]) : r[e];
-      v[e] = relu ? fmaxf(o, 0.f) : o;
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + u * rstride;
+      if (rr < rows) {
+        xv[u] = *(const u32x4*)(x + (rr * cpr + cc) * EPC);
+        if (RES) rv[u] = *(const u32x4*)(res + (rr * cpr + cc) * EPC);
+      }
     }
-    *(u32x4*)(y + i * EPC) = f32_to_chunk<T>(v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + u * rstride;
+      if (rr < rows) {
+        float v[EPC], q[EPC];
+        chunk_to_f32<T>(xv[u], v);
+        if (RES) chunk_to_f32<T>(rv[u], q);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float o = fmaf(v[e], sc[e], sh[e]);
+          if (RES == 1) o += q[e];
+          if (RES == 2) o += fmaf(q[e], rsc[e], rsh[e]);
+          v[e] = relu ? fmaxf(o, 0.f) : o;
+        }
+        *(u32x4*)(y + (rr * cpr + cc) * EPC) = f32_to_chunk<T>(v);
+      }
+    }
   }
 }
 
 // mask modes for the backward: 0 none, 1 mask_src > 0, 2 recompute x*scale+shift > 0
-template <typename T>
-__device__ __forceinline__ void masked_dy(const T* dy, const T* x, const T* mask_src,
-                                          const float* scale, const float* shift, long long i, int c0,
-                                          int mask_mode, float* d, float* xv) {
-  constexpr int EPC = Elem<T>::EPC;
-  chunk_to_f32<T>(*(const u32x4*)(dy + i * EPC), d);
-  chunk_to_f32<T>(*(const u32x4*)(x + i * EPC), xv);
-  if (mask_mode == 1) {
-    float mk[EPC];
-    chunk_to_f32<T>(*(const u32x4*)(mask_src + i * EPC), mk);
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) d[e] = mk[e] > 0.f ? d[e] : 0.f;
-  } else if (mask_mode == 2) {
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) d[e] = fmaf(xv[e], scale[c0 + e], shift[c0 + e]) > 0.f ? d[e] : 0.f;
-  }
-}
 
 // partial[slot][2][C] += (sum dy_masked, sum dy_masked * x^) over this block's rows
 template <typename T>
@@ -116,14 +136,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(
     for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     if (cc < cpr && trow < rl) {
       const int c0 = cc * EPC;
-      float mu[EPC], rs[EPC];
+      float mu[EPC], rs[EPC], sc[EPC], sh[EPC];
+      load_params<EPC>(mean, c0, mu);
+      load_params<EPC>(rstd, c0, rs);
+      if (mask_mode == 2) { load_params<EPC>(scale, c0, sc); load_params<EPC>(shift, c0, sh); }
+      for (long long r = r0 + trow; r < r1; r += 2 * rl) {
+        const long long i0 = (r * cpr + cc) * EPC, i1 = ((r + rl) * cpr + cc) * EPC;
+        const bool two = r + rl < r1;
+        u32x4 dv0 = *(const u32x4*)(dy + i0), xv0 = *(const u32x4*)(x + i0), mv0, dv1, xv1, mv1;
+        if (mask_mode == 1) mv0 = *(const u32x4*)(mask_src + i0);
+        if (two) {
+          dv1 = *(const u32x4*)(dy + i1); xv1 = *(const u32x4*)(x + i1);
+          if (mask_mode == 1) mv1 = *(const u32x4*)(mask_src + i1);
+        }
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; }
-      for (long long r = r0 + trow; r < r1; r += rl) {
-        float d[EPC], xv[EPC];
-        masked_dy<T>(dy, x, mask_src, scale, shift, r * cpr + cc, c0, mask_mode, d, xv);
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !two) break;
+          float d[EPC], xf[EPC];
+          chunk_to_f32<T>(u ? dv1 : dv0, d);
+          chunk_to_f32<T>(u ? xv1 : xv0, xf);
+          if (mask_mode == 1) {
+            float mk[EPC];
+            chunk_to_f32<T>(u ? mv1 : mv0, mk);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { s1[e] += d[e]; s2[e] += d[e] * (xv[e] - mu[e]) * rs[e]; }
+            for (int e = 0; e < EPC; ++e) d[e] = mk[e] > 0.f ? d[e] : 0.f;
+          } else if (mask_mode == 2) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) d[e] = fmaf(xf[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { s1[e] += d[e]; s2[e] += d[e] * (xf[e] - mu[e]) * rs[e]; }
+        }
       }
     }
     __syncthreads();
@@ -161,32 +204,83 @@ __global__ void bn_bwd_finalize(const double* __restrict__ local_sums,
   c2[c] = (float)(global_sums[C + c] / count);
 }
 
-// dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]
+// dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]; one channel chunk per thread, 2 rows in flight
 template <typename T>
-__global__ void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                              const T* __restrict__ mask_src, const float* __restrict__ scale,
                              const float* __restrict__ shift, const float* __restrict__ mean,
                              const float* __restrict__ rstd, const float* __restrict__ c1,
-                             const float* __restrict__ c2, long long nchunks, int C, int mask_mode,
+                             const float* __restrict__ c2, long long rows, int C, int mask_mode,
                              T* __restrict__ dx, T* __restrict__ dmasked) {
   constexpr int EPC = Elem<T>::EPC;
+  constexpr int U = 2;
   const int cpr = C / EPC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cpr) * EPC;
-    float d[EPC], xv[EPC], o[EPC];
-    masked_dy<T>(dy, x, mask_src, scale, shift, i, c0, mask_mode, d, xv);
+  const long long gtid = blockIdx.x * 256ll + threadIdx.x;
+  const long long rstride = (gridDim.x * 256ll) / cpr;
+  const int cc = (int)(gtid % cpr);
+  const int c0 = cc * EPC;
+  float sc[EPC], sh[EPC], mu[EPC], rs[EPC], k1[EPC], k2[EPC];
+  load_params<EPC>(scale, c0, sc);
+  load_params<EPC>(mean, c0, mu);
+  load_params<EPC>(rstd, c0, rs);
+  load_params<EPC>(c1, c0, k1);
+  load_params<EPC>(c2, c0, k2);
+  if (mask_mode == 2) load_params<EPC>(shift, c0, sh);
+  for (long long r = gtid / cpr; r < rows; r += U * rstride) {
+    u32x4 dv[U], xv[U], mv[U];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      const float xh = (xv[e] - mean[c0 + e]) * rstd[c0 + e];
-      o[e] = scale[c0 + e] * (d[e] - c1[c0 + e] - xh * c2[c0 + e]);
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + u * rstride;
+      if (rr < rows) {
+        const long long i = (rr * cpr + cc) * EPC;
+        dv[u] = *(const u32x4*)(dy + i);
+        xv[u] = *(const u32x4*)(x + i);
+        if (mask_mode == 1) mv[u] = *(const u32x4*)(mask_src + i);
+      }
     }
-    *(u32x4*)(dx + i * EPC) = f32_to_chunk<T>(o);
-    if (dmasked) *(u32x4*)(dmasked + i * EPC) = f32_to_chunk<T>(d);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + u * rstride;
+      if (rr < rows) {
+        const long long i = (rr * cpr + cc) * EPC;
+        float d[EPC], xf[EPC], o[EPC];
+        chunk_to_f32<T>(dv[u], d);
+        chunk_to_f32<T>(xv[u], xf);
+        if (mask_mode == 1) {
+          float mk[EPC];
+          chunk_to_f32<T>(mv[u], mk);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) d[e] = mk[e] > 0.f ? d[e] : 0.f;
+        } else if (mask_mode == 2) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) d[e] = fmaf(xf[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float xh = (xf[e] - mu[e]) * rs[e];
+          o[e] = sc[e] * (d[e] - k1[e] - xh * k2[e]);
+        }
+        *(u32x4*)(dx + i) = f32_to_chunk<T>(o);
+        if (dmasked) *(u32x4*)(dmasked + i) = f32_to_chunk<T>(d);
+      }
+    }
   }
 }
 
-int grid_for(long long n) { return (int)min((long long)8192, (n + 255) / 256); }
+// grid such that grid*256 is a multiple of chunks-per-row (every thread keeps one channel chunk)
+int grid_rows(long long rows, int cpr, int unroll) {
+  int g = 1, t = cpr;
+  // m = cpr / gcd(cpr, 256)
+  int a = cpr, b = 256;
+  while (b) { int q = a % b; a = b; b = q; }
+  const int m = cpr / a;
+  long long want = (rows * cpr + 256ll * unroll - 1) / (256ll * unroll);
+  want = max(1ll, min(want, 4096ll));
+  g = (int)((want + m - 1) / m * m);
+  (void)t;
+  return g;
+}
+
 
 }  // namespace
 
@@ -218,13 +312,18 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
                     int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_apply: C=%d must be a multiple of %d", C, epc);
-  const long long nchunks = rows * (C / epc);
-  if (dtype == SIMCLR_DT_BF16)
-    hipLaunchKernelGGL((bn_apply<uint16_t>), dim3(grid_for(nchunks)), dim3(256), 0, stream, (const uint16_t*)x,
-                       scale, shift, (const uint16_t*)res, rscale, rshift, (uint16_t*)y, nchunks, C, relu);
-  else
-    hipLaunchKernelGGL((bn_apply<float>), dim3(grid_for(nchunks)), dim3(256), 0, stream, (const float*)x, scale,
-                       shift, (const float*)res, rscale, rshift, (float*)y, nchunks, C, relu);
+  SIMCLR_CHECK_ARG(!rscale || res, "bn_apply: rscale needs res");
+  const int grid = grid_rows(rows, C / epc, 4);
+  const int mode = res ? (rscale ? 2 : 1) : 0;
+#define LA(TT, RR)                                                                                      \
+  hipLaunchKernelGGL((bn_apply<TT, RR>), dim3(grid), dim3(256), 0, stream, (const TT*)x, scale, shift, \
+                     (const TT*)res, rscale, rshift, (TT*)y, rows, C, relu)
+  if (dtype == SIMCLR_DT_BF16) {
+    if (mode == 0) LA(uint16_t, 0); else if (mode == 1) LA(uint16_t, 1); else LA(uint16_t, 2);
+  } else {
+    if (mode == 0) LA(float, 0); else if (mode == 1) LA(float, 1); else LA(float, 2);
+  }
+#undef LA
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -268,14 +367,14 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
                         int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, epc);
-  const long long nchunks = rows * (C / epc);
+  const int grid = grid_rows(rows, C / epc, 2);
   if (dtype == SIMCLR_DT_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply<uint16_t>), dim3(grid_for(nchunks)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((bn_bwd_apply<uint16_t>), dim3(grid), dim3(256), 0, stream,
                        (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)mask_src, scale, shift, mean,
-                       rstd, c1, c2, nchunks, C, mask_mode, (uint16_t*)dx, (uint16_t*)dmasked);
+                       rstd, c1, c2, rows, C, mask_mode, (uint16_t*)dx, (uint16_t*)dmasked);
   else
-    hipLaunchKernelGGL((bn_bwd_apply<float>), dim3(grid_for(nchunks)), dim3(256), 0, stream, (const float*)dy,
-                       (const float*)x, (const float*)mask_src, scale, shift, mean, rstd, c1, c2, nchunks, C,
+    hipLaunchKernelGGL((bn_bwd_apply<float>), dim3(grid), dim3(256), 0, stream, (const float*)dy,
+                       (const float*)x, (const float*)mask_src, scale, shift, mean, rstd, c1, c2, rows, C,
                        mask_mode, (float*)dx, (float*)dmasked);
   SIMCLR_CHECK_LAUNCH();
   return 0;

@@ -26,14 +26,20 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
 struct ConvP {
   const void* x;   // gathered tensor [V, IH, IW, *] (pixel pitch = pixpitch elements)
-  const void* w;   // [N][K] K-contiguous
-  void* y;         // [M][N]
+  const void* w;   // [N][K] K-contiguous, K = KH*KW*IC
+  void* y;         // output tensor [V, OH, OW, N]
   float* stats;    // nullable: [nslot][2][N] partial (sum, sumsq) per output channel
   int V, IH, IW, IC, OH, OW, N, KH, KW, stride, pad;
   int pixpitch;    // elements between consecutive ix of the gathered tensor (usually IC)
-  int M, K;
+  int M, K;        // M = rows of THIS launch (= V*cls_h*cls_w)
   int nslot, accumulate;
   int m_tiles, n_tiles;
+  // Output-pixel class (strided dgrad): rows enumerate pixels (v, a*cs+py, b*cs+px), a<cls_h, b<cls_w.
+  // All rows of a class share the same set of contributing taps, so no MFMA work is spent on
+  // structurally-zero taps.  Forward / stride-1 dgrad: one class, cs=1, every tap.
+  int cs, py, px, cls_h, cls_w;
+  int ntaps;
+  int taps[9];
 };
 
 template <typename T> struct MMA;
@@ -66,6 +72,8 @@ __device__ __forceinline__ bool tile_of_block(int m_tiles, int n_tiles, int& mt,
 
 // ------------------------------------------------------------------------------------
 // forward / dgrad implicit GEMM.  Tile BM=128 x BN (128|64) x 128 bytes of K; 4 waves.
+// Epilogue (bf16): the C tile is staged through LDS (row pitch +8 B: conflict-free 8-byte
+// writes) and stored as whole 128/256-byte NHWC rows, 8 bytes per lane -> full cache lines.
 // ------------------------------------------------------------------------------------
 template <typename T, int MODE, int BN, bool STATS>
 __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
@@ -78,6 +86,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
   constexpr int NI = 4;                 // 16-col n fragments per wave (64 cols)
   constexpr int AJ = BM / 32;           // A chunks per thread per k-tile (4)
   constexpr int BJ = BN / 32;           // B chunks per thread per k-tile (4 or 2)
+  constexpr bool LDS_EPI = sizeof(T) == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* As = (u32x4*)smem;                       // [2][BM*8]
   u32x4* Bs = As + 2 * BM * 8;                    // [2][BN*8]
@@ -90,6 +99,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
   const int wm = wave / WN, wn = wave % WN;
   const T* __restrict__ X = (const T*)p.x;
   const T* __restrict__ Wt = (const T*)p.w;
+  const int cls_hw = p.cls_h * p.cls_w;
 
   // ---- per-thread gather bookkeeping: rows (tid>>3)+32j, chunk tid&7 ----
   const int kc = tid & 7;
@@ -101,21 +111,24 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
     const int m = m0 + (tid >> 3) + 32 * j;
     a_ok[j] = m < p.M;
     const int mm = a_ok[j] ? m : 0;
-    const int v = mm / (p.OH * p.OW);
-    const int rem = mm - v * (p.OH * p.OW);
-    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    const int v = mm / cls_hw;
+    const int rem = mm - v * cls_hw;
+    const int ca = rem / p.cls_w, cb = rem - ca * p.cls_w;
+    const int oy = ca * p.cs + p.py, ox = cb * p.cs + p.px;
     a_img[j] = (long long)v * p.IH * p.IW;
     if (MODE == MODE_FWD) { a_by[j] = oy * p.stride - p.pad; a_bx[j] = ox * p.stride - p.pad; }
     else { a_by[j] = oy + p.pad; a_bx[j] = ox + p.pad; }
   }
-  const int KT = p.K / BK;
+  const int kpt = p.IC / BK;            // k-tiles per tap
+  const int KT = p.ntaps * kpt;
 
   u32x4 ra[AJ], rb[BJ];
   auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / p.IC;
-    const int ci0 = k0 - tap * p.IC;
+    const int ti = kt / kpt;
+    const int ci0 = (kt - ti * kpt) * BK;
+    const int tap = p.taps[ti];
     const int ty = tap / p.KW, tx = tap - ty * p.KW;
+    const int k0 = tap * p.IC + ci0;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       int iy, ix;
@@ -123,12 +136,10 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
       if (MODE == MODE_FWD) {
         iy = a_by[j] + ty; ix = a_bx[j] + tx;
       } else {
-        const int tyy = a_by[j] - ty, txx = a_bx[j] - tx;
+        const int tyy = a_by[j] - ty, txx = a_bx[j] - tx;   // divisible by stride for this class's taps
         ok = ok && tyy >= 0 && txx >= 0;
-        if (p.stride > 1) {
-          ok = ok && (tyy % p.stride == 0) && (txx % p.stride == 0);
-          iy = tyy / p.stride; ix = txx / p.stride;
-        } else { iy = tyy; ix = txx; }
+        if (p.stride > 1) { iy = tyy / p.stride; ix = txx / p.stride; }
+        else { iy = tyy; ix = txx; }
       }
       ok = ok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
       ra[j] = zero16();
@@ -160,8 +171,10 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  store_tile(0);
+  if (KT > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
@@ -188,30 +201,16 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: NHWC store (4 consecutive channels per lane) ----
+  // output address of class-local row m (element offset of channel 0), or -1
+  auto row_offset = [&](int m) -> long long {
+    if (m >= p.M) return -1;
+    const int v = m / cls_hw;
+    const int rem = m - v * cls_hw;
+    const int ca = rem / p.cls_w, cb = rem - ca * p.cls_w;
+    return (((long long)v * p.OH + ca * p.cs + p.py) * p.OW + cb * p.cs + p.px) * p.N;
+  };
   T* __restrict__ Y = (T*)p.y;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * 64 + ni * 16 + g * 4;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wm * (MI * 16) + mi * 16 + fl;
-      if (m < p.M && n < p.N) {
-        T* dst = Y + (long long)m * p.N + n;
-        float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-        if (p.accumulate) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += Elem<T>::ld(dst + r);
-        }
-        if (sizeof(T) == 4) {
-          *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
-          *(u32x2*)dst = pk;
-        }
-      }
-    }
-  }
+
   if (STATS) {
     // per-channel sum / sum-of-squares over this tile's rows (rows >= M are exact zeros)
     float* red = (float*)smem;  // [WM][BN][2] floats, reuse LDS (all MFMA reads are done)
@@ -240,6 +239,66 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
       atomicAdd(st + n0 + tid, s);
       atomicAdd(st + p.N + n0 + tid, ss);
     }
+    __syncthreads();
+  }
+
+  if (LDS_EPI) {
+    // ---- stage the bf16 C tile in LDS, then store whole rows (8 B per lane, full lines) ----
+    constexpr int PITCH = BN * 2 + 8;                       // bytes
+    constexpr int LPR = BN * 2 / 8;                         // lanes per row (32 or 16)
+    unsigned char* Cs = smem;                               // [BM][PITCH]
+    long long* rowoff = (long long*)(smem + BM * PITCH);    // [BM]
+    if (tid < BM) rowoff[tid] = row_offset(m0 + tid);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nl = wn * 64 + ni * 16 + g * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int ml = wm * (MI * 16) + mi * 16 + fl;
+        u32x2 pk;
+        pk[0] = pack_bf16x2(acc[ni][mi][0], acc[ni][mi][1]);
+        pk[1] = pack_bf16x2(acc[ni][mi][2], acc[ni][mi][3]);
+        *(u32x2*)(Cs + ml * PITCH + nl * 2) = pk;
+      }
+    }
+    __syncthreads();
+    const int c8 = tid % LPR;                               // 8-byte column within the row
+    const int ncol = n0 + c8 * 4;
+#pragma unroll 4
+    for (int r = tid / LPR; r < BM; r += 256 / LPR) {
+      const long long off = rowoff[r];
+      if (off >= 0 && ncol < p.N) {
+        u32x2 v = *(const u32x2*)(Cs + r * PITCH + c8 * 8);
+        uint16_t* dst = (uint16_t*)Y + off + ncol;
+        if (p.accumulate) {
+          const u32x2 o = *(const u32x2*)dst;
+          v[0] = pack_bf16x2(__uint_as_float(v[0] << 16) + __uint_as_float(o[0] << 16),
+                             __uint_as_float(v[0] & 0xffff0000u) + __uint_as_float(o[0] & 0xffff0000u));
+          v[1] = pack_bf16x2(__uint_as_float(v[1] << 16) + __uint_as_float(o[1] << 16),
+                             __uint_as_float(v[1] & 0xffff0000u) + __uint_as_float(o[1] & 0xffff0000u));
+        }
+        *(u32x2*)dst = v;
+      }
+    }
+  } else {
+    // ---- fp32 parity mode: direct 16-byte stores (4 consecutive channels per lane) ----
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const long long off = row_offset(m0 + wm * (MI * 16) + mi * 16 + fl);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + g * 4;
+        if (off >= 0 && n < p.N) {
+          T* dst = Y + off + n;
+          float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+          if (p.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += Elem<T>::ld(dst + r);
+          }
+          *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
   }
 }
 
@@ -259,11 +318,21 @@ struct WgradP {
   int k_tiles, n_tiles;
 };
 
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// XOR key that spreads the 32-byte channel blocks of a pixel row over the LDS banks.
+//  bf16: the 8 pixel rows one 32-lane half touches in a ds_read_b64_tr_b16 (pixels 8g+q, q<4)
+//        get 8 distinct keys;   f32: consecutive pixels get consecutive keys.
+template <typename T> __device__ __forceinline__ int px_key(int px) {
+  return sizeof(T) == 2 ? ((px & 3) | (((px >> 3) & 1) << 2)) : (px & 7);
+}
+
 template <typename T, int BKW, int BNW>
 __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BR = 8 * EPC;                 // pixels per reduction chunk (64 bf16 / 32 f32)
-  constexpr int WK = (BKW >= 64) ? 2 : 2;     // waves along k rows
+  constexpr int WK = 2;                       // waves along k rows
   constexpr int WNN = 2;                      // waves along n
   constexpr int KI = BKW / WK / 16;           // 16-row fragments per wave along k
   constexpr int NI = BNW / WNN / 16;
@@ -271,12 +340,12 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   constexpr int B_CPR = BNW / EPC;
   constexpr int A_CH = BR * A_CPR / 256;      // chunks per thread
   constexpr int B_CH = BR * B_CPR / 256;
-  constexpr int A_BLK = BKW * sizeof(T) / 32; // 32-byte blocks per pixel row
-  constexpr int B_BLK = BNW * sizeof(T) / 32;
-  constexpr int PG = (sizeof(T) == 2) ? 8 : 1;  // pixels per lane-group per MFMA k slot
+  constexpr int A_RB = BKW * sizeof(T);       // row bytes
+  constexpr int B_RB = BNW * sizeof(T);
+  constexpr int A_BLK = A_RB / 32;            // 32-byte blocks per pixel row
+  constexpr int B_BLK = B_RB / 32;
+  constexpr int BUF = BR * (A_RB + B_RB);     // bytes per LDS buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* As = smem;                            // [BR][BKW] T
-  unsigned char* Bs = smem + BR * BKW * sizeof(T);     // [BR][BNW] T
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fl = lane & 15;
@@ -328,63 +397,55 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
       if (m < p.M && n0 + cc * EPC < p.N) rb[j] = ld16(DY + (long long)m * p.N + n0 + cc * EPC);
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int buf) {
+    unsigned char* As = smem + buf * BUF;
+    unsigned char* Bs = As + BR * A_RB;
 #pragma unroll
     for (int j = 0; j < A_CH; ++j) {
       const int id = tid + 256 * j;
       const int px = id / A_CPR, cc = id % A_CPR;
-      const int blk = (cc >> 1) ^ ((px / PG) & (A_BLK - 1));
-      *(u32x4*)(As + px * (BKW * sizeof(T)) + blk * 32 + (cc & 1) * 16) = ra[j];
+      const int blk = (cc >> 1) ^ (px_key<T>(px) & (A_BLK - 1));
+      *(u32x4*)(As + px * A_RB + blk * 32 + (cc & 1) * 16) = ra[j];
     }
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) {
       const int id = tid + 256 * j;
       const int px = id / B_CPR, cc = id % B_CPR;
-      const int blk = (cc >> 1) ^ ((px / PG) & (B_BLK - 1));
-      *(u32x4*)(Bs + px * (BNW * sizeof(T)) + blk * 32 + (cc & 1) * 16) = rb[j];
+      const int blk = (cc >> 1) ^ (px_key<T>(px) & (B_BLK - 1));
+      *(u32x4*)(Bs + px * B_RB + blk * 32 + (cc & 1) * 16) = rb[j];
     }
   };
-  // element (pixel px, channel ch) of a tile with row bytes RB and NBLK 32-byte blocks
-  auto lds_elem = [&](const unsigned char* base, int RB, int NBLK, int px, int ch) -> const T* {
+  // byte offset of element (pixel px, channel ch) inside a tile with RB row bytes / NBLK blocks
+  auto elem_off = [&](int RB, int NBLK, int px, int ch) -> int {
     const int byte = ch * (int)sizeof(T);
-    const int blk = (byte >> 5) ^ ((px / PG) & (NBLK - 1));
-    return (const T*)(base + px * RB + blk * 32 + (byte & 31));
+    return px * RB + (((byte >> 5) ^ (px_key<T>(px) & (NBLK - 1))) << 5) + (byte & 31);
   };
-
-  for (int c = c_begin; c < c_end; ++c) {
-    load_chunk(c);
-    __syncthreads();   // previous chunk's fragment reads are done
-    store_chunk();
-    __syncthreads();
+  auto compute = [&](int buf) {
+    const unsigned char* As = smem + buf * BUF;
+    const unsigned char* Bs = As + BR * A_RB;
     if (sizeof(T) == 2) {
+      // bf16: hardware transpose reads.  Lane (fl,g) supplies the address of pixel row
+      // 8g+(fl>>2) (+4 for the second read), channel sub-chunk (fl&3)*4 of the 16-channel group
+      // and receives, for channel `fl`, pixels 8g..8g+3 (+4..7) = the MFMA k layout.
 #pragma unroll
       for (int ks = 0; ks < BR / 32; ++ks) {
         u32x4 af[KI], bf[NI];
+        const int px0 = ks * 32 + g * 8 + (fl >> 2);
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
-          const int ch = wk * (KI * 16) + i * 16 + fl;
-          uint32_t w4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int px = ks * 32 + g * 8 + 2 * e;
-            const uint16_t lo = *(const uint16_t*)lds_elem(As, BKW * 2, A_BLK, px, ch);
-            const uint16_t hi = *(const uint16_t*)lds_elem(As, BKW * 2, A_BLK, px + 1, ch);
-            w4[e] = (uint32_t)lo | ((uint32_t)hi << 16);
-          }
-          af[i] = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+          const int ch = wk * (KI * 16) + i * 16 + (fl & 3) * 4;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(As + elem_off(A_RB, A_BLK, px0, ch)));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(As + elem_off(A_RB, A_BLK, px0 + 4, ch)));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          af[i] = (u32x4){l2[0], l2[1], h2[0], h2[1]};
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          const int ch = wn * (NI * 16) + i * 16 + fl;
-          uint32_t w4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int px = ks * 32 + g * 8 + 2 * e;
-            const uint16_t lo = *(const uint16_t*)lds_elem(Bs, BNW * 2, B_BLK, px, ch);
-            const uint16_t hi = *(const uint16_t*)lds_elem(Bs, BNW * 2, B_BLK, px + 1, ch);
-            w4[e] = (uint32_t)lo | ((uint32_t)hi << 16);
-          }
-          bf[i] = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+          const int ch = wn * (NI * 16) + i * 16 + (fl & 3) * 4;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bs + elem_off(B_RB, B_BLK, px0, ch)));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bs + elem_off(B_RB, B_BLK, px0 + 4, ch)));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          bf[i] = (u32x4){l2[0], l2[1], h2[0], h2[1]};
         }
 #pragma unroll
         for (int ki = 0; ki < KI; ++ki)
@@ -400,10 +461,10 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
         const int px = ks * 4 + g;
 #pragma unroll
         for (int i = 0; i < KI; ++i)
-          af[i] = *(const float*)lds_elem(As, BKW * 4, A_BLK, px, wk * (KI * 16) + i * 16 + fl);
+          af[i] = *(const float*)(As + elem_off(A_RB, A_BLK, px, wk * (KI * 16) + i * 16 + fl));
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-          bf[i] = *(const float*)lds_elem(Bs, BNW * 4, B_BLK, px, wn * (NI * 16) + i * 16 + fl);
+          bf[i] = *(const float*)(Bs + elem_off(B_RB, B_BLK, px, wn * (NI * 16) + i * 16 + fl));
 #pragma unroll
         for (int ki = 0; ki < KI; ++ki)
 #pragma unroll
@@ -411,6 +472,19 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
             acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni], af[ki], acc[ki][ni], 0, 0, 0);
       }
     }
+  };
+
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) load_chunk(c + 1);
+    compute(buf);
+    if (c + 1 < c_end) store_chunk(buf ^ 1);
+    __syncthreads();
   }
   // D[n = g*4+reg][k row = fl]  ->  slab[split][kk][n .. n+3]
   float* slab = p.dw + (long long)split * p.K * p.N;
@@ -617,19 +691,53 @@ __global__ void unpack_stem_dw(const float* __restrict__ src, float* __restrict_
 }
 
 template <typename T, int MODE>
-int launch_igemm(const ConvP& p0, hipStream_t stream) {
-  ConvP p = p0;
+void launch_igemm_one(ConvP p, hipStream_t stream) {
   const int BN = (p.N <= 64) ? 64 : 128;
   p.m_tiles = ceil_div(p.M, 128);
   p.n_tiles = ceil_div(p.N, BN);
+  if (p.M <= 0) return;
   const int grid = ceil_div(p.m_tiles, 8) * 8 * p.n_tiles;
-  const size_t lds = 2 * (128 + BN) * 128;
+  size_t lds = 2 * (128 + BN) * 128;
+  const size_t epi = 128 * (BN * 2 + 8) + 128 * sizeof(long long);
+  if (sizeof(T) == 2 && epi > lds) lds = epi;
   const bool st = p.stats != nullptr;
 #define L(BNv, STv) \
   hipLaunchKernelGGL((conv_igemm<T, MODE, BNv, STv>), dim3(grid), dim3(256), lds, stream, p)
   if (BN == 64) { if (st) L(64, true); else L(64, false); }
   else { if (st) L(128, true); else L(128, false); }
 #undef L
+}
+
+// Forward and stride-1 dgrad: one class with every tap.  Strided dgrad: one launch per output
+// parity class with only the taps that can contribute (1x1 s2: a single class has work, the
+// other three are zero-filled unless accumulating).
+template <typename T, int MODE>
+int launch_igemm(const ConvP& p0, hipStream_t stream) {
+  ConvP p = p0;
+  if (MODE == MODE_FWD || p.stride == 1) {
+    p.cs = 1; p.py = 0; p.px = 0; p.cls_h = p.OH; p.cls_w = p.OW;
+    p.ntaps = p.KH * p.KW;
+    for (int t = 0; t < p.ntaps; ++t) p.taps[t] = t;
+    p.M = p.V * p.OH * p.OW;
+    launch_igemm_one<T, MODE>(p, stream);
+    return 0;
+  }
+  const int S = p.stride;
+  for (int py = 0; py < S; ++py)
+    for (int px = 0; px < S; ++px) {
+      ConvP q = p;
+      q.cs = S; q.py = py; q.px = px;
+      q.cls_h = (p.OH - py + S - 1) / S;
+      q.cls_w = (p.OW - px + S - 1) / S;
+      q.ntaps = 0;
+      for (int ty = 0; ty < p.KH; ++ty)
+        for (int tx = 0; tx < p.KW; ++tx)
+          if ((py + p.pad - ty) % S == 0 && (px + p.pad - tx) % S == 0 && q.ntaps < 9)
+            q.taps[q.ntaps++] = ty * p.KW + tx;
+      q.M = p.V * q.cls_h * q.cls_w;
+      if (q.ntaps == 0 && p.accumulate) continue;   // nothing to add
+      launch_igemm_one<T, MODE>(q, stream);
+    }
   return 0;
 }
 
@@ -650,6 +758,7 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   SIMCLR_CHECK_ARG(V > 0 && OH > 0 && OW > 0 && stride >= 1, "conv2d_fwd: bad geometry");
   SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd: M overflows int32");
   SIMCLR_CHECK_ARG(!stats || nslot > 0, "conv2d_fwd: nslot must be > 0 with stats");
+  SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd: at most 9 taps (got %dx%d)", KH, KW);
   ConvP p = {};
   p.x = x; p.w = w_t; p.y = y; p.stats = stats; p.nslot = nslot;
   p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
@@ -671,6 +780,7 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
   SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0, "conv2d_dgrad: Cout=%d must be a multiple of %d", Cout, 8 * epc);
   SIMCLR_CHECK_ARG(Cin % 4 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 4", Cin);
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad: M overflows int32");
+  SIMCLR_CHECK_ARG(KH * KW <= 9 && stride <= 2, "conv2d_dgrad: at most 9 taps and stride <= 2");
   ConvP p = {};
   p.x = dy; p.w = w_d; p.y = dx; p.stats = nullptr; p.nslot = 1; p.accumulate = accumulate;
   p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
@@ -730,7 +840,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   p.n_tiles = ceil_div(p.N, bnw);
   const int grid = p.k_tiles * p.n_tiles * p.splits;
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
-  const size_t lds = (size_t)br * (bkw + bnw) * esz;
+  const size_t lds = 2 * (size_t)br * (bkw + bnw) * esz;
 #define LW(TT, A, B) hipLaunchKernelGGL((conv_wgrad<TT, A, B>), dim3(grid), dim3(256), lds, stream, p)
   if (dtype == SIMCLR_DT_BF16) {
     if (bkw == 128 && bnw == 128) LW(uint16_t, 128, 128);

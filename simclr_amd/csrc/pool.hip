@@ -239,19 +239,19 @@ __global__ void axpy_f32(float a, const float* __restrict__ x, float* __restrict
        i += (long long)gridDim.x * blockDim.x)
     y[i] = fmaf(a, x[i], y[i]);
 }
-// out[0] = 0.5 * sum x^2  (tf.nn.l2_loss), single workgroup, fp64 accumulate
+// out[0] += 0.5 * sum x^2  (tf.nn.l2_loss); out pre-zeroed; fp64 per-block partials
 __global__ __launch_bounds__(256) void l2_loss_f32(const float* __restrict__ x, long long n,
                                                    float* __restrict__ out) {
   __shared__ double sh[256];
   double a = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 256) a += (double)x[i] * x[i];
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) a += (double)x[i] * x[i];
   sh[threadIdx.x] = a;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = (float)(0.5 * sh[0]);
+  if (threadIdx.x == 0) atomicAdd(out, (float)(0.5 * sh[0]));
 }
 
 int grid_for(long long n) { return (int)min((long long)8192, (n + 255) / 256); }
@@ -387,7 +387,7 @@ int simclr_axpy_f32(float a, const float* x, float* y, long long n, hipStream_t 
   return 0;
 }
 int simclr_l2_loss_f32(const float* x, long long n, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(l2_loss_f32, dim3(1), dim3(256), 0, stream, x, n, out);
+  hipLaunchKernelGGL(l2_loss_f32, dim3(min(256, ceil_div(n, 1024))), dim3(256), 0, stream, x, n, out);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

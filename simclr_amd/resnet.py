@@ -203,8 +203,10 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         """dy: gradient wrt this layer's (activated) output.  Returns (dx, dy_masked)."""
         s = self.saved
         if mask_mode is None:
-            mask_mode = 1 if s.get('masked') else 0
-            mask_src = s['y'] if mask_mode == 1 else None
+            # plain BN+ReLU: the ReLU mask is recomputed from x*scale+shift (exactly (y > 0)),
+            # which saves re-reading the activated output in both backward passes
+            mask_mode = 2 if s.get('masked') else 0
+            mask_src = None
         x = s['x']
         part = ops.bn_bwd_reduce(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], mask_mode)
         local = ops.bn_reduce_slots(part)

@@ -16,7 +16,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import metrics
+from . import metrics, ops
 from . import model as model_lib
 from . import objective as obj_lib
 from .comm import Strategy, num_replicas
@@ -86,6 +86,7 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
     RT.strategy = strategy
 
     def single_step(features, labels):
+        ops.begin_step(features.device)
         projection_head_outputs, supervised_head_outputs = model(features, training=True)   # :577-578
         R = num_replicas(strategy)
         con_loss = sup_loss = None
@@ -111,6 +112,7 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
         sync.wait()
         optimizer.apply_gradients([(v.grad, v) for v in model._flat_order])                # :622
         RT.weights_version += 1
+        ops.end_step()
 
         # ---- metrics (device scalars, no sync): tf2/run.py:587-613 ----
         if con_loss is not None:

@@ -303,6 +303,7 @@ def check_bn(rows_shape, C, dtype, relu, residual, seed=0):
     mask_mode = 1 if relu else 0
     dyd = dy.to(DEV)
     p = ops.bn_bwd_reduce(dyd, xd, yd, scale, shift, mean_d, rstd_d, mask_mode)
+    p2 = ops.bn_bwd_reduce(dyd, xd, None, scale, shift, mean_d, rstd_d, 2 if (relu and not residual) else mask_mode) if not residual else None
     ls = ops.bn_reduce_slots(p)
     dgamma = torch.zeros(C, device=DEV); dbeta = torch.zeros(C, device=DEV)
     c1, c2 = ops.bn_bwd_finalize(ls, ls, m, dgamma, dbeta)
@@ -318,6 +319,11 @@ def check_bn(rows_shape, C, dtype, relu, residual, seed=0):
            _res('bn_dx ' + tag, dx, xr.grad, 5e-5 if dtype == torch.float32 else 1e-2)]
     if residual == 'identity':
         out.append(_res('bn_dmasked ' + tag, dmask, rr.grad, t))
+    if p2 is not None and relu:
+        # mask recomputed from x*scale+shift (mask_mode 2) must give the same sums as mask from y
+        out.append(_res('bn_bwd_reduce_mode2 ' + tag, ops.bn_reduce_slots(p2), ls, 1e-6, 1e-6))
+        dx2, _ = ops.bn_bwd_apply(dyd, xd, None, scale, shift, mean_d, rstd_d, c1, c2, 2)
+        out.append(_res('bn_dx_mode2 ' + tag, dx2, xr.grad, 5e-5 if dtype == torch.float32 else 1e-2))
     return out
 
 

@@ -1,0 +1,175 @@
+"""GPU parity tests (pytest -m gpu): every HIP kernel, called through the C ABI, against the CPU
+oracle / float64 CPU references on seeded inputs, plus the committed golden vectors and the
+end-to-end training step.  The check bodies live in tests/gpu_checks.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def _assert(results):
+    bad = [r for r in results if not r['ok']]
+    assert not bad, '\n'.join('%s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']) for r in bad)
+
+
+def test_native_library_is_loaded_and_probes_match():
+    from simclr_amd._lib import lib
+    from tests import gpu_checks as gc
+    assert os.path.exists(lib()._dll._name)
+    _assert(gc.check_probes())
+    m = gc.probe_ds_read_tr16()       # lane i of a 16-lane group receives column i of a 4x16 tile
+    assert m[0].tolist() == [0, 16, 32, 48] and m[17].tolist() == [65, 81, 97, 113]
+
+
+def test_ntxent_closed_forms():
+    from tests import gpu_checks as gc
+    _assert(gc.check_ntxent_closed_forms())
+
+
+@pytest.mark.parametrize('n,R,D,rank', [(64, 1, 128, 0), (96, 1, 64, 0), (32, 4, 128, 2), (512, 1, 128, 0),
+                                        (64, 2, 256, 1), (100, 1, 128, 0), (512, 8, 128, 5)])
+def test_ntxent_vs_oracle(n, R, D, rank):
+    from tests import gpu_checks as gc
+    _assert(gc.check_ntxent(n, R, D=D, rank=rank))
+
+
+def test_ntxent_no_norm_temperature_one():
+    from tests import gpu_checks as gc
+    _assert(gc.check_ntxent(64, 1, hidden_norm=False, temperature=1.0))
+
+
+def test_ntxent_golden_vectors():
+    """Committed fixtures (tests/golden/ntxent_golden.npz): loss and gradient of every replica."""
+    from simclr_amd import ops
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ntxent_golden.npz'))
+    for name in 'abcd':
+        n, R, D, T, norm = z[name + '_meta']
+        n, R, D = int(n), int(R), int(D)
+        hs = [torch.from_numpy(h).float().cuda() for h in z[name + '_hidden']]
+        zs, invs = zip(*[ops.l2norm_fwd(h) if norm else (h, None) for h in hs])
+        z_all = torch.cat([t[:n] for t in zs] + [t[n:] for t in zs]).contiguous()
+        slots = [torch.zeros(2 * n, D, device='cuda') for _ in range(R)]
+        locals_, losses = [], []
+        N = n * R
+        for q in range(R):
+            out, rs, ws = ops.ntxent_fwd(zs[q], z_all, q, float(T))
+            dl, da = ops.ntxent_bwd(zs[q], z_all, q, float(T), rs, 1.0 / R, out, ws)
+            locals_.append(dl); losses.append(float(out[0]))
+            for r in range(R):
+                slots[r][:n] += da[r * n:(r + 1) * n]
+                slots[r][n:] += da[N + r * n:N + (r + 1) * n]
+        assert np.allclose(losses, z[name + '_loss'], rtol=1e-5)
+        for r in range(R):
+            dz = locals_[r] + slots[r]
+            dh = ops.l2norm_bwd(zs[r], invs[r], dz) if norm else dz
+            ref = z[name + '_grad'][r]
+            assert np.abs(dh.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9
+
+
+@pytest.mark.parametrize('classic,nesterov', [(True, False), (True, True), (False, False), (False, True)])
+def test_lars_vs_oracle(classic, nesterov):
+    from tests import gpu_checks as gc
+    _assert(gc.check_lars(classic=classic, nesterov=nesterov))
+
+
+CONV_CASES = [(2, 8, 64, 64, 1, 1), (3, 14, 64, 128, 3, 1), (2, 15, 128, 64, 3, 2), (2, 16, 64, 256, 1, 2),
+              (3, 9, 128, 192, 3, 1), (130, 1, 128, 64, 1, 1), (2, 12, 256, 128, 3, 2), (1, 7, 64, 64, 3, 2)]
+
+
+@pytest.mark.parametrize('dtype', [F32, BF])
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(V, H, Cin, Cout, k, s, dtype):
+    from tests import gpu_checks as gc
+    _assert(gc.check_conv(V, H, H, Cin, Cout, k, s, dtype))
+
+
+@pytest.mark.parametrize('dtype', [F32, BF])
+@pytest.mark.parametrize('V,H,k,s', [(4, 32, 7, 2), (4, 16, 3, 1), (2, 224, 7, 2), (2, 33, 7, 2)])
+def test_stem_conv(V, H, k, s, dtype):
+    from tests import gpu_checks as gc
+    _assert(gc.check_stem(V, H, k, s, 64, dtype))
+
+
+@pytest.mark.parametrize('dtype', [F32, BF])
+@pytest.mark.parametrize('shape,C,relu,resid', [((6, 7, 5), 64, True, None), ((6, 7, 5), 64, False, None),
+                                                ((6, 7, 5), 64, True, 'identity'), ((6, 7, 5), 64, True, 'bn'),
+                                                ((37,), 2048, False, None), ((500,), 128, True, None),
+                                                ((3, 5, 5), 48, True, None)])
+def test_batch_norm(shape, C, relu, resid, dtype):
+    from tests import gpu_checks as gc
+    _assert(gc.check_bn(shape, C, dtype, relu, resid))
+
+
+@pytest.mark.parametrize('dtype', [F32, BF])
+@pytest.mark.parametrize('H', [16, 15, 112])
+def test_pooling(H, dtype):
+    from tests import gpu_checks as gc
+    _assert(gc.check_pool(2, H, 64, dtype))
+
+
+@pytest.mark.parametrize('dtype', [F32, BF])
+@pytest.mark.parametrize('rows,nclass,cpad', [(64, 1000, 1008), (16, 10, 16)])
+def test_supervised_head_loss(rows, nclass, cpad, dtype):
+    from tests import gpu_checks as gc
+    _assert(gc.check_sup_head(rows, nclass, cpad, dtype))
+
+
+def test_train_step_resnet18_f32_two_steps():
+    """Full tf2/run.py:557-622 step in fp32 parity mode vs the float64 oracle (calibrated tolerances,
+    see gpu_checks.check_train_step)."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_train_step(depth=18, image_size=32, batch=16, compute_dtype='f32', steps=2))
+
+
+def test_train_step_resnet50_f32_reference_init():
+    """ResNet-50 with the reference's initialisation: embeddings within 1e-5, loss within 1e-3 rel
+    (the BASELINE.json north_star tolerances)."""
+    from tests import gpu_checks as gc
+    res = gc.check_train_step(depth=50, image_size=64, batch=4, compute_dtype='f32', num_classes=1000,
+                              randomize_bn=False)
+    _assert(res)
+    emb = [r for r in res if r['name'].startswith('step_embeddings_abs')][0]
+    loss = [r for r in res if r['name'].startswith('step_con_loss')][0]
+    assert emb['err'] <= 1e-5, emb
+    assert loss['err'] <= 1e-3, loss
+
+
+def test_train_step_bf16():
+    from tests import gpu_checks as gc
+    _assert(gc.check_train_step(depth=18, image_size=32, batch=16, compute_dtype='bf16', randomize_bn=False))
+    _assert(gc.check_train_step(depth=50, image_size=64, batch=4, compute_dtype='bf16', num_classes=1000,
+                                randomize_bn=False))
+
+
+def test_model_api_shapes_and_errors():
+    """Drop-in surface: Model()(inputs, training) -> ([2b, 128] float32, logits), endpoints, errors."""
+    from simclr_amd import model as model_lib
+    from simclr_amd import objective as obj_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    FLAGS.reset(); FLAGS.update(resnet_depth=50, image_size=64, use_blur=False, compute_dtype='bf16')
+    RT.reset(); RT.device = torch.device('cuda')
+    m = model_lib.Model(1000)
+    x = torch.rand(4, 64, 64, 6, device='cuda')
+    proj, sup = m(x, training=True)
+    assert proj.shape == (8, 128) and proj.dtype == torch.float32
+    assert sup.dense().shape == (8, 1000)
+    ep = m.resnet_model.endpoints      # tf2/colabs/finetuning.ipynb:909 geometry at 64 px
+    assert tuple(ep['initial_conv'].shape) == (8, 32, 32, 64) and tuple(ep['block_group4'].shape) == (8, 2, 2, 2048)
+    assert tuple(ep['final_avg_pool'].shape) == (8, 2048)
+    n_train = sum(v.numel() for v in m.resnet_model.trainable_variables)
+    n_bn = sum(v.numel() for v in m.resnet_model.variables if not v.trainable)
+    assert n_train == 23508032 and n_bn == 53120          # colabs/load_and_inference.ipynb:406 "23.56M"
+    loss, logits_con, labels_con = obj_lib.add_contrastive_loss(proj, True, 0.1, None)
+    assert logits_con.shape == (4, 4) and labels_con.shape == (4, 8)
+    assert logits_con.dense().shape == (4, 4) and labels_con.dense().sum() == 4
+    with pytest.raises(ValueError):
+        m(torch.rand(4, 64, 64, 5, device='cuda'), training=True)
+    FLAGS.update(use_blur=True)
+    with pytest.raises(NotImplementedError):
+        m(x, training=True)
+    FLAGS.reset(); RT.reset()

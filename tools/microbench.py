@@ -1,0 +1,148 @@
+"""Per-layer micro-benchmark of the hot kernels at ResNet-50 1x / 224 px / V views per GPU.
+
+python tools/microbench.py [--views 1024] [--dtype bf16] [--what conv,bn,ntxent,lars]
+Prints one line per distinct layer shape: time (us), TFLOP/s, algorithmic GB/s; and a per-step
+total weighted by how often the shape occurs.  Timing: HIP events on the launch stream, median of
+`--iters` launches after warm-up; inputs are random (never zeros: DVFS).
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from simclr_amd import ops  # noqa: E402
+
+# (H, Cin, Cout, k, stride, count) of every conv in ResNet-50 1x after the stem (tf2/resnet.py:385-526)
+R50 = [
+    (56, 64, 256, 1, 1, 1),    # g1 shortcut
+    (56, 64, 64, 1, 1, 1), (56, 256, 64, 1, 1, 2), (56, 64, 64, 3, 1, 3), (56, 64, 256, 1, 1, 3),
+    (56, 256, 512, 1, 2, 1),   # g2 shortcut
+    (56, 256, 128, 1, 1, 1), (56, 128, 128, 3, 2, 1), (28, 512, 128, 1, 1, 3), (28, 128, 128, 3, 1, 3),
+    (28, 128, 512, 1, 1, 4),
+    (28, 512, 1024, 1, 2, 1),  # g3 shortcut
+    (28, 512, 256, 1, 1, 1), (28, 256, 256, 3, 2, 1), (14, 1024, 256, 1, 1, 5), (14, 256, 256, 3, 1, 5),
+    (14, 256, 1024, 1, 1, 6),
+    (14, 1024, 2048, 1, 2, 1),  # g4 shortcut
+    (14, 1024, 512, 1, 1, 1), (14, 512, 512, 3, 2, 1), (7, 2048, 512, 1, 1, 2), (7, 512, 512, 3, 1, 2),
+    (7, 512, 2048, 1, 1, 3),
+]
+
+
+def timeit(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--views', type=int, default=1024)
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--what', default='conv,bn,ntxent,lars')
+    ap.add_argument('--out', default='gpurun_out/microbench.json')
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dev = 'cuda'
+    V = args.views
+    what = args.what.split(',')
+    res = []
+    tot = dict(fwd=0.0, fwd_nostats=0.0, dgrad=0.0, wgrad=0.0, bn_apply=0.0, bn_bwd=0.0)
+    if 'conv' in what:
+        print('%-26s %9s %9s %9s %9s | TF/s fwd dgrad wgrad | GB/s fwd' % ('layer', 'fwd_us', 'nostat_us', 'dgrad_us', 'wgrad_us'))
+        for (H, Cin, Cout, k, s, cnt) in R50:
+            pad = (k - 1) // 2
+            OH = (H + (k - 1) - k) // s + 1
+            x = torch.randn(V, H, H, Cin, device=dev).to(dt)
+            w = (torch.randn(k, k, Cin, Cout, device=dev) * (k * k * Cin) ** -0.5)
+            dy = torch.randn(V, OH, OH, Cout, device=dev).to(dt)
+            w_t = ops.prep_weights(w, 0, dt); w_d = ops.prep_weights(w, 1, dt)
+            y = torch.empty(V, OH, OH, Cout, device=dev, dtype=dt)
+            dx = torch.empty(V, H, H, Cin, device=dev, dtype=dt)
+            dw = torch.empty(k * k * Cin, Cout, device=dev)
+            stats = ops.new_stats(Cout, dev)
+            t_f = timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=stats, out=y), args.iters)
+            t_n = timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=None, out=y), args.iters)
+            t_d = timeit(lambda: ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H, out=dx), args.iters)
+            t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, k, k, s, pad, out=dw), args.iters)
+            fl = 2.0 * V * OH * OH * k * k * Cin * Cout
+            by = x.element_size() * (x.numel() + y.numel())
+            name = '%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt)
+            print('%-26s %9.0f %9.0f %9.0f %9.0f | %6.0f %6.0f %6.0f | %6.0f' % (
+                name, t_f, t_n, t_d, t_w, fl / t_f / 1e6, fl / t_d / 1e6, fl / t_w / 1e6, by / t_f / 1e3), flush=True)
+            res.append(dict(layer=name, fwd_us=t_f, fwd_nostats_us=t_n, dgrad_us=t_d, wgrad_us=t_w, flops=fl, bytes=by, count=cnt))
+            tot['fwd'] += cnt * t_f; tot['fwd_nostats'] += cnt * t_n; tot['dgrad'] += cnt * t_d; tot['wgrad'] += cnt * t_w
+            del x, dy, y, dx
+        print('per-step totals (ms): fwd %.2f (no stats %.2f)  dgrad %.2f  wgrad %.2f' % (
+            tot['fwd'] / 1e3, tot['fwd_nostats'] / 1e3, tot['dgrad'] / 1e3, tot['wgrad'] / 1e3), flush=True)
+    if 'bn' in what:
+        print('%-22s %9s %9s %9s %9s | GB/s apply resid bwd_red bwd_app' % ('tensor', 'apply_us', 'resid_us', 'bwdred_us', 'bwdapp_us'))
+        shapes = [(56, 64, 7), (56, 256, 4), (28, 128, 8), (28, 512, 5), (14, 256, 12), (14, 1024, 7), (7, 512, 6), (7, 2048, 4)]
+        for (H, C, cnt) in shapes:
+            x = torch.randn(V, H, H, C, device=dev).to(dt)
+            r = torch.randn(V, H, H, C, device=dev).to(dt)
+            dy = torch.randn(V, H, H, C, device=dev).to(dt)
+            y = torch.empty_like(x); dx = torch.empty_like(x)
+            scale = torch.rand(C, device=dev) + 0.5; shift = torch.randn(C, device=dev) * 0.1
+            mean = torch.randn(C, device=dev) * 0.1; rstd = torch.rand(C, device=dev) + 0.5
+            c1 = torch.randn(C, device=dev) * 0.01; c2 = torch.randn(C, device=dev) * 0.01
+            t_a = timeit(lambda: ops.bn_apply(x, scale, shift, True, out=y), args.iters)
+            t_r = timeit(lambda: ops.bn_apply(x, scale, shift, True, res=r, out=y), args.iters)
+            t_br = timeit(lambda: ops.bn_bwd_reduce(dy, x, y, scale, shift, mean, rstd, 1), args.iters)
+            t_ba = timeit(lambda: ops.bn_bwd_apply(dy, x, y, scale, shift, mean, rstd, c1, c2, 1, out=dx), args.iters)
+            nb = x.numel() * x.element_size()
+            print('%-22s %9.0f %9.0f %9.0f %9.0f | %6.0f %6.0f %6.0f %6.0f' % (
+                '%dx%d C%d x%d' % (H, H, C, cnt), t_a, t_r, t_br, t_ba, 2 * nb / t_a / 1e3, 3 * nb / t_r / 1e3,
+                3 * nb / t_br / 1e3, 4 * nb / t_ba / 1e3), flush=True)
+            res.append(dict(layer='bn %dx%d C%d' % (H, H, C), apply_us=t_a, resid_us=t_r, bwdred_us=t_br, bwdapp_us=t_ba, bytes=nb, count=cnt))
+            del x, r, dy, y, dx
+    if 'ntxent' in what:
+        for (n, N) in [(512, 512), (512, 4096), (256, 2048), (4096, 4096)]:
+            D = 128
+            zl = torch.nn.functional.normalize(torch.randn(2 * n, D, device=dev), dim=1)
+            za = torch.nn.functional.normalize(torch.randn(2 * N, D, device=dev), dim=1)
+            za[:n] = zl[:n]; za[N:N + n] = zl[n:]
+            ws = ops.ntxent_workspace(n, N, D, dev)
+            out, rs, _ = ops.ntxent_fwd(zl, za, 0, 0.1, ws)
+            t_f = timeit(lambda: ops.ntxent_fwd(zl, za, 0, 0.1, ws), args.iters)
+            t_b = timeit(lambda: ops.ntxent_bwd(zl, za, 0, 0.1, rs, 1.0, out, ws), args.iters)
+            fl = 24.0 * n * N * D
+            by = 2.0 * (2 * n + 2 * N) * D * 4
+            print('ntxent n=%d N=%d: fwd %.0f us bwd %.0f us | fused fwd+bwd %.1f TF/s (24nND), algorithmic %.1f GB/s' % (
+                n, N, t_f, t_b, fl / (t_f + t_b) / 1e6, by / (t_f + t_b) / 1e3), flush=True)
+            res.append(dict(layer='ntxent n%d N%d' % (n, N), fwd_us=t_f, bwd_us=t_b, flops=fl, bytes=by))
+    if 'lars' in what:
+        from simclr_amd.lars_optimizer import LARSOptimizer, Variable
+        sizes = []
+        for (H, Cin, Cout, k, s, cnt) in R50:
+            sizes += [(k * k * Cin * Cout,)] * cnt + [(Cout,), (Cout,)] * cnt
+        sizes += [(7 * 7 * 3 * 64,), (2048 * 2048,), (2048 * 2048,), (2048 * 128,), (2048 * 1000,), (1000,)]
+        vs = []
+        for i, shp in enumerate(sizes):
+            v = Variable('conv2d_%d/kernel:0' % i if shp[0] > 4096 else 'batch_normalization_%d/gamma:0' % i,
+                         torch.randn(shp, device=dev) * 0.05)
+            v.grad = torch.randn(shp, device=dev) * 1e-3
+            vs.append(v)
+        opt = LARSOptimizer(0.1, weight_decay=1e-6, exclude_from_weight_decay=['batch_normalization', 'bias', 'head_supervised'])
+        gv = [(v.grad, v) for v in vs]
+        t = timeit(lambda: opt.apply_gradients(gv), args.iters)
+        nel = sum(s[0] for s in sizes)
+        print('lars %d tensors %.1f M elems: %.0f us, %.0f GB/s (7 x 4 B/elem two-pass)' % (len(vs), nel / 1e6, t, 28.0 * nel / t / 1e3), flush=True)
+        res.append(dict(layer='lars', us=t, elems=nel))
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(res, open(args.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
