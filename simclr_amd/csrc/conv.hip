@@ -19,6 +19,7 @@
 // CONSECUTIVE output channels of one pixel -> 8/16-byte NHWC stores and per-channel
 // BatchNorm statistics (tf2/resnet.py:50-60) reduce with 4 xor-shuffles in the epilogue.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,6 +41,9 @@ struct ConvP {
   int cs, py, px, cls_h, cls_w;
   int ntaps;
   int taps[9];
+  // 4-bit fields, tap i at bits [4i,4i+4): tap id, dy+8, dx+8 (input offset of tap i relative to the per-row
+  // base pixel).  Packed words instead of arrays: dynamically indexed kernel-argument arrays go to scratch.
+  unsigned long long tap_w, dy_w, dx_w;
 };
 
 template <typename T> struct MMA;
@@ -75,7 +79,9 @@ __device__ __forceinline__ bool tile_of_block(int m_tiles, int n_tiles, int& mt,
 // Epilogue (bf16): the C tile is staged through LDS (row pitch +8 B: conflict-free 8-byte
 // writes) and stored as whole 128/256-byte NHWC rows, 8 bytes per lane -> full cache lines.
 // ------------------------------------------------------------------------------------
-template <typename T, int MODE, int BN, bool STATS>
+__device__ u32x4 g_zero16;   // source of zero chunks for direct-to-LDS loads (padding / tails)
+
+template <typename T, int MODE, int BN, bool STATS, bool GLDS>
 __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BM = 128;
@@ -101,14 +107,20 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
   const T* __restrict__ Wt = (const T*)p.w;
   const int cls_hw = p.cls_h * p.cls_w;
 
-  // ---- per-thread gather bookkeeping: rows (tid>>3)+32j, chunk tid&7 ----
-  const int kc = tid & 7;
+  // ---- per-thread gather bookkeeping ----
+  // register staging: rows (tid>>3)+32j, chunk tid&7 (written to the swizzled LDS slot).
+  // direct-to-LDS (GLDS): wave-instruction j of wave w fills LDS rows 8*(w*AJ+j)..+7 linearly
+  // (lane -> row +(lane>>3), slot lane&7), so the XOR swizzle moves to the SOURCE: the lane
+  // fetches logical chunk (lane&7)^(lane>>3) (guide rule 21: linear dest + swizzled source).
+  const int kc = GLDS ? ((lane & 7) ^ (lane >> 3)) : (tid & 7);
+  auto a_row = [&](int j) -> int { return GLDS ? 8 * (wave * AJ + j) + (lane >> 3) : (tid >> 3) + 32 * j; };
+  auto b_row = [&](int j) -> int { return GLDS ? 8 * (wave * BJ + j) + (lane >> 3) : (tid >> 3) + 32 * j; };
   int a_by[AJ], a_bx[AJ];
   long long a_img[AJ];
   bool a_ok[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int m = m0 + (tid >> 3) + 32 * j;
+    const int m = m0 + a_row(j);
     a_ok[j] = m < p.M;
     const int mm = a_ok[j] ? m : 0;
     const int v = mm / cls_hw;
@@ -147,9 +159,44 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int n = n0 + (tid >> 3) + 32 * j;
+      const int n = n0 + b_row(j);
       rb[j] = zero16();
       if (n < p.N) rb[j] = ld16(Wt + ((long long)n * p.K + k0 + kc * EPC));
+    }
+  };
+  // direct-to-LDS version of load_tile: 16-byte global_load_lds per lane, no VGPR staging
+  auto issue_tile = [&](int kt, int buf) {
+    const int ti = kt / kpt;
+    const int ci0 = (kt - ti * kpt) * BK;
+    const int tap = p.taps[ti];
+    const int ty = tap / p.KW, tx = tap - ty * p.KW;
+    const int k0 = tap * p.IC + ci0;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    unsigned char* a_dst = (unsigned char*)(As + buf * BM * 8) + wave * AJ * 1024;
+    unsigned char* b_dst = (unsigned char*)(Bs + buf * BN * 8) + wave * BJ * 1024;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      int iy, ix;
+      bool ok = a_ok[j];
+      if (MODE == MODE_FWD) {
+        iy = a_by[j] + ty; ix = a_bx[j] + tx;
+      } else {
+        const int tyy = a_by[j] - ty, txx = a_bx[j] - tx;
+        ok = ok && tyy >= 0 && txx >= 0;
+        if (p.stride > 1) { iy = tyy / p.stride; ix = txx / p.stride; }
+        else { iy = tyy; ix = txx; }
+      }
+      ok = ok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const void* src = ok ? (const void*)(X + ((a_img[j] + (long long)iy * p.IW + ix) * p.pixpitch + ci0 + kc * EPC))
+                           : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int n = n0 + b_row(j);
+      const void* src = (n < p.N) ? (const void*)(Wt + ((long long)n * p.K + k0 + kc * EPC)) : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
     }
   };
   auto store_tile = [&](int buf) {
@@ -171,14 +218,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (KT > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
+  auto compute_tile = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4 af[MI], bf[NI];
@@ -197,8 +237,32 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MMA<T>::run(bf[ni], af[mi], acc[ni][mi]);
     }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
+  };
+  if (GLDS) {
+    // tile kt+1 streams into the other LDS buffer (LDS-DMA, no registers) while tile kt is consumed;
+    // one barrier per k-tile: it both publishes tile kt and retires the reads of tile kt-1.
+    if (KT > 0) issue_tile(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < KT) issue_tile(kt + 1, buf ^ 1);
+      compute_tile(buf);
+    }
     __syncthreads();
+  } else {
+    if (KT > 0) {
+      load_tile(0);
+      store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < KT) load_tile(kt + 1);
+      compute_tile(buf);
+      if (kt + 1 < KT) store_tile(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // output address of class-local row m (element offset of channel 0), or -1
@@ -303,6 +367,265 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 }
 
 // ------------------------------------------------------------------------------------
+// Persistent variant of conv_igemm: a fixed grid of workgroups (2 per CU) walks the tile list.
+// The (tile, k-tile) steps are flattened into ONE software pipeline, so the direct-to-LDS loads
+// of the next tile's first k-tile are in flight while the current tile finishes its MFMAs and
+// stores its outputs -- short-K (1x1) layers no longer pay a cold prologue per tile.  Every
+// workgroup keeps a fixed N-tile, so the BatchNorm statistics (sum, sum of squares per output
+// channel) stay in registers across all its M-tiles and are flushed with ONE set of atomics at
+// the end instead of one per tile.  XCD-aware: workgroups that share an M-tile (different
+// N-tiles) sit on the same XCD and advance in lockstep, so the gathered A tile is served by
+// that XCD's L2.
+// ------------------------------------------------------------------------------------
+template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void conv_igemm_persistent(const ConvP p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BK = 8 * EPC;
+  constexpr int WN = BN / 64;           // waves along N
+  constexpr int WM = NW / WN;           // waves along M
+  constexpr int MI = BM / WM / 16;      // 16-row m fragments per wave
+  constexpr int NI = 4;
+  constexpr int AJ = BM / (8 * NW);     // direct-to-LDS wave-instructions (8 rows each) per wave, A tile
+  constexpr int BJ = BN / (8 * NW);
+  static_assert(AJ >= 1 && BJ >= 1 && MI >= 1, "tile / wave configuration");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* As = (u32x4*)smem;                       // [STAGES][BM*8]
+  u32x4* Bs = As + STAGES * BM * 8;               // [STAGES][BN*8]
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, fl = lane & 15;
+  const int wm = wave / WN, wn = wave % WN;
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ Wt = (const T*)p.w;
+  T* __restrict__ Y = (T*)p.y;
+  const int cls_hw = p.cls_h * p.cls_w;
+
+  // workgroup -> (N-tile, first M-tile, M-tile stride); gridDim.x is a multiple of 8*n_tiles
+  const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+  const int nt = l % p.n_tiles;
+  const int mslots = gridDim.x / p.n_tiles;
+  const int mslot = (l / p.n_tiles) * 8 + xcd;
+  const int n0 = nt * BN;
+  const int count = (mslot < p.m_tiles) ? (p.m_tiles - mslot + mslots - 1) / mslots : 0;
+  const int kpt = p.IC / BK;
+  const int KT = p.ntaps * kpt;
+
+  const int kc = (lane & 7) ^ (lane >> 3);
+  // 1x1 stride-1 (and the Dense layers): output row m reads input pixel m -- no decode at all
+  const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.cs == 1 &&
+                    p.IH == p.OH && p.IW == p.OW;
+  // Row state: (a_ry, a_rx) = base input pixel of the row, a_rb = its address (chunk kc, channel 0).
+  // Tap i reads pixel (a_ry + tap_dy[i], a_rx + tap_dx[i]) -- offsets are uniform per tap and
+  // precomputed on the host, so a tap change costs two adds, two unsigned compares and one 64-bit
+  // add per row, and a k-tile inside a tap costs nothing but `+ ci0`.
+  int a_ry[AJ], a_rx[AJ];
+  const T* a_rb[AJ];
+  bool a_ok[AJ];
+  const T* a_tp[AJ];
+  bool a_tok[AJ];
+  auto setup_rows = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int m = mt * BM + 8 * (wave * AJ + j) + (lane >> 3);
+      a_ok[j] = m < p.M;
+      const int mm = a_ok[j] ? m : 0;
+      long long pix;                       // base input pixel index of the row
+      int ry = 0, rx = 0;
+      if (flat) {
+        pix = mm;
+      } else {
+        const int v = mm / cls_hw;
+        const int rem = mm - v * cls_hw;
+        const int ca = rem / p.cls_w, cb = rem - ca * p.cls_w;
+        if (MODE == MODE_FWD) { ry = ca * p.stride - p.pad; rx = cb * p.stride - p.pad; }
+        else { ry = ca; rx = cb; }
+        pix = ((long long)v * p.IH + ry) * p.IW + rx;
+      }
+      a_ry[j] = ry; a_rx[j] = rx;
+      a_rb[j] = X + pix * p.pixpitch + kc * EPC;
+      a_tp[j] = a_rb[j];                   // flat: final; otherwise overwritten by set_tap
+      a_tok[j] = a_ok[j];
+    }
+  };
+  auto set_tap = [&](int ti) __attribute__((always_inline)) {      // only on a tap change (uniform)
+    if (flat) return;
+    const int dy = (int)((p.dy_w >> (4 * ti)) & 15) - 8, dx = (int)((p.dx_w >> (4 * ti)) & 15) - 8;
+    const long long doff = ((long long)dy * p.IW + dx) * p.pixpitch;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      a_tok[j] = a_ok[j] && (unsigned)(a_ry[j] + dy) < (unsigned)p.IH && (unsigned)(a_rx[j] + dx) < (unsigned)p.IW;
+      a_tp[j] = a_rb[j] + doff;
+    }
+  };
+  // weight rows of this workgroup never change
+  const T* b_src[BJ];
+  bool b_ok[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int n = n0 + 8 * (wave * BJ + j) + (lane >> 3);
+    b_ok[j] = n < p.N;
+    b_src[j] = Wt + (long long)(b_ok[j] ? n : 0) * p.K + kc * EPC;
+  }
+  // ti = tap index, ci = k-tile index inside the tap (both tracked incrementally: no divisions)
+  auto issue_tile = [&](int ti, int ci, int buf) __attribute__((always_inline)) {
+    const int ci0 = ci * BK;
+    const int k0 = (int)((p.tap_w >> (4 * ti)) & 15) * p.IC + ci0;
+    unsigned char* a_dst = (unsigned char*)(As + buf * BM * 8) + wave * AJ * 1024;
+    unsigned char* b_dst = (unsigned char*)(Bs + buf * BN * 8) + wave * BJ * 1024;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const void* src = a_tok[j] ? (const void*)(a_tp[j] + ci0) : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const void* src = b_ok[j] ? (const void*)(b_src[j] + k0) : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
+    }
+  };
+
+  float st_s[NI][4], st_q[NI][4];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st_s[i][r] = 0.f; st_q[i][r] = 0.f; }
+  }
+
+  // issue cursor: runs STAGES-1 pipeline steps ahead of the compute cursor.  With 3 stages two
+  // k-tiles are in flight across every barrier (counted vmcnt leaves the newest one outstanding).
+  int it = 0, iti = 0, ici = 0, ibuf = 0, buf = 0;
+  int issued = 0, consumed = 0;
+  const int total = count * KT;
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    issue_tile(iti, ici, ibuf);
+    ibuf = (ibuf + 1 == STAGES) ? 0 : ibuf + 1;
+    ++issued;
+    if (++ici == kpt) {
+      ici = 0;
+      if (++iti == p.ntaps) {
+        iti = 0;
+        if (++it < count) setup_rows(mslot + it * mslots);
+      }
+      if (it < count) set_tap(iti);
+    }
+  };
+  if (count > 0) {
+    setup_rows(mslot);
+    set_tap(0);
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES - 1; ++sidx)
+      if (issued < total) issue_next();
+  }
+  for (int ct = 0; ct < count; ++ct) {
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) {
+      // the tile about to be consumed must have landed; newer tiles may stay in flight
+      if (STAGES == 3 && issued - consumed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (STAGES == 3) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      } else {
+        __syncthreads();
+      }
+      if (issued < total) issue_next();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 af[MI], bf[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int r = wm * (MI * 16) + i * 16 + fl;
+          af[i] = As[buf * BM * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int r = wn * 64 + i * 16 + fl;
+          bf[i] = Bs[buf * BN * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))];
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MMA<T>::run(bf[ni], af[mi], acc[ni][mi]);
+      }
+      buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+      ++consumed;
+    }
+    // ---- epilogue of tile ct: registers -> NHWC (4 consecutive channels per lane), no LDS, no barrier
+    const int m0 = (mslot + ct * mslots) * BM;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (MI * 16) + mi * 16 + fl;
+      long long off = -1;
+      if (flat) {
+        if (m < p.M) off = (long long)m * p.N;
+      } else if (m < p.M) {
+        const int v = m / cls_hw;
+        const int rem = m - v * cls_hw;
+        const int ca = rem / p.cls_w, cb = rem - ca * p.cls_w;
+        off = (((long long)v * p.OH + ca * p.cs + p.py) * p.OW + cb * p.cs + p.px) * p.N;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + g * 4;
+        if (STATS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
+        }
+        if (off >= 0 && n < p.N) {
+          T* dst = Y + off + n;
+          float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+          if (p.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += Elem<T>::ld(dst + r);
+          }
+          if (sizeof(T) == 4) {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            u32x2 pk; pk[0] = pack_bf16x2(v[0], v[1]); pk[1] = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)dst = pk;
+          }
+        }
+      }
+    }
+  }
+  if (STATS) {
+    // one flush per workgroup: lanes -> 16-lane groups -> waves (LDS) -> atomics into a slot
+    __syncthreads();
+    float* red = (float*)smem;  // [WM][BN][2]
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = st_s[ni][r], ss = st_q[ni][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+        if (fl == 0) {
+          const int nl = wn * 64 + ni * 16 + g * 4 + r;
+          red[(wm * BN + nl) * 2] = s;
+          red[(wm * BN + nl) * 2 + 1] = ss;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N && count > 0) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; ss += red[(w * BN + tid) * 2 + 1]; }
+      float* st = p.stats + (long long)(mslot % p.nslot) * 2 * p.N;
+      atomicAdd(st + n0 + tid, s);
+      atomicAdd(st + p.N + n0 + tid, ss);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // wgrad: dW[K, N] (fp32 split-slabs) = sum over pixels A(m, k) * dY(m, n).
 // Tile BKW (k rows: one tap x BKW input channels) x BNW, reduction chunks of BR pixels.
 // LDS tiles keep the natural [pixel][channel] layout (coalesced 16-byte staging); the
@@ -371,8 +694,16 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   const int c_end = min(nchunks, c_begin + p.chunks_per_split);
 
   u32x4 ra[A_CH], rb[B_CH];
+  // 1x1 stride-1 (and Dense): reduction pixel m reads input pixel m -- no decode
+  const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.IH == p.OH && p.IW == p.OW;
+  const int ohow = p.OH * p.OW;
+  const float inv_ow = 1.0f / (float)p.OW;
   auto load_chunk = [&](int c) {
     const int mbase = c * BR;
+    // (image, pixel-in-image) of the chunk's first pixel: ONE division per chunk (uniform), the
+    // per-lane pixel then needs at most two wrap steps and a reciprocal multiply (exact: rem < 2^14)
+    const int vbase = flat ? 0 : mbase / ohow;
+    const int rbase = flat ? 0 : mbase - vbase * ohow;
 #pragma unroll
     for (int j = 0; j < A_CH; ++j) {
       const int id = tid + 256 * j;
@@ -380,12 +711,18 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
       const int m = mbase + px;
       ra[j] = zero16();
       if (m < p.M) {
-        const int v = m / (p.OH * p.OW);
-        const int rem = m - v * (p.OH * p.OW);
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        const int iy = oy * p.stride - p.pad + ty, ix = ox * p.stride - p.pad + tx;
-        if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
-          ra[j] = ld16(X + (((long long)v * p.IH + iy) * p.IW + ix) * p.pixpitch + ci0 + cc * EPC);
+        if (flat) {
+          ra[j] = ld16(X + (long long)m * p.pixpitch + ci0 + cc * EPC);
+        } else {
+          int v = vbase, rem = rbase + px;
+          if (rem >= ohow) { rem -= ohow; ++v; }
+          if (rem >= ohow) { rem -= ohow; ++v; }
+          if (rem >= ohow) { v = m / ohow; rem = m - v * ohow; }     // tiny images only
+          const int oy = (int)(((float)rem + 0.5f) * inv_ow), ox = rem - oy * p.OW;
+          const int iy = oy * p.stride - p.pad + ty, ix = ox * p.stride - p.pad + tx;
+          if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+            ra[j] = ld16(X + (((long long)v * p.IH + iy) * p.IW + ix) * p.pixpitch + ci0 + cc * EPC);
+        }
       }
     }
 #pragma unroll
@@ -701,8 +1038,86 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   const size_t epi = 128 * (BN * 2 + 8) + 128 * sizeof(long long);
   if (sizeof(T) == 2 && epi > lds) lds = epi;
   const bool st = p.stats != nullptr;
-#define L(BNv, STv) \
-  hipLaunchKernelGGL((conv_igemm<T, MODE, BNv, STv>), dim3(grid), dim3(256), lds, stream, p)
+  static const bool no_glds = getenv("SIMCLR_NO_GLDS") != nullptr;   // A/B switches for benchmarking
+  static const bool no_persist = getenv("SIMCLR_NO_PERSISTENT") != nullptr;
+  if (!no_glds && !no_persist && p.ntaps > 0 && p.n_tiles <= 64) {
+    // Tile choice.  128x128 / 128x64 (4 waves, 2-3 workgroups per CU) is bounded by the L2->LDS
+    // load path at ~64 FLOP per loaded byte; long-K layers use 256x128 (8 waves, 1 workgroup per
+    // CU, 85 FLOP/B).  SIMCLR_TILE=128|256 forces one for A/B measurements.
+    static const char* tile_env = getenv("SIMCLR_TILE");
+    const int KT = p.ntaps * (p.IC * (int)sizeof(T) / 128);
+    bool big = false;   // measured: slower than 2x(128x128) on every ResNet-50 layer (profiles/r01 notes)
+    if (tile_env) big = BN == 128 && atoi(tile_env) == 256;
+    static const char* stage_env = getenv("SIMCLR_STAGES");
+    const bool three = stage_env && atoi(stage_env) == 3;
+    (void)KT;
+    if (big) {
+      p.m_tiles = ceil_div(p.M, 256);
+      const int unit = 8 * p.n_tiles;
+      int pg = (256 / unit) * unit;
+      if (pg < unit) pg = unit;
+      const int need = ceil_div(p.m_tiles, 8) * unit;
+      if (pg > need) pg = need;
+      const size_t plds = (three ? 3 : 2) * (256 + 128) * 128;
+      static bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
+      if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128);
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128);
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+        attr_set = true;
+      }
+      if (three) {
+        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true>), dim3(pg), dim3(512), plds, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false>), dim3(pg), dim3(512), plds, stream, p);
+      } else {
+        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true>), dim3(pg), dim3(512), plds, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false>), dim3(pg), dim3(512), plds, stream, p);
+      }
+      return;
+    }
+    // persistent grid: 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one per tile
+    const int unit = 8 * p.n_tiles;
+    if (three && BN == 128) {   // experimental: 3-stage ring, 96 KB LDS, 1 workgroup per CU
+      int pg = (256 / unit) * unit;
+      if (pg < unit) pg = unit;
+      const int need = ceil_div(p.m_tiles, 8) * unit;
+      if (pg > need) pg = need;
+      const size_t plds = 3 * (128 + 128) * 128;
+      static bool attr3 = false;
+      if (!attr3) {
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        attr3 = true;
+      }
+      if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true>), dim3(pg), dim3(256), plds, stream, p);
+      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false>), dim3(pg), dim3(256), plds, stream, p);
+      return;
+    }
+    const int resident = (BN == 64 ? 3 : 2) * 256;      // workgroups that fit: LDS 48 KB / 64 KB each
+    int pg = (resident / unit) * unit;
+    if (pg < unit) pg = unit;
+    const int need = ceil_div(p.m_tiles, 8) * unit;     // enough workgroups to give every M-tile a slot
+    if (pg > need) pg = need;
+    const size_t plds = 2 * (128 + BN) * 128;
+#define LP(BNv, STv) \
+    hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv>), dim3(pg), dim3(256), plds, stream, p)
+    if (BN == 64) { if (st) LP(64, true); else LP(64, false); }
+    else { if (st) LP(128, true); else LP(128, false); }
+#undef LP
+    return;
+  }
+#define L(BNv, STv)                                                                                    \
+  do {                                                                                                 \
+    if (no_glds) hipLaunchKernelGGL((conv_igemm<T, MODE, BNv, STv, false>), dim3(grid), dim3(256), lds, stream, p); \
+    else hipLaunchKernelGGL((conv_igemm<T, MODE, BNv, STv, true>), dim3(grid), dim3(256), lds, stream, p);          \
+  } while (0)
   if (BN == 64) { if (st) L(64, true); else L(64, false); }
   else { if (st) L(128, true); else L(128, false); }
 #undef L
@@ -717,7 +1132,16 @@ int launch_igemm(const ConvP& p0, hipStream_t stream) {
   if (MODE == MODE_FWD || p.stride == 1) {
     p.cs = 1; p.py = 0; p.px = 0; p.cls_h = p.OH; p.cls_w = p.OW;
     p.ntaps = p.KH * p.KW;
-    for (int t = 0; t < p.ntaps; ++t) p.taps[t] = t;
+    p.tap_w = p.dy_w = p.dx_w = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+      p.taps[t] = t;
+      const int ty = t / p.KW, tx = t % p.KW;
+      // fwd: row base = (oy*s-pad, ox*s-pad), tap adds (+ty,+tx); dgrad s1: base = (oy, ox), tap adds (pad-ty, pad-tx)
+      const int dy = (MODE == MODE_FWD) ? ty : p.pad - ty, dx = (MODE == MODE_FWD) ? tx : p.pad - tx;
+      p.tap_w |= (unsigned long long)t << (4 * t);
+      p.dy_w |= (unsigned long long)(dy + 8) << (4 * t);
+      p.dx_w |= (unsigned long long)(dx + 8) << (4 * t);
+    }
     p.M = p.V * p.OH * p.OW;
     launch_igemm_one<T, MODE>(p, stream);
     return 0;
@@ -730,10 +1154,16 @@ int launch_igemm(const ConvP& p0, hipStream_t stream) {
       q.cls_h = (p.OH - py + S - 1) / S;
       q.cls_w = (p.OW - px + S - 1) / S;
       q.ntaps = 0;
+      q.tap_w = q.dy_w = q.dx_w = 0;
       for (int ty = 0; ty < p.KH; ++ty)
         for (int tx = 0; tx < p.KW; ++tx)
-          if ((py + p.pad - ty) % S == 0 && (px + p.pad - tx) % S == 0 && q.ntaps < 9)
+          if ((py + p.pad - ty) % S == 0 && (px + p.pad - tx) % S == 0 && q.ntaps < 9) {
+            // class rows have base pixel (a, b); this tap reads dy pixel (a + (py+pad-ty)/S, b + (px+pad-tx)/S)
+            q.tap_w |= (unsigned long long)(ty * p.KW + tx) << (4 * q.ntaps);
+            q.dy_w |= (unsigned long long)((py + p.pad - ty) / S + 8) << (4 * q.ntaps);
+            q.dx_w |= (unsigned long long)((px + p.pad - tx) / S + 8) << (4 * q.ntaps);
             q.taps[q.ntaps++] = ty * p.KW + tx;
+          }
       q.M = p.V * q.cls_h * q.cls_w;
       if (q.ntaps == 0 && p.accumulate) continue;   // nothing to add
       launch_igemm_one<T, MODE>(q, stream);
