@@ -85,6 +85,15 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
 int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulate, int V, int IH, int IW,
                         int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,
                         simclr_stream_t stream);
+/* dgrad whose output is the gradient wrt a BatchNormRelu output (tf2/resnet.py:74-78): the ReLU mask and
+ * the BatchNorm-backward reductions sum(dm), sum(dm*x^) are fused into the epilogue; dx receives
+ * dm = dx*mask.  stats float[nslot][2][Cin] zeroed by the caller.  mask_mode 1: bn_mask>0 (tensor after the
+ * ReLU, e.g. the block output of resnet.py:487); 2: bn_x*scale+shift>0.  stride 1 only. */
+int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumulate, const void* bn_x,
+                           const void* bn_mask, const float* bn_scale, const float* bn_shift,
+                           const float* bn_mean, const float* bn_rstd, int mask_mode, float* stats, int nslot,
+                           int V, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                           int stride, int pad, int dtype, simclr_stream_t stream);
 size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int Cout, int KH, int KW,
                                            int dtype);
 /* dw[KH*KW*Cin][Cout] fp32 (HWIO) (+)= x^T * dy.  `pixpitch` = elements between neighbouring pixels

@@ -44,6 +44,14 @@ struct ConvP {
   // 4-bit fields, tap i at bits [4i,4i+4): tap id, dy+8, dx+8 (input offset of tap i relative to the per-row
   // base pixel).  Packed words instead of arrays: dynamically indexed kernel-argument arrays go to scratch.
   unsigned long long tap_w, dy_w, dx_w;
+  // Fused BatchNorm-backward reduce (dgrad only): the output IS the gradient wrt a BN(+ReLU) output, so
+  // the epilogue masks it (ReLU), accumulates sum(dm) and sum(dm * x^) per channel into `stats` and
+  // stores dm.  bn_x = that BN's raw input (same shape as y); bn_mask (mode 1) = tensor whose sign
+  // gives the ReLU mask (the block output); mode 2 = mask recomputed from bn_x*scale+shift.
+  const void* bn_x;
+  const void* bn_mask;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
+  int bn_mode;     // 0 off, 1 mask tensor, 2 recompute
 };
 
 template <typename T> struct MMA;
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 // N-tiles) sit on the same XCD and advance in lockstep, so the gathered A tile is served by
 // that XCD's L2.
 // ------------------------------------------------------------------------------------
-template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS>
+template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void conv_igemm_persistent(const ConvP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* As = (u32x4*)smem;                       // [STAGES][BM*8]
   u32x4* Bs = As + STAGES * BM * 8;               // [STAGES][BN*8]
+  float* bnp = (float*)(Bs + STAGES * BN * 8);    // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -486,6 +495,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
     }
   };
 
+  if (BNEPI) {
+    for (int i = tid; i < BN; i += NW * 64) {
+      const int n = n0 + i;
+      const bool ok = n < p.N;
+      bnp[i] = (ok && p.bn_mode == 2) ? p.bn_scale[n] : 0.f;
+      bnp[BN + i] = (ok && p.bn_mode == 2) ? p.bn_shift[n] : 0.f;
+      bnp[2 * BN + i] = ok ? p.bn_mean[n] : 0.f;
+      bnp[3 * BN + i] = ok ? p.bn_rstd[n] : 0.f;
+    }
+    // visibility: the first barrier of the k-loop (or the explicit one before the flush) orders these writes
+  }
   float st_s[NI][4], st_q[NI][4];
   if (STATS) {
 #pragma unroll
@@ -574,7 +594,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * 64 + ni * 16 + g * 4;
-        if (STATS) {
+        if (STATS && !BNEPI) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
         }
@@ -584,6 +604,41 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
           if (p.accumulate) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += Elem<T>::ld(dst + r);
+          }
+          if (BNEPI) {
+            // v = gradient wrt the BN(+ReLU) output at (row, channels n..n+3)
+            const int nl = wn * 64 + ni * 16 + g * 4;
+            float xf[4], mk[4];
+            if (sizeof(T) == 4) {
+              const float4 xv = *(const float4*)((const float*)p.bn_x + off + n);
+              xf[0] = xv.x; xf[1] = xv.y; xf[2] = xv.z; xf[3] = xv.w;
+            } else {
+              const u32x2 xv = *(const u32x2*)((const uint16_t*)p.bn_x + off + n);
+              xf[0] = __uint_as_float(xv[0] << 16); xf[1] = __uint_as_float(xv[0] & 0xffff0000u);
+              xf[2] = __uint_as_float(xv[1] << 16); xf[3] = __uint_as_float(xv[1] & 0xffff0000u);
+            }
+            if (p.bn_mode == 1) {
+              if (sizeof(T) == 4) {
+                const float4 mv = *(const float4*)((const float*)p.bn_mask + off + n);
+                mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
+              } else {
+                const u32x2 mv = *(const u32x2*)((const uint16_t*)p.bn_mask + off + n);
+                mk[0] = __uint_as_float(mv[0] << 16); mk[1] = __uint_as_float(mv[0] & 0xffff0000u);
+                mk[2] = __uint_as_float(mv[1] << 16); mk[3] = __uint_as_float(mv[1] & 0xffff0000u);
+              }
+            } else {
+              const float4 sc = *(const float4*)(bnp + nl), sh = *(const float4*)(bnp + BN + nl);
+              mk[0] = fmaf(xf[0], sc.x, sh.x); mk[1] = fmaf(xf[1], sc.y, sh.y);
+              mk[2] = fmaf(xf[2], sc.z, sh.z); mk[3] = fmaf(xf[3], sc.w, sh.w);
+            }
+            const float4 mu = *(const float4*)(bnp + 2 * BN + nl), rs = *(const float4*)(bnp + 3 * BN + nl);
+            const float mua[4] = {mu.x, mu.y, mu.z, mu.w}, rsa[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = mk[r] > 0.f ? v[r] : 0.f;
+              st_s[ni][r] += v[r];
+              st_q[ni][r] += v[r] * (xf[r] - mua[r]) * rsa[r];
+            }
           }
           if (sizeof(T) == 4) {
             *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -1040,7 +1095,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   const bool st = p.stats != nullptr;
   static const bool no_glds = getenv("SIMCLR_NO_GLDS") != nullptr;   // A/B switches for benchmarking
   static const bool no_persist = getenv("SIMCLR_NO_PERSISTENT") != nullptr;
-  if (!no_glds && !no_persist && p.ntaps > 0 && p.n_tiles <= 64) {
+  if ((p.bn_mode || (!no_glds && !no_persist)) && p.ntaps > 0 && p.n_tiles <= 64) {
     // Tile choice.  128x128 / 128x64 (4 waves, 2-3 workgroups per CU) is bounded by the L2->LDS
     // load path at ~64 FLOP per loaded byte; long-K layers use 256x128 (8 waves, 1 workgroup per
     // CU, 85 FLOP/B).  SIMCLR_TILE=128|256 forces one for A/B measurements.
@@ -1051,7 +1106,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     static const char* stage_env = getenv("SIMCLR_STAGES");
     const bool three = stage_env && atoi(stage_env) == 3;
     (void)KT;
-    if (big) {
+    if (big && !p.bn_mode) {
       p.m_tiles = ceil_div(p.M, 256);
       const int unit = 8 * p.n_tiles;
       int pg = (256 / unit) * unit;
@@ -1061,28 +1116,28 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       const size_t plds = (three ? 3 : 2) * (256 + 128) * 128;
       static bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
       if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true>,
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false>,
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true>,
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false>,
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
         attr_set = true;
       }
       if (three) {
-        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true>), dim3(pg), dim3(512), plds, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false>), dim3(pg), dim3(512), plds, stream, p);
+        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true, false>), dim3(pg), dim3(512), plds, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false, false>), dim3(pg), dim3(512), plds, stream, p);
       } else {
-        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true>), dim3(pg), dim3(512), plds, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false>), dim3(pg), dim3(512), plds, stream, p);
+        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true, false>), dim3(pg), dim3(512), plds, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false, false>), dim3(pg), dim3(512), plds, stream, p);
       }
       return;
     }
     // persistent grid: 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one per tile
     const int unit = 8 * p.n_tiles;
-    if (three && BN == 128) {   // experimental: 3-stage ring, 96 KB LDS, 1 workgroup per CU
+    if (three && BN == 128 && !p.bn_mode) {   // experimental: 3-stage ring, 96 KB LDS, 1 workgroup per CU
       int pg = (256 / unit) * unit;
       if (pg < unit) pg = unit;
       const int need = ceil_div(p.m_tiles, 8) * unit;
@@ -1090,14 +1145,14 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       const size_t plds = 3 * (128 + 128) * 128;
       static bool attr3 = false;
       if (!attr3) {
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true>,
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false>,
+        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
         attr3 = true;
       }
-      if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true>), dim3(pg), dim3(256), plds, stream, p);
-      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false>), dim3(pg), dim3(256), plds, stream, p);
+      if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true, false>), dim3(pg), dim3(256), plds, stream, p);
+      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false, false>), dim3(pg), dim3(256), plds, stream, p);
       return;
     }
     const int resident = (BN == 64 ? 3 : 2) * 256;      // workgroups that fit: LDS 48 KB / 64 KB each
@@ -1105,11 +1160,13 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     if (pg < unit) pg = unit;
     const int need = ceil_div(p.m_tiles, 8) * unit;     // enough workgroups to give every M-tile a slot
     if (pg > need) pg = need;
-    const size_t plds = 2 * (128 + BN) * 128;
-#define LP(BNv, STv) \
-    hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv>), dim3(pg), dim3(256), plds, stream, p)
-    if (BN == 64) { if (st) LP(64, true); else LP(64, false); }
-    else { if (st) LP(128, true); else LP(128, false); }
+    const size_t plds = 2 * (128 + BN) * 128 + (p.bn_mode ? 4 * BN * sizeof(float) : 0);
+#define LP(BNv, STv, BEv) \
+    hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
+    if (p.bn_mode) {           // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
+      if (BN == 64) LP(64, true, true); else LP(128, true, true);
+    } else if (BN == 64) { if (st) LP(64, true, false); else LP(64, false, false); }
+    else { if (st) LP(128, true, false); else LP(128, false, false); }
 #undef LP
     return;
   }
@@ -1216,6 +1273,39 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
   p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cout;
   p.M = V * IH * IW; p.K = KH * KW * Cout;
+  if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
+  else launch_igemm<float, MODE_DGRAD>(p, stream);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// Data gradient with the BatchNorm-backward reduce of the PRODUCER layer fused into the epilogue.
+// dx here is the gradient wrt the output of a BatchNormRelu whose raw input is bn_x ([V,IH,IW,Cin]):
+// the kernel stores dm = dx * relu_mask and adds per-channel (sum dm, sum dm*x^) into
+// stats[nslot][2][Cin] (zeroed by the caller).  mask_mode 1: mask = bn_mask > 0 (bn_mask = the tensor
+// after the ReLU, e.g. the residual block output); 2: mask = bn_x*scale+shift > 0.
+int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumulate, const void* bn_x,
+                           const void* bn_mask, const float* bn_scale, const float* bn_shift,
+                           const float* bn_mean, const float* bn_rstd, int mask_mode, float* stats, int nslot,
+                           int V, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                           int stride, int pad, int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_bn: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0, "conv2d_dgrad_bn: Cout=%d must be a multiple of %d", Cout, 8 * epc);
+  SIMCLR_CHECK_ARG(Cin % 4 == 0, "conv2d_dgrad_bn: Cin=%d must be a multiple of 4", Cin);
+  SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad_bn: M overflows int32");
+  SIMCLR_CHECK_ARG(KH * KW <= 9 && stride == 1, "conv2d_dgrad_bn: stride-1 convolutions with <= 9 taps only");
+  SIMCLR_CHECK_ARG(mask_mode == 1 || mask_mode == 2, "conv2d_dgrad_bn: mask_mode must be 1 or 2");
+  SIMCLR_CHECK_ARG(bn_x && bn_mean && bn_rstd && stats && nslot > 0, "conv2d_dgrad_bn: null BN argument");
+  SIMCLR_CHECK_ARG(mask_mode != 1 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 needs bn_mask");
+  SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn: mask_mode 2 needs scale/shift");
+  ConvP p = {};
+  p.x = dy; p.w = w_d; p.y = dx; p.stats = stats; p.nslot = nslot; p.accumulate = accumulate;
+  p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cout;
+  p.M = V * IH * IW; p.K = KH * KW * Cout;
+  p.bn_x = bn_x; p.bn_mask = bn_mask; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+  p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.bn_mode = mask_mode;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
   else launch_igemm<float, MODE_DGRAD>(p, stream);
   SIMCLR_CHECK_LAUNCH();

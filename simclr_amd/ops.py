@@ -161,6 +161,26 @@ def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=Fals
     return out
 
 
+def conv2d_dgrad_bn(dy, w_d, KH, KW, pad, IH, IW, bn, out=None, accumulate=False):
+    """dgrad + fused BN-backward reduce of the producer BatchNormRelu.  `bn` = dict(x, mask, scale, shift,
+    mean, rstd, mode).  Returns (dm, partial[NSLOT,2,Cin])."""
+    V, OH, OW, Cout = dy.shape
+    Cin = w_d.shape[0]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(V, IH, IW, Cin, device=dy.device, dtype=dy.dtype)
+    partial = new_stats(Cin, dy.device)
+    K = KH * KW * Cout
+    esz = dy.element_size()
+    _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin,
+            esz * (V * OH * OW * Cout + (2 + (bn['mode'] == 1)) * V * IH * IW * Cin + K * Cin),
+            lambda: lib().conv2d_dgrad_bn(_p(dy), _p(w_d), _p(out), int(accumulate), _p(bn['x']), _p(bn.get('mask')),
+                                          _p(bn.get('scale')), _p(bn.get('shift')), _p(bn['mean']), _p(bn['rstd']),
+                                          bn['mode'], _p(partial), NSLOT, V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
+                                          pad, dt(dy), _s()))
+    return out, partial
+
+
 _wgrad_ws = {}
 
 

@@ -199,6 +199,32 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         self.saved['masked'] = bool(relu)
         return Act(y)
 
+    def fusion_info(self, mask_src=None):
+        """What a consumer conv's dgrad epilogue needs to fuse this layer's backward reduce
+        (simclr_conv2d_dgrad_bn): plain BN+ReLU -> mask recomputed from x (mode 2); residual tail
+        -> mask from the block output (mode 1)."""
+        s = self.saved
+        if mask_src is not None:
+            return dict(x=s['x'], mask=mask_src, mean=s['mean'], rstd=s['rstd'], mode=1)
+        assert s.get('masked'), 'fusion_info without mask_src needs a BN+ReLU layer'
+        return dict(x=s['x'], scale=s['scale'], shift=s['shift'], mean=s['mean'], rstd=s['rstd'], mode=2)
+
+    def backward_fused(self, dm, partial):
+        """Second half of the backward when the reduce was fused into the producing dgrad: dm is the
+        already-masked gradient, partial the per-channel (sum dm, sum dm*x^) slots."""
+        s = self.saved
+        local = ops.bn_reduce_slots(partial)
+        glob = local
+        R = num_replicas(RT.strategy)
+        if FLAGS.global_bn and R > 1:
+            glob = RT.strategy.all_reduce_sum(local.clone())
+        dgamma = self.gamma.ensure_grad() if self.gamma is not None and self.gamma.trainable else None
+        dbeta = self.beta.ensure_grad() if self.beta is not None and self.beta.trainable else None
+        c1, c2 = ops.bn_bwd_finalize(local, glob, s['count'], dgamma, dbeta)
+        dx, _ = ops.bn_bwd_apply(dm, s['x'], None, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2, 0)
+        self.saved = None
+        return dx
+
     def backward(self, dy, mask_src=None, mask_mode=None, want_masked=False):
         """dy: gradient wrt this layer's (activated) output.  Returns (dx, dy_masked)."""
         s = self.saved
@@ -285,7 +311,9 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         self.saved = dict(x=x, H=H, W=W, pad=pad)
         return Act(y, stats)
 
-    def backward(self, dy, need_dx=True, dx_out=None, accumulate=False):
+    def backward(self, dy, need_dx=True, dx_out=None, accumulate=False, fuse_bn=None):
+        """Returns dx, or (dm, partial) when `fuse_bn` (BatchNormRelu.fusion_info of the layer that
+        produced this conv's input) asks for the fused BN-backward reduce (stride-1 convs only)."""
         k, s = self.kernel_size, self.strides
         sv = self.saved
         self.saved = None
@@ -301,6 +329,10 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'], out=g.view(-1, self.filters))
         if not need_dx:
             return None
+        if fuse_bn is not None:
+            assert s == 1
+            return ops.conv2d_dgrad_bn(dy, self.w_d, k, k, sv['pad'], sv['H'], sv['W'], fuse_bn, out=dx_out,
+                                       accumulate=accumulate)
         return ops.conv2d_dgrad(dy, self.w_d, k, k, s, sv['pad'], sv['H'], sv['W'], out=dx_out,
                                 accumulate=accumulate)
 
@@ -364,14 +396,25 @@ class ResidualBlock(Layer):  # tf2/resnet.py:314-382
         self.out = out.t
         return out
 
-    def backward(self, dout):
-        dh, dsum = self.bn2.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
+    def tail_info(self):
+        return self.bn2.fusion_info(mask_src=self.out)
+
+    def backward(self, dout, dout_partial=None, prev_tail=None):
+        """dout_partial given: dout is already ReLU-masked and the tail BN's reduce is done (fused into
+        the next block's dgrad).  prev_tail: tail_info() of the block feeding this one -- its reduce is
+        fused into this block's last dgrad.  Returns (dx, partial-or-None)."""
+        if dout_partial is not None:
+            dh, dsum = self.bn2.backward_fused(dout, dout_partial), dout
+        else:
+            dh, dsum = self.bn2.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
         self.out = None
         dx = self.shortcut.backward(dsum) if self.shortcut is not None else dsum
-        da = self.conv2.backward(dh)
-        dh1, _ = self.bn1.backward(da)
+        dm1, part1 = self.conv2.backward(dh, fuse_bn=self.bn1.fusion_info())
+        dh1 = self.bn1.backward_fused(dm1, part1)
+        if prev_tail is not None and self.conv1.strides == 1:
+            return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
         self.conv1.backward(dh1, dx_out=dx, accumulate=True)
-        return dx
+        return dx, None
 
 
 class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
@@ -403,16 +446,28 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         self.out = out.t
         return out
 
-    def backward(self, dout):
-        dh3, dsum = self.bn3.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
+    def tail_info(self):
+        return self.bn3.fusion_info(mask_src=self.out)
+
+    def backward(self, dout, dout_partial=None, prev_tail=None):
+        """See ResidualBlock.backward.  Returns (dx, partial-or-None)."""
+        if dout_partial is not None:
+            dh3, dsum = self.bn3.backward_fused(dout, dout_partial), dout
+        else:
+            dh3, dsum = self.bn3.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
         self.out = None
         dx = self.shortcut.backward(dsum) if self.shortcut is not None else dsum
-        da2 = self.conv3.backward(dh3)
-        dh2, _ = self.bn2.backward(da2)
-        da1 = self.conv2.backward(dh2)
-        dh1, _ = self.bn1.backward(da1)
+        dm2, part2 = self.conv3.backward(dh3, fuse_bn=self.bn2.fusion_info())
+        dh2 = self.bn2.backward_fused(dm2, part2)
+        if self.conv2.strides == 1:
+            dm1, part1 = self.conv2.backward(dh2, fuse_bn=self.bn1.fusion_info())
+            dh1 = self.bn1.backward_fused(dm1, part1)
+        else:
+            dh1, _ = self.bn1.backward(self.conv2.backward(dh2))
+        if prev_tail is not None:
+            return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
         self.conv1.backward(dh1, dx_out=dx, accumulate=True)
-        return dx
+        return dx, None
 
 
 class BlockGroup(Layer):  # tf2/resnet.py:490-526
@@ -432,10 +487,12 @@ class BlockGroup(Layer):  # tf2/resnet.py:490-526
             inputs = layer(inputs, training)
         return inputs
 
-    def backward(self, d):
-        for layer in reversed(self.layers):
-            d = layer.backward(d)
-        return d
+    def backward(self, d, partial=None, prev_tail=None):
+        """prev_tail: tail_info() of the last block of the previous group (None for group 1)."""
+        for i in range(len(self.layers) - 1, -1, -1):
+            pt = self.layers[i - 1].tail_info() if i > 0 else prev_tail
+            d, partial = self.layers[i].backward(d, partial, pt)
+        return d, partial
 
 
 class Resnet(Layer):  # tf2/resnet.py:529-699
@@ -502,8 +559,10 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
         _, H, W, _ = self._final.shape
         d = ops.global_avgpool_bwd(dh, H, W)
         self._final = None
+        partial = None
         for i, g in reversed(list(enumerate(self.block_groups))):
-            d = g.backward(d)
+            prev_tail = self.block_groups[i - 1].layers[-1].tail_info() if i > 0 else None
+            d, partial = g.backward(d, partial, prev_tail)
             if on_stage is not None:
                 on_stage(i + 1)
         if self._pool is not None:

@@ -229,6 +229,56 @@ def check_conv(V, H, W, Cin, Cout, k, stride, dtype, seed=0):
     return res
 
 
+def check_dgrad_bn(V, H, Cin, Cout, k, dtype, mask_mode, accumulate, seed=0):
+    """simclr_conv2d_dgrad_bn (dgrad + fused ReLU mask + BN-backward sums) vs float64:
+    dm = (dgrad(dy) [+ prev]) * mask,  sums = (sum dm, sum dm * (x-mean)*rstd) per channel."""
+    g = torch.Generator().manual_seed(seed)
+    pad = (k - 1) // 2
+    x_raw = _rand((V, H, H, Cin), dtype, g) * 1.5 + 0.3          # raw input of the producer BN
+    w = _rand((k, k, Cin, Cout), dtype, g, (k * k * Cin) ** -0.5)
+    dy = _rand((V, H, H, Cout), dtype, g)
+    prev = _rand((V, H, H, Cin), dtype, g) if accumulate else None
+    mask_t = _rand((V, H, H, Cin), dtype, g)                     # mode 1: sign gives the mask
+    scale = torch.rand(Cin, generator=g) - 0.4
+    shift = 0.3 * torch.randn(Cin, generator=g)
+    mean = 0.2 * torch.randn(Cin, generator=g)
+    rstd = 0.5 + torch.rand(Cin, generator=g)
+    # reference
+    xr = torch.zeros(V, Cin, H, H, dtype=torch.float64, requires_grad=True)
+    yr = F.conv2d(F.pad(xr, (pad, k - 1 - pad, pad, k - 1 - pad)), w.double().permute(3, 2, 0, 1))
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    da = xr.grad.permute(0, 2, 3, 1)
+    if accumulate:
+        da = da + prev.double()
+    if mask_mode == 1:
+        m = mask_t.double() > 0
+    else:
+        m = (x_raw.float() * scale + shift).double() > 0          # fp32 fma like the kernel
+    dm_ref = torch.where(m, da, torch.zeros(1, dtype=torch.float64))
+    xh = (x_raw.double() - mean.double()) * rstd.double()
+    s1 = dm_ref.sum((0, 1, 2)); s2 = (dm_ref * xh).sum((0, 1, 2))
+    # device
+    w_d = ops.prep_weights(w.float().to(DEV), 1, dtype)
+    bn = dict(x=x_raw.to(DEV), mask=mask_t.to(DEV) if mask_mode == 1 else None, scale=scale.to(DEV),
+              shift=shift.to(DEV), mean=mean.to(DEV), rstd=rstd.to(DEV), mode=mask_mode)
+    out = prev.to(DEV).clone() if accumulate else None
+    dm, part = ops.conv2d_dgrad_bn(dy.to(DEV), w_d, k, k, pad, H, H, bn, out=out, accumulate=accumulate)
+    sums = ops.bn_reduce_slots(part)
+    torch.cuda.synchronize()
+    tag = 'V%d %dx%d %d->%d k%d %s mode%d acc%d' % (V, H, H, Cin, Cout, k, str(dtype).split('.')[-1], mask_mode, accumulate)
+    t = _tol(dtype)
+    # elements whose fp32 mask argument is within rounding of 0 may legitimately flip: compare where |arg| is clear
+    if mask_mode == 2:
+        arg = (x_raw.float() * scale + shift).abs()
+        clear = arg > 1e-3 * (arg.max() + 1e-9)
+        got = torch.where(clear, dm.double().cpu(), dm_ref)
+    else:
+        got = dm
+    return [_res('dgrad_bn_dm ' + tag, got, dm_ref, t * (2 if accumulate else 1)),
+            _res('dgrad_bn_sum ' + tag, sums[0], s1, 2e-3 if dtype == torch.bfloat16 else 1e-4, 1e-3 * float(dm_ref.abs().sum((0, 1, 2)).max())),
+            _res('dgrad_bn_sumxhat ' + tag, sums[1], s2, 2e-3 if dtype == torch.bfloat16 else 1e-4, 1e-3 * float((dm_ref * xh).abs().sum((0, 1, 2)).max()))]
+
+
 def check_stem(V, H, k, stride, Cout, dtype, seed=0):
     g = torch.Generator().manual_seed(seed)
     img = torch.rand(V // 2, H, H, 6, generator=g)

@@ -58,6 +58,8 @@ def main():
                                         (2, 16, 64, 256, 1, 2), (3, 9, 128, 192, 3, 1), (130, 1, 128, 64, 1, 1),
                                         (2, 12, 256, 128, 3, 2)]:
             run(gc.check_conv, V, H, H, Cin, Cout, k, s, dt)
+        for (V, H, Cin, Cout, k, mode, acc) in [(3, 9, 128, 64, 1, 2, 0), (2, 14, 64, 128, 3, 2, 0), (3, 8, 256, 64, 1, 1, 1), (2, 7, 64, 64, 3, 1, 0)]:
+            run(gc.check_dgrad_bn, V, H, Cin, Cout, k, dt, mode, acc)
         run(gc.check_stem, 4, 32, 7, 2, 64, dt)
         run(gc.check_stem, 4, 16, 3, 1, 64, dt)
         run(gc.check_stem, 2, 224, 7, 2, 64, dt)
