@@ -397,9 +397,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   constexpr int BJ = BN / (8 * NW);
   static_assert(AJ >= 1 && BJ >= 1 && MI >= 1, "tile / wave configuration");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* As = (u32x4*)smem;                       // [STAGES][BM*8]
-  u32x4* Bs = As + STAGES * BM * 8;               // [STAGES][BN*8]
-  float* bnp = (float*)(Bs + STAGES * BN * 8);    // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile
+  // LDS: STAGES x [A tile (BM rows) | B tile (BN rows)] of 128-byte rows, then the epilogue scratch.
+  // A whole stage (>= BM*BN*2 bytes) doubles as the bf16 C staging buffer once it has been consumed.
+  constexpr int STG = (BM + BN) * 8;              // u32x4 per stage
+  u32x4* As = (u32x4*)smem;                       // stage s: As + s*STG
+  u32x4* Bs = As + BM * 8;                        // stage s: Bs + s*STG
+  float* bnp = (float*)(As + STAGES * STG);       // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile
+  long long* rowoff = (long long*)(bnp + 4 * BN); // [BM] output offsets of the tile rows (LDS epilogue)
+  constexpr bool LDS_EPI = sizeof(T) == 2;        // bf16: coalesced row-wise epilogue through LDS
+  constexpr int NTH = NW * 64;
+  constexpr int CPR = BN / 8;                     // 16-byte chunks (8 channels) per C row
+  constexpr int RPP = NTH / CPR;                  // rows per pass of the row-wise epilogue
+  static_assert(!LDS_EPI || (BM * BN * 2 <= STG * 16), "C tile must fit in one stage");
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -481,8 +490,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   auto issue_tile = [&](int ti, int ci, int buf) __attribute__((always_inline)) {
     const int ci0 = ci * BK;
     const int k0 = (int)((p.tap_w >> (4 * ti)) & 15) * p.IC + ci0;
-    unsigned char* a_dst = (unsigned char*)(As + buf * BM * 8) + wave * AJ * 1024;
-    unsigned char* b_dst = (unsigned char*)(Bs + buf * BN * 8) + wave * BJ * 1024;
+    unsigned char* a_dst = (unsigned char*)(As + buf * STG) + wave * AJ * 1024;
+    unsigned char* b_dst = (unsigned char*)(Bs + buf * STG) + wave * BJ * 1024;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const void* src = a_tok[j] ? (const void*)(a_tp[j] + ci0) : (const void*)&g_zero16;
@@ -506,6 +515,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
     }
     // visibility: the first barrier of the k-loop (or the explicit one before the flush) orders these writes
   }
+  // row-wise epilogue state: this thread's fixed 8-channel chunk and its partial sums
+  const int e_cc = tid % CPR;
+  float e_s[8], e_q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { e_s[e] = 0.f; e_q[e] = 0.f; }
   float st_s[NI][4], st_q[NI][4];
   if (STATS) {
 #pragma unroll
@@ -562,12 +576,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const int r = wm * (MI * 16) + i * 16 + fl;
-          af[i] = As[buf * BM * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))];
+          af[i] = As[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))];
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int r = wn * 64 + i * 16 + fl;
-          bf[i] = Bs[buf * BN * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))];
+          bf[i] = Bs[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))];
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -577,8 +591,77 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       buf = (buf + 1 == STAGES) ? 0 : buf + 1;
       ++consumed;
     }
-    // ---- epilogue of tile ct: registers -> NHWC (4 consecutive channels per lane), no LDS, no barrier
     const int m0 = (mslot + ct * mslots) * BM;
+    auto row_off = [&](int m) __attribute__((always_inline)) -> long long {
+      if (m >= p.M) return -1;
+      if (flat) return (long long)m * p.N;
+      const int v = m / cls_hw;
+      const int rem = m - v * cls_hw;
+      const int ca = rem / p.cls_w, cb = rem - ca * p.cls_w;
+      return (((long long)v * p.OH + ca * p.cs + p.py) * p.OW + cb * p.cs + p.px) * p.N;
+    };
+    if (LDS_EPI) {
+      // ---- bf16 epilogue through LDS: the stage consumed last is free until the next barrier-issue.
+      // 1) barrier (every wave is done reading it)  2) accumulators -> bf16 C tile (8-byte granules,
+      // XOR-swizzled by row)  3) barrier  4) row-wise pass: 16-byte coalesced loads of the BN input /
+      // mask / previous value, ReLU mask, per-channel sums, 16-byte coalesced stores.
+      const int cst = (buf == 0) ? STAGES - 1 : buf - 1;
+      unsigned char* Cs = (unsigned char*)(As + cst * STG);
+      __syncthreads();
+      if (tid < BM) rowoff[tid] = row_off(m0 + tid);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int ml = wm * (MI * 16) + mi * 16 + fl;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (STATS && !BNEPI) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
+          }
+          const int q = wn * 16 + ni * 4 + g;                    // 8-byte granule (4 channels) in the row
+          u32x2 pk;
+          pk[0] = pack_bf16x2(acc[ni][mi][0], acc[ni][mi][1]);
+          pk[1] = pack_bf16x2(acc[ni][mi][2], acc[ni][mi][3]);
+          *(u32x2*)(Cs + ml * (BN * 2) + ((q ^ ((ml & 7) << 1)) << 3)) = pk;
+        }
+      }
+      __syncthreads();
+      const int ncol = n0 + e_cc * 8;
+#pragma unroll 2
+      for (int r = tid / CPR; r < BM; r += RPP) {
+        const long long off = rowoff[r];
+        if (off < 0 || ncol >= p.N) continue;
+        const u32x4 cv = *(const u32x4*)(Cs + r * (BN * 2) + (((e_cc * 2) ^ ((r & 7) << 1)) << 3));
+        uint16_t* dst = (uint16_t*)Y + off + ncol;
+        float v[8];
+        chunk_to_f32<uint16_t>(cv, v);
+        if (p.accumulate) {
+          float o[8];
+          chunk_to_f32<uint16_t>(*(const u32x4*)dst, o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += o[e];
+        }
+        if (BNEPI) {
+          float xf[8], mk[8];
+          chunk_to_f32<uint16_t>(*(const u32x4*)((const uint16_t*)p.bn_x + off + ncol), xf);
+          if (p.bn_mode == 1) {
+            chunk_to_f32<uint16_t>(*(const u32x4*)((const uint16_t*)p.bn_mask + off + ncol), mk);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mk[e] = fmaf(xf[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            e_s[e] += v[e];
+            e_q[e] += v[e] * (xf[e] - bnp[2 * BN + e_cc * 8 + e]) * bnp[3 * BN + e_cc * 8 + e];
+          }
+        }
+        if (p.accumulate || BNEPI) *(u32x4*)dst = f32_to_chunk<uint16_t>(v);
+        else *(u32x4*)dst = cv;
+      }
+    } else {
+    // ---- fp32 parity mode: registers -> NHWC (4 consecutive channels per lane), no LDS, no barrier
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = m0 + wm * (MI * 16) + mi * 16 + fl;
@@ -649,6 +732,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         }
       }
     }
+    }
+  }
+  if (STATS && BNEPI && LDS_EPI) {
+    // flush of the row-wise sums: NTH threads = RPP row-lanes x CPR channel chunks -> LDS -> atomics
+    __syncthreads();
+    float* red = (float*)smem;  // [RPP][BN][2]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[((tid / CPR) * BN + e_cc * 8 + e) * 2] = e_s[e];
+      red[((tid / CPR) * BN + e_cc * 8 + e) * 2 + 1] = e_q[e];
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N && count > 0) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int w = 0; w < RPP; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+      float* st = p.stats + (long long)(mslot % p.nslot) * 2 * p.N;
+      atomicAdd(st + n0 + tid, s1);
+      atomicAdd(st + p.N + n0 + tid, s2);
+    }
+    return;
   }
   if (STATS) {
     // one flush per workgroup: lanes -> 16-lane groups -> waves (LDS) -> atomics into a slot
@@ -1096,71 +1199,17 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   static const bool no_glds = getenv("SIMCLR_NO_GLDS") != nullptr;   // A/B switches for benchmarking
   static const bool no_persist = getenv("SIMCLR_NO_PERSISTENT") != nullptr;
   if ((p.bn_mode || (!no_glds && !no_persist)) && p.ntaps > 0 && p.n_tiles <= 64) {
-    // Tile choice.  128x128 / 128x64 (4 waves, 2-3 workgroups per CU) is bounded by the L2->LDS
-    // load path at ~64 FLOP per loaded byte; long-K layers use 256x128 (8 waves, 1 workgroup per
-    // CU, 85 FLOP/B).  SIMCLR_TILE=128|256 forces one for A/B measurements.
-    static const char* tile_env = getenv("SIMCLR_TILE");
-    const int KT = p.ntaps * (p.IC * (int)sizeof(T) / 128);
-    bool big = false;   // measured: slower than 2x(128x128) on every ResNet-50 layer (profiles/r01 notes)
-    if (tile_env) big = BN == 128 && atoi(tile_env) == 256;
-    static const char* stage_env = getenv("SIMCLR_STAGES");
-    const bool three = stage_env && atoi(stage_env) == 3;
-    (void)KT;
-    if (big && !p.bn_mode) {
-      p.m_tiles = ceil_div(p.M, 256);
-      const int unit = 8 * p.n_tiles;
-      int pg = (256 / unit) * unit;
-      if (pg < unit) pg = unit;
-      const int need = ceil_div(p.m_tiles, 8) * unit;
-      if (pg > need) pg = need;
-      const size_t plds = (three ? 3 : 2) * (256 + 128) * 128;
-      static bool attr_set = false;   // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
-      if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 128);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-        attr_set = true;
-      }
-      if (three) {
-        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, true, false>), dim3(pg), dim3(512), plds, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 3, false, false>), dim3(pg), dim3(512), plds, stream, p);
-      } else {
-        if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, true, false>), dim3(pg), dim3(512), plds, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 256, 128, 8, 2, false, false>), dim3(pg), dim3(512), plds, stream, p);
-      }
-      return;
-    }
+    // Tile choice: 128x128 / 128x64, 4 waves, 2-stage LDS ring, 2-3 workgroups per CU.  Measured
+    // alternatives that were slower on every ResNet-50 layer (profiles/r01_notes.md): 256x128 with 8
+    // waves (one workgroup per CU), and 3-stage rings with counted vmcnt for either tile.
     // persistent grid: 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one per tile
     const int unit = 8 * p.n_tiles;
-    if (three && BN == 128 && !p.bn_mode) {   // experimental: 3-stage ring, 96 KB LDS, 1 workgroup per CU
-      int pg = (256 / unit) * unit;
-      if (pg < unit) pg = unit;
-      const int need = ceil_div(p.m_tiles, 8) * unit;
-      if (pg > need) pg = need;
-      const size_t plds = 3 * (128 + 128) * 128;
-      static bool attr3 = false;
-      if (!attr3) {
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-        hipFuncSetAttribute((const void*)conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-        attr3 = true;
-      }
-      if (st) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, true, false>), dim3(pg), dim3(256), plds, stream, p);
-      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 3, false, false>), dim3(pg), dim3(256), plds, stream, p);
-      return;
-    }
     const int resident = (BN == 64 ? 3 : 2) * 256;      // workgroups that fit: LDS 48 KB / 64 KB each
     int pg = (resident / unit) * unit;
     if (pg < unit) pg = unit;
     const int need = ceil_div(p.m_tiles, 8) * unit;     // enough workgroups to give every M-tile a slot
     if (pg > need) pg = need;
-    const size_t plds = 2 * (128 + BN) * 128 + (p.bn_mode ? 4 * BN * sizeof(float) : 0);
+    const size_t plds = 2 * (128 + BN) * 128 + 4 * BN * sizeof(float) + 128 * sizeof(long long);
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
     if (p.bn_mode) {           // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
