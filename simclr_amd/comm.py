@@ -41,7 +41,7 @@ class Strategy:
         R = self.num_replicas_in_sync
         n = tensor.shape[0] // R
         out = torch.empty((n,) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
-        if tensor.is_cuda:
+        if dist.get_backend(self.group) == 'nccl':
             dist.reduce_scatter_tensor(out, tensor.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
         else:  # gloo has no reduce_scatter: all_reduce + slice (same result)
             t = tensor.clone()
