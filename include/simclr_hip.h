@@ -72,9 +72,9 @@ int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long
 
 /* ---- convolution / dense: tf2/resnet.py:183-208 (Conv2dFixedPadding), tf2/model.py:143-154 ----- */
 /* master HWIO fp32 -> compute copies.  mode 0: [Cout][KH*KW*Cin] (fwd), 1: [Cin][KH*KW*Cout]
- * (dgrad), 2: stem [Cout][KHP][KWP][4] zero padded. */
+ * (dgrad), 2: stem [Cout][KHP][KWP][4] zero padded.  CinP/CoutP (0 = none): zero-padded channel dims. */
 int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,
-                        int KHP, int KWP, int dtype, simclr_stream_t stream);
+                        int KHP, int KWP, int CinP, int CoutP, int dtype, simclr_stream_t stream);
 /* y[V,OH,OW,Cout] = conv(x[V,IH,IW,Cin], w), explicit symmetric padding `pad` (resnet.py:167-180).
  * stats (nullable) float[nslot][2][Cout], zeroed by caller: per-channel partial (sum, sum sq) of y
  * for BatchNorm (resnet.py:50-78).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0. */
@@ -141,6 +141,19 @@ int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int 
                               simclr_stream_t stream);
 int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, int V, int HW, int C,
                               int dtype, simclr_stream_t stream);
+
+/* ---- ResNet-D shortcut pool (tf2/resnet.py:330-338,400-408) and selective-kernel unit (:266-277) ---- */
+int simclr_avgpool2_fwd(const void* x, void* y, int V, int H, int W, int C, int stride, int dtype,
+                        simclr_stream_t stream);
+int simclr_avgpool2_bwd(const void* dy, void* dx, int V, int H, int W, int C, int stride, int dtype,
+                        simclr_stream_t stream);
+int simclr_sk_pool_fwd(const void* a, void* g, int V, int HW, int f, int gpitch, int dtype, simclr_stream_t stream);
+int simclr_sk_mix_fwd(const void* a, const void* l, void* out, int V, int HW, int f, int lpitch, int dtype,
+                      simclr_stream_t stream);
+int simclr_sk_mix_bwd_logits(const void* a, const void* l, const void* dout, void* dl, int V, int HW, int f,
+                             int lpitch, int dtype, simclr_stream_t stream);
+int simclr_sk_mix_bwd_streams(const void* l, const void* dout, const void* dg, void* da, int V, int HW, int f,
+                              int lpitch, int gpitch, int dtype, simclr_stream_t stream);
 
 /* ---- supervised (linear-eval) head tail: tf2/objective.py:27-32, tf2/metrics.py:49-55 ---------- */
 int simclr_bias_softmax_xent(const void* z, const float* bias, const int* labels, int rows,

@@ -1139,33 +1139,33 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
 }
 
 // ---- weight re-layout (fp32 HWIO master -> compute copies) ---------------------------
-// mode 0: fwd   dst[co][(kh*KW+kw)*CI+ci]
-// mode 1: dgrad dst[ci][(kh*KW+kw)*CO+co]
-// mode 2: stem  dst[co][(kh*KWP+kw)*4+ci]   zero padded to KHP x KWP x 4
+// mode 0: fwd   dst[co][(kh*KW+kw)*CIP+ci]     (CIP >= CI, COP >= CO: zero-padded channel dims)
+// mode 1: dgrad dst[ci][(kh*KW+kw)*COP+co]
+// mode 2: stem  dst[co][(kh*KWP+kw)*4+ci]   zero padded to KHP x KWP x 4 (COP rows)
 template <typename T>
 __global__ void prep_weights(const float* __restrict__ w, T* __restrict__ dst, int KH, int KW, int CI,
-                             int CO, int mode, int KHP, int KWP) {
+                             int CO, int mode, int KHP, int KWP, int CIP, int COP) {
   long long total;
-  if (mode == 2) total = (long long)CO * KHP * KWP * 4;
-  else total = (long long)KH * KW * CI * CO;
+  if (mode == 2) total = (long long)COP * KHP * KWP * 4;
+  else total = (long long)KH * KW * CIP * COP;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     float v = 0.f;
     if (mode == 0) {
-      const int co = (int)(i / ((long long)KH * KW * CI));
-      const int k = (int)(i % ((long long)KH * KW * CI));
-      const int tap = k / CI, ci = k % CI;
-      v = w[((long long)tap * CI + ci) * CO + co];
+      const int co = (int)(i / ((long long)KH * KW * CIP));
+      const int k = (int)(i % ((long long)KH * KW * CIP));
+      const int tap = k / CIP, ci = k % CIP;
+      if (ci < CI && co < CO) v = w[((long long)tap * CI + ci) * CO + co];
     } else if (mode == 1) {
-      const int ci = (int)(i / ((long long)KH * KW * CO));
-      const int k = (int)(i % ((long long)KH * KW * CO));
-      const int tap = k / CO, co = k % CO;
-      v = w[((long long)tap * CI + ci) * CO + co];
+      const int ci = (int)(i / ((long long)KH * KW * COP));
+      const int k = (int)(i % ((long long)KH * KW * COP));
+      const int tap = k / COP, co = k % COP;
+      if (ci < CI && co < CO) v = w[((long long)tap * CI + ci) * CO + co];
     } else {
       const int co = (int)(i / (KHP * KWP * 4));
       const int k = (int)(i % (KHP * KWP * 4));
       const int kh = k / (KWP * 4), kw = (k / 4) % KWP, ci = k % 4;
-      if (kh < KH && kw < KW && ci < CI) v = w[(((long long)kh * KW + kw) * CI + ci) * CO + co];
+      if (kh < KH && kw < KW && ci < CI && co < CO) v = w[(((long long)kh * KW + kw) * CI + ci) * CO + co];
     }
     Elem<T>::st(dst + i, v);
   }
@@ -1462,17 +1462,22 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
 }
 
 // fp32 HWIO master weights -> compute-dtype copies.  mode 0 fwd, 1 dgrad, 2 stem (padded).
+// CinP/CoutP (>= Cin/Cout, 0 = no padding): channel dims of the destination, zero-filled beyond the
+// real channels (used where a layer's channel count is not a multiple of the 64-element k-tile).
 int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,
-                        int KHP, int KWP, int dtype, hipStream_t stream) {
+                        int KHP, int KWP, int CinP, int CoutP, int dtype, hipStream_t stream) {
   SIMCLR_CHECK_ARG(mode >= 0 && mode <= 2, "prep_weights: bad mode %d", mode);
-  const long long total = mode == 2 ? (long long)Cout * KHP * KWP * 4 : (long long)KH * KW * Cin * Cout;
+  if (CinP <= 0) CinP = Cin;
+  if (CoutP <= 0) CoutP = Cout;
+  SIMCLR_CHECK_ARG(CinP >= Cin && CoutP >= Cout, "prep_weights: padded dims smaller than real dims");
+  const long long total = mode == 2 ? (long long)CoutP * KHP * KWP * 4 : (long long)KH * KW * CinP * CoutP;
   const int grid = min(4096, ceil_div(total, 256));
   if (dtype == SIMCLR_DT_BF16)
     hipLaunchKernelGGL((prep_weights<uint16_t>), dim3(grid), dim3(256), 0, stream, w_hwio, (uint16_t*)dst,
-                       KH, KW, Cin, Cout, mode, KHP, KWP);
+                       KH, KW, Cin, Cout, mode, KHP, KWP, CinP, CoutP);
   else
     hipLaunchKernelGGL((prep_weights<float>), dim3(grid), dim3(256), 0, stream, w_hwio, (float*)dst, KH,
-                       KW, Cin, Cout, mode, KHP, KWP);
+                       KW, Cin, Cout, mode, KHP, KWP, CinP, CoutP);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

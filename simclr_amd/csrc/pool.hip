@@ -169,6 +169,174 @@ __global__ void global_avgpool_bwd(const T* __restrict__ dy, const T* __restrict
   }
 }
 
+// ---- ResNet-D shortcut: AveragePooling2D(2, strides, SAME if strides==1 else VALID after FixedPadding(2))
+// (tf2/resnet.py:330-338, 400-408).  stride 2: windows rows 2oy..2oy+1 (the (0,1) zero pad is part of
+// the tensor -> divisor always 4); stride 1 SAME: pad (0,1), TF divides by the number of VALID cells.
+template <typename T>
+__global__ void avgpool2_fwd(const T* __restrict__ x, T* __restrict__ y, int V, int H, int W, int C, int OH,
+                             int OW, int stride) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long long total = (long long)V * OH * OW * cpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const long long pix = i / cpr;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), v = (int)(pix / ((long long)OW * OH));
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    int cnt = 0;
+    for (int ky = 0; ky < 2; ++ky)
+      for (int kx = 0; kx < 2; ++kx) {
+        const int iy = oy * stride + ky, ix = ox * stride + kx;
+        if (iy < H && ix < W) {
+          float xv[EPC];
+          chunk_to_f32<T>(*(const u32x4*)(x + (((long long)v * H + iy) * W + ix) * C + cc * EPC), xv);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) acc[e] += xv[e];
+          ++cnt;
+        }
+      }
+    const float inv = 1.f / (float)(stride == 1 ? cnt : 4);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] *= inv;
+    *(u32x4*)(y + pix * C + cc * EPC) = f32_to_chunk<T>(acc);
+  }
+}
+template <typename T>
+__global__ void avgpool2_bwd(const T* __restrict__ dy, T* __restrict__ dx, int V, int H, int W, int C, int OH,
+                             int OW, int stride) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long long total = (long long)V * H * W * cpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const long long pix = i / cpr;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), v = (int)(pix / ((long long)W * H));
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int ky = 0; ky < 2; ++ky)
+      for (int kx = 0; kx < 2; ++kx) {
+        const int ty = iy - ky, tx = ix - kx;
+        if (ty < 0 || tx < 0 || ty % stride || tx % stride) continue;
+        const int oy = ty / stride, ox = tx / stride;
+        if (oy >= OH || ox >= OW) continue;
+        float w;
+        if (stride == 1) {
+          const int cnt = ((oy + 1 < H) ? 2 : 1) * ((ox + 1 < W) ? 2 : 1);
+          w = 1.f / (float)cnt;
+        } else {
+          w = 0.25f;
+        }
+        float d[EPC];
+        chunk_to_f32<T>(*(const u32x4*)(dy + (((long long)v * OH + oy) * OW + ox) * C + cc * EPC), d);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += d[e] * w;
+      }
+    *(u32x4*)(dx + pix * C + cc * EPC) = f32_to_chunk<T>(acc);
+  }
+}
+
+// ---- Selective-kernel unit (tf2/resnet.py:266-277).  a = [V, HW, 2f]: stream k occupies channels
+// [k*f, (k+1)*f).  g[v,c] = mean_hw(a0+a1);  mix = softmax over the two streams of l[v, k*f+c];
+// out = a0*m0 + a1*m1.
+template <typename T>
+__global__ void sk_pool_fwd(const T* __restrict__ a, T* __restrict__ gout, int V, int HW, int f, int gpitch) {
+  // one thread per (v, 4-channel group); gout [V, gpitch] (pad channels zero-filled by the caller)
+  const long long total = (long long)V * (f / 4);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % (f / 4)) * 4;
+    const int v = (int)(i / (f / 4));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p) {
+      const T* r = a + ((long long)v * HW + p) * 2 * f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += Elem<T>::ld(r + c0 + e) + Elem<T>::ld(r + f + c0 + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Elem<T>::st(gout + (long long)v * gpitch + c0 + e, acc[e] / (float)HW);
+  }
+}
+template <typename T>
+__global__ void sk_mix_fwd(const T* __restrict__ a, const T* __restrict__ l, T* __restrict__ out, int V, int HW,
+                           int f, int lpitch) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = f / EPC;
+  const long long total = (long long)V * HW * cpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const long long pix = i / cpr;
+    const int v = (int)(pix / HW);
+    float a0[EPC], a1[EPC], o[EPC];
+    chunk_to_f32<T>(*(const u32x4*)(a + pix * 2 * f + cc * EPC), a0);
+    chunk_to_f32<T>(*(const u32x4*)(a + pix * 2 * f + f + cc * EPC), a1);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float l0 = Elem<T>::ld(l + (long long)v * lpitch + cc * EPC + e);
+      const float l1 = Elem<T>::ld(l + (long long)v * lpitch + f + cc * EPC + e);
+      const float m0 = 1.f / (1.f + __expf(l1 - l0));
+      o[e] = a0[e] * m0 + a1[e] * (1.f - m0);
+    }
+    *(u32x4*)(out + pix * f + cc * EPC) = f32_to_chunk<T>(o);
+  }
+}
+// dl[v, k*f+c] = softmax-backward of (sum_hw dout*a0, sum_hw dout*a1); one thread per (v, c)
+template <typename T>
+__global__ void sk_mix_bwd_logits(const T* __restrict__ a, const T* __restrict__ l, const T* __restrict__ dout,
+                                  T* __restrict__ dl, int V, int HW, int f, int lpitch) {
+  const long long total = (long long)V * f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % f);
+    const int v = (int)(i / f);
+    float d0 = 0.f, d1 = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      const long long pix = (long long)v * HW + p;
+      const float d = Elem<T>::ld(dout + pix * f + c);
+      d0 += d * Elem<T>::ld(a + pix * 2 * f + c);
+      d1 += d * Elem<T>::ld(a + pix * 2 * f + f + c);
+    }
+    const float l0 = Elem<T>::ld(l + (long long)v * lpitch + c), l1 = Elem<T>::ld(l + (long long)v * lpitch + f + c);
+    const float m0 = 1.f / (1.f + __expf(l1 - l0)), m1 = 1.f - m0;
+    const float dot = m0 * d0 + m1 * d1;
+    Elem<T>::st(dl + (long long)v * lpitch + c, m0 * (d0 - dot));
+    Elem<T>::st(dl + (long long)v * lpitch + f + c, m1 * (d1 - dot));
+  }
+}
+// da[v,hw,k*f+c] = dout*m_k + dg[v,c]/HW   (dg = gradient wrt the pooled feature g)
+template <typename T>
+__global__ void sk_mix_bwd_streams(const T* __restrict__ l, const T* __restrict__ dout, const T* __restrict__ dg,
+                                   T* __restrict__ da, int V, int HW, int f, int lpitch, int gpitch) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = f / EPC;
+  const long long total = (long long)V * HW * cpr;
+  const float inv = 1.f / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    const long long pix = i / cpr;
+    const int v = (int)(pix / HW);
+    float d[EPC], o0[EPC], o1[EPC];
+    chunk_to_f32<T>(*(const u32x4*)(dout + pix * f + cc * EPC), d);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float l0 = Elem<T>::ld(l + (long long)v * lpitch + cc * EPC + e);
+      const float l1 = Elem<T>::ld(l + (long long)v * lpitch + f + cc * EPC + e);
+      const float m0 = 1.f / (1.f + __expf(l1 - l0));
+      const float gq = Elem<T>::ld(dg + (long long)v * gpitch + cc * EPC + e) * inv;
+      o0[e] = d[e] * m0 + gq;
+      o1[e] = d[e] * (1.f - m0) + gq;
+    }
+    *(u32x4*)(da + pix * 2 * f + cc * EPC) = f32_to_chunk<T>(o0);
+    *(u32x4*)(da + pix * 2 * f + f + cc * EPC) = f32_to_chunk<T>(o1);
+  }
+}
+
 // Supervised head tail: logits = z + bias; softmax CE vs int labels (mean over rows);
 // dlogits = (softmax - onehot) * gscale / rows ; padded classes (>= nclass) get 0.
 // One wave per row.  out[0] += loss contribution, out[1] += top-1 hits  (atomics; caller zeroes)
@@ -335,6 +503,92 @@ int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, in
                                 (const uint16_t*)dy, (const uint16_t*)mask_src, (uint16_t*)dx, V, HW, C),
              hipLaunchKernelGGL((global_avgpool_bwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
                                 (const float*)dy, (const float*)mask_src, (float*)dx, V, HW, C));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+
+/* ResNet-D shortcut average pool (tf2/resnet.py:330-338, 400-408): 2x2, stride 1 (SAME, TF valid-count
+ * divisor) or 2 (after FixedPadding(2)); OH = H (stride 1) or (H+1)/2. */
+int simclr_avgpool2_fwd(const void* x, void* y, int V, int H, int W, int C, int stride, int dtype,
+                        hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0 && (stride == 1 || stride == 2), "avgpool2_fwd: bad C/stride");
+  const int OH = stride == 1 ? H : (H + 1) / 2, OW = stride == 1 ? W : (W + 1) / 2;
+  const long long total = (long long)V * OH * OW * (C / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((avgpool2_fwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)x, (uint16_t*)y, V, H, W, C, OH, OW, stride),
+             hipLaunchKernelGGL((avgpool2_fwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)x, (float*)y, V, H, W, C, OH, OW, stride));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+int simclr_avgpool2_bwd(const void* dy, void* dx, int V, int H, int W, int C, int stride, int dtype,
+                        hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0 && (stride == 1 || stride == 2), "avgpool2_bwd: bad C/stride");
+  const int OH = stride == 1 ? H : (H + 1) / 2, OW = stride == 1 ? W : (W + 1) / 2;
+  const long long total = (long long)V * H * W * (C / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((avgpool2_bwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)dy, (uint16_t*)dx, V, H, W, C, OH, OW, stride),
+             hipLaunchKernelGGL((avgpool2_bwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)dy, (float*)dx, V, H, W, C, OH, OW, stride));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+/* SK unit (tf2/resnet.py:266-277).  a [V,HW,2f] (T): the two streams; g [V,gpitch]: pooled feature
+ * (first f channels written); l [V,lpitch]: mixing logits (2f used); out [V,HW,f]. */
+int simclr_sk_pool_fwd(const void* a, void* g, int V, int HW, int f, int gpitch, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(f % 4 == 0 && gpitch >= f, "sk_pool_fwd: bad f/gpitch");
+  const long long total = (long long)V * (f / 4);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((sk_pool_fwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)a, (uint16_t*)g, V, HW, f, gpitch),
+             hipLaunchKernelGGL((sk_pool_fwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)a, (float*)g, V, HW, f, gpitch));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+int simclr_sk_mix_fwd(const void* a, const void* l, void* out, int V, int HW, int f, int lpitch, int dtype,
+                      hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(f % epc == 0 && lpitch >= 2 * f, "sk_mix_fwd: bad f/lpitch");
+  const long long total = (long long)V * HW * (f / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((sk_mix_fwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)a, (const uint16_t*)l, (uint16_t*)out, V, HW, f, lpitch),
+             hipLaunchKernelGGL((sk_mix_fwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)a, (const float*)l, (float*)out, V, HW, f, lpitch));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+/* dl [V,lpitch] = gradient wrt the mixing logits (softmax over the two streams). */
+int simclr_sk_mix_bwd_logits(const void* a, const void* l, const void* dout, void* dl, int V, int HW, int f,
+                             int lpitch, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(f > 0 && lpitch >= 2 * f, "sk_mix_bwd_logits: bad f/lpitch");
+  const long long total = (long long)V * f;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((sk_mix_bwd_logits<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)a, (const uint16_t*)l, (const uint16_t*)dout, (uint16_t*)dl, V, HW, f, lpitch),
+             hipLaunchKernelGGL((sk_mix_bwd_logits<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)a, (const float*)l, (const float*)dout, (float*)dl, V, HW, f, lpitch));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+/* da [V,HW,2f] = dout*m_k + dg/HW : gradient wrt both streams (mix path + pooled-feature path). */
+int simclr_sk_mix_bwd_streams(const void* l, const void* dout, const void* dg, void* da, int V, int HW, int f,
+                              int lpitch, int gpitch, int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(f % epc == 0 && lpitch >= 2 * f && gpitch >= f, "sk_mix_bwd_streams: bad shape");
+  const long long total = (long long)V * HW * (f / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((sk_mix_bwd_streams<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const uint16_t*)l, (const uint16_t*)dout, (const uint16_t*)dg, (uint16_t*)da, V, HW, f, lpitch, gpitch),
+             hipLaunchKernelGGL((sk_mix_bwd_streams<float>), dim3(grid_for(total)), dim3(256), 0, stream,
+                                (const float*)l, (const float*)dout, (const float*)dg, (float*)da, V, HW, f, lpitch, gpitch));
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

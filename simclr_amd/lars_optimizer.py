@@ -39,7 +39,11 @@ class Variable:
 
     def ensure_grad(self):
         if self.grad is None:
-            self.grad = torch.zeros_like(self.value)
+            # slot rounded up to 64 elements: kernels that work on channel-padded tensors may write
+            # (zeros) up to the next multiple of 64 past the logical end
+            n = self.value.numel()
+            buf = torch.zeros((n + 63) // 64 * 64, device=self.value.device, dtype=self.value.dtype)
+            self.grad = buf[:n].view(self.value.shape)
         return self.grad
 
 

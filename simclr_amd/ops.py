@@ -120,17 +120,19 @@ def ntxent_logits_ab(z_local, z_all, temperature):
 
 
 # ---------------------------------------------------------------- conv / dense
-def prep_weights(w_hwio, mode, dtype, khp=0, kwp=0, out=None):
+def prep_weights(w_hwio, mode, dtype, khp=0, kwp=0, out=None, cin_p=0, cout_p=0):
+    """fp32 HWIO master -> compute copy.  cin_p / cout_p: zero-padded channel dims of the copy."""
     KH, KW, CI, CO = w_hwio.shape
+    cip, cop = cin_p or CI, cout_p or CO
     if mode == 2:
-        shape = (CO, khp * kwp * 4)
+        shape = (cop, khp * kwp * 4)
     elif mode == 0:
-        shape = (CO, KH * KW * CI)
+        shape = (cop, KH * KW * cip)
     else:
-        shape = (CI, KH * KW * CO)
+        shape = (cip, KH * KW * cop)
     if out is None:
         out = torch.empty(shape, device=w_hwio.device, dtype=dtype)
-    lib().prep_weights(_p(w_hwio), _p(out), KH, KW, CI, CO, mode, khp, kwp, dt(out), _s())
+    lib().prep_weights(_p(w_hwio), _p(out), KH, KW, CI, CO, mode, khp, kwp, cip, cop, dt(out), _s())
     return out
 
 
@@ -398,6 +400,50 @@ def global_avgpool_bwd(dy, H, W, mask_src=None):
     dx = torch.empty(V, H, W, C, device=dy.device, dtype=dy.dtype)
     lib().global_avgpool_bwd(_p(dy), _p(mask_src), _p(dx), V, H * W, C, dt(dy), _s())
     return dx
+
+
+def avgpool2_fwd(x, stride):
+    V, H, W, C = x.shape
+    OH, OW = (H, W) if stride == 1 else ((H + 1) // 2, (W + 1) // 2)
+    y = torch.empty(V, OH, OW, C, device=x.device, dtype=x.dtype)
+    lib().avgpool2_fwd(_p(x), _p(y), V, H, W, C, stride, dt(x), _s())
+    return y
+
+
+def avgpool2_bwd(dy, H, W, stride):
+    V, OH, OW, C = dy.shape
+    dx = torch.empty(V, H, W, C, device=dy.device, dtype=dy.dtype)
+    lib().avgpool2_bwd(_p(dy), _p(dx), V, H, W, C, stride, dt(dy), _s())
+    return dx
+
+
+# ---------------------------------------------------------------- selective kernel unit
+def sk_pool_fwd(a, f, gpitch):
+    V, H, W, _ = a.shape
+    g = torch.zeros(V, gpitch, device=a.device, dtype=a.dtype)
+    lib().sk_pool_fwd(_p(a), _p(g), V, H * W, f, gpitch, dt(a), _s())
+    return g
+
+
+def sk_mix_fwd(a, l, f):
+    V, H, W, _ = a.shape
+    out = torch.empty(V, H, W, f, device=a.device, dtype=a.dtype)
+    lib().sk_mix_fwd(_p(a), _p(l), _p(out), V, H * W, f, l.shape[1], dt(a), _s())
+    return out
+
+
+def sk_mix_bwd_logits(a, l, dout, f):
+    V, H, W, _ = a.shape
+    dl = torch.zeros_like(l)
+    lib().sk_mix_bwd_logits(_p(a), _p(l), _p(dout), _p(dl), V, H * W, f, l.shape[1], dt(a), _s())
+    return dl
+
+
+def sk_mix_bwd_streams(l, dout, dg, f):
+    V, H, W, _ = dout.shape
+    da = torch.empty(V, H, W, 2 * f, device=dout.device, dtype=dout.dtype)
+    lib().sk_mix_bwd_streams(_p(l), _p(dout), _p(dg), _p(da), V, H * W, f, l.shape[1], dg.shape[1], dt(dout), _s())
+    return da
 
 
 # ---------------------------------------------------------------- supervised head / misc

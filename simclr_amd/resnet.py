@@ -15,9 +15,10 @@ MI355X-first differences (numerically equivalent to the reference graph):
   * stem BN + ReLU + max-pool (resnet.py:602-611) are one pass over the stem output;
   * the 3-channel input is packed once (pad + view split, tf2/model.py:250-259) so the
     stem conv needs no bounds checks.
-Not built in this round (fail loudly): SK (sk_ratio>0, resnet.py:217-277), SE
-(se_ratio>0, :280-311), DropBlock (:81-157, unreachable in the reference too),
-channels_first.
+Selective kernels (sk_ratio>0: SK_Conv2D resnet.py:217-277, ResNet-D stem :566-591 and avg-pool
+shortcut :330-338/:400-408) are built; channel counts that are not a multiple of 64 (SK squeeze
+dim, 32*w stem) are zero-padded internally.  Not built (fail loudly): SE (se_ratio>0, :280-311),
+DropBlock (:81-157, unreachable in the reference too), channels_first.
 """
 import math
 
@@ -73,13 +74,20 @@ class scope:
         RT.scope.pop()
 
 
-class Act:
-    """An activation tensor plus (optionally) the fused per-channel statistics partials."""
-    __slots__ = ('t', 'stats')
+def pad64(c):
+    """Channel counts that are not a multiple of the 64-element k-tile are zero-padded internally."""
+    return (c + 63) // 64 * 64
 
-    def __init__(self, t, stats=None):
+
+class Act:
+    """An activation tensor plus (optionally) the fused per-channel statistics partials.  `c` is the
+    logical channel count when the tensor carries zero-padded channels (t.shape[-1] = pad64(c))."""
+    __slots__ = ('t', 'stats', 'c')
+
+    def __init__(self, t, stats=None, c=None):
         self.t = t
         self.stats = stats
+        self.c = t.shape[-1] if c is None else c
 
 
 class PackedInput:
@@ -148,24 +156,32 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         self.gamma = self.beta = self.moving_mean = self.moving_variance = None
         self.saved = None
 
-    def build(self, C):
+    def build(self, C, Cp=None):
+        """C logical channels; Cp >= C channels of the (zero-padded) tensor.  Storage is padded, the
+        Variables are views of the first C entries; pad gamma/beta are 0 so pad channels stay 0."""
         dev = RT.device
+        Cp = C if Cp is None else Cp
+        self._pg = self._pb = None
         if self.scale:
-            g = torch.zeros(C) if self.init_zero else torch.ones(C)     # :42-45
-            self.gamma = Variable(self._base + '/gamma:0', g.to(dev), self.trainable)
+            self._pg = torch.zeros(Cp, device=dev)
+            if not self.init_zero:                                       # :42-45
+                self._pg[:C] = 1.0
+            self.gamma = Variable(self._base + '/gamma:0', self._pg[:C], self.trainable)
         if self.center:
-            self.beta = Variable(self._base + '/beta:0', torch.zeros(C, device=dev), self.trainable)
-        self.moving_mean = Variable(self._base + '/moving_mean:0', torch.zeros(C, device=dev), False)
-        self.moving_variance = Variable(self._base + '/moving_variance:0', torch.ones(C, device=dev), False)
+            self._pb = torch.zeros(Cp, device=dev)
+            self.beta = Variable(self._base + '/beta:0', self._pb[:C], self.trainable)
+        self._pmm = torch.zeros(Cp, device=dev)
+        self._pmv = torch.ones(Cp, device=dev)
+        self.moving_mean = Variable(self._base + '/moving_mean:0', self._pmm[:C], False)
+        self.moving_variance = Variable(self._base + '/moving_variance:0', self._pmv[:C], False)
 
     def prepare(self, inputs, training):
         """Statistics -> (mean, rstd, scale, shift); moving-average update when training."""
         x = inputs.t
         C = x.shape[-1]
         if self.moving_mean is None:
-            self.build(C)
-        g = self.gamma.value if self.gamma is not None else None
-        b = self.beta.value if self.beta is not None else None
+            self.build(inputs.c, C)
+        g, b = self._pg, self._pb
         rows = x.numel() // C
         if training:
             if inputs.stats is None:
@@ -176,16 +192,15 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
             if FLAGS.global_bn and R > 1:            # SyncBatchNormalization, :50-60
                 RT.strategy.all_reduce_sum(sums)
                 count = rows * R
-            mean, rstd, scale, shift = ops.bn_finalize(sums, count, g, b, self.moving_mean.value,
-                                                       self.moving_variance.value, FLAGS.batch_norm_decay,
-                                                       BATCH_NORM_EPSILON)
+            mean, rstd, scale, shift = ops.bn_finalize(sums, count, g, b, self._pmm, self._pmv,
+                                                       FLAGS.batch_norm_decay, BATCH_NORM_EPSILON)
         else:
-            mean = self.moving_mean.value
-            rstd = torch.rsqrt(self.moving_variance.value + BATCH_NORM_EPSILON)
+            mean = self._pmm
+            rstd = torch.rsqrt(self._pmv + BATCH_NORM_EPSILON)
             scale = rstd if g is None else g * rstd
             shift = -mean * scale if b is None else b - mean * scale
             count = rows
-        self.saved = dict(x=x, mean=mean, rstd=rstd, scale=scale, shift=shift, count=count, y=None)
+        self.saved = dict(x=x, mean=mean, rstd=rstd, scale=scale, shift=shift, count=count, y=None, c=inputs.c)
         return scale, shift
 
     def __call__(self, inputs, training, relu=None, add=None, add_bn=None):
@@ -197,7 +212,7 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         y = ops.bn_apply(inputs.t, scale, shift, relu, res=add, rscale=rs, rshift=rb)
         self.saved['y'] = y
         self.saved['masked'] = bool(relu)
-        return Act(y)
+        return Act(y, c=inputs.c)
 
     def fusion_info(self, mask_src=None):
         """What a consumer conv's dgrad epilogue needs to fuse this layer's backward reduce
@@ -263,28 +278,35 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         self.kernel_size = kernel_size
         self.strides = strides
         self.trainable = kwargs.get('trainable', True)
-        outer = RT.unique('conv2d_fixed_padding')
-        inner = RT.unique('conv2d')
-        self._name = RT.path(outer, inner, 'kernel:0')
+        self._name = self._make_name()
         self.kernel = None
         self._version = -1
         self.saved = None
 
-    def build(self, cin):
+    def _make_name(self):
+        outer = RT.unique('conv2d_fixed_padding')
+        inner = RT.unique('conv2d')
+        return RT.path(outer, inner, 'kernel:0')
+
+    def build(self, cin, cin_p=None):
+        """cin logical input channels; cin_p channels of the (zero-padded) input tensor."""
         k = self.kernel_size
         w = _variance_scaling((k, k, cin, self.filters), k * k * cin, _gen())
         self.kernel = Variable(self._name, w.to(RT.device), self.trainable)
         self.cin = cin
+        self.cin_p = cin if cin_p is None else cin_p
+        self.cout_p = pad64(self.filters) if self.filters % 64 else self.filters
+        self.padded = self.cin_p != cin or self.cout_p != self.filters
 
     def _refresh(self, stem_geo=None):
         if self._version == RT.weights_version and getattr(self, '_dtype', None) == RT.dtype:
             return
         w = self.kernel.value
         if stem_geo is not None:
-            self.w_s = ops.prep_weights(w, 2, RT.dtype, stem_geo['KHP'], stem_geo['KWP'])
+            self.w_s = ops.prep_weights(w, 2, RT.dtype, stem_geo['KHP'], stem_geo['KWP'], cout_p=self.cout_p)
         else:
-            self.w_t = ops.prep_weights(w, 0, RT.dtype)
-            self.w_d = ops.prep_weights(w, 1, RT.dtype)
+            self.w_t = ops.prep_weights(w, 0, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
+            self.w_d = ops.prep_weights(w, 1, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
         self._version = RT.weights_version
         self._dtype = RT.dtype
 
@@ -294,22 +316,27 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             if self.kernel is None:
                 self.build(3)
             self._refresh(inputs.geo)
-            stats = ops.new_stats(self.filters, RT.device) if (want_stats and training) else None
+            stats = ops.new_stats(self.cout_p, RT.device) if (want_stats and training) else None
             y = ops.stem_conv_fwd(inputs.xp, self.w_s, inputs.geo, s, stats=stats)
             self.saved = dict(packed=inputs)
-            return Act(y, stats)
+            return Act(y, stats, c=self.filters)
         x = inputs.t
-        V, H, W, cin = x.shape
+        V, H, W, cin_p = x.shape
         if self.kernel is None:
-            self.build(cin)
+            self.build(inputs.c, cin_p)
         self._refresh()
         pad = (k - 1) // 2                                  # FixedPadding / SAME at stride 1
         OH = (H + (k - 1) - k) // s + 1
         OW = (W + (k - 1) - k) // s + 1
-        stats = ops.new_stats(self.filters, RT.device) if (want_stats and training) else None
+        stats = ops.new_stats(self.cout_p, RT.device) if (want_stats and training) else None
         y = ops.conv2d_fwd(x, self.w_t, k, k, s, pad, OH, OW, stats=stats)
         self.saved = dict(x=x, H=H, W=W, pad=pad)
-        return Act(y, stats)
+        return Act(y, stats, c=self.filters)
+
+    def _store_wgrad(self, tmp4):
+        """tmp4: [k, k, cin_p, cout_p] fp32 -> logical slice into the gradient buffer."""
+        g = self.kernel.ensure_grad()
+        g.copy_(tmp4[:, :, :g.shape[2], :self.filters])
 
     def backward(self, dy, need_dx=True, dx_out=None, accumulate=False, fuse_bn=None):
         """Returns dx, or (dm, partial) when `fuse_bn` (BatchNormRelu.fusion_info of the layer that
@@ -321,12 +348,17 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         if 'packed' in sv:
             if train_w:
                 pk = sv['packed']
-                g = self.kernel.ensure_grad()
-                ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, out=g)
+                if self.cout_p == self.filters:
+                    ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, out=self.kernel.ensure_grad())
+                else:
+                    self._store_wgrad(ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s))
             return None
         if train_w:
-            g = self.kernel.ensure_grad()
-            ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'], out=g.view(-1, self.filters))
+            if not self.padded:
+                ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'], out=self.kernel.ensure_grad().view(-1, self.filters))
+            else:
+                tmp = ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'])
+                self._store_wgrad(tmp.view(k, k, self.cin_p, self.cout_p))
         if not need_dx:
             return None
         if fuse_bn is not None:
@@ -335,6 +367,16 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
                                        accumulate=accumulate)
         return ops.conv2d_dgrad(dy, self.w_d, k, k, s, sv['pad'], sv['H'], sv['W'], out=dx_out,
                                 accumulate=accumulate)
+
+
+class _PlainConv1x1(Conv2dFixedPadding):
+    """The bare tf.keras.layers.Conv2D(k=1) layers inside SK_Conv2D (tf2/resnet.py:243-256)."""
+
+    def __init__(self, filters):
+        super().__init__(filters, 1, 1)
+
+    def _make_name(self):
+        return RT.path(RT.unique('conv2d'), 'kernel:0')
 
 
 class IdentityLayer(Layer):  # tf2/resnet.py:211-214
@@ -351,25 +393,84 @@ def _no_dropblock(keep_prob, size):
 
 
 # --------------------------------------------------------------------------- blocks
+class SK_Conv2D(Layer):  # pylint: disable=invalid-name
+    """Selective kernel convolutional layer (tf2/resnet.py:217-277): a 3x3 conv producing two streams
+    (2f channels), BN+ReLU, a squeeze path (global mean of the stream sum -> 1x1 -> BN+ReLU -> 1x1)
+    whose 2-way softmax mixes the streams."""
+
+    def __init__(self, filters, strides, sk_ratio, min_dim=32, data_format='channels_last', **kwargs):
+        self.filters = filters
+        self.sk_ratio = sk_ratio
+        self.min_dim = min_dim
+        with scope(RT.unique('sk__conv2d')):
+            self.conv2d_fixed_padding = Conv2dFixedPadding(filters=2 * filters, kernel_size=3, strides=strides,
+                                                           data_format=data_format)          # :231-236
+            self.batch_norm_relu = BatchNormRelu(data_format=data_format)                     # :237
+            mid_dim = max(int(filters * sk_ratio), min_dim)                                    # :242
+            self.conv2d_0 = _PlainConv1x1(mid_dim)                                             # :243-249
+            self.batch_norm_relu_1 = BatchNormRelu(data_format=data_format)                   # :250
+            self.conv2d_1 = _PlainConv1x1(2 * filters)                                         # :251-257
+        self.saved = None
+
+    @property
+    def strides(self):
+        return self.conv2d_fixed_padding.strides
+
+    def __call__(self, inputs, training):
+        f = self.filters
+        a = self.batch_norm_relu(self.conv2d_fixed_padding(inputs, training), training)       # :264-265
+        V = a.t.shape[0]
+        g = ops.sk_pool_fwd(a.t, f, pad64(f))                                                 # :266-270
+        h = self.conv2d_0(Act(g.view(V, 1, 1, -1), c=f), training)                            # :271
+        h = self.batch_norm_relu_1(h, training)                                               # :272
+        l = self.conv2d_1(h, training, want_stats=False)                                      # :273
+        lt = l.t.view(V, -1)
+        out = ops.sk_mix_fwd(a.t, lt, f)                                                      # :274-277
+        self.saved = dict(a=a.t, l=lt)
+        return Act(out, c=f)
+
+    def backward(self, dout, fuse_bn=None):
+        """dout: gradient wrt the mixed output [V,H,W,f].  Returns what the 3x3 conv's backward returns."""
+        f = self.filters
+        sv = self.saved
+        self.saved = None
+        a, l = sv['a'], sv['l']
+        V = a.shape[0]
+        dl = ops.sk_mix_bwd_logits(a, l, dout, f)
+        dh = self.conv2d_1.backward(dl.view(V, 1, 1, -1))
+        dh, _ = self.batch_norm_relu_1.backward(dh)
+        dg = self.conv2d_0.backward(dh).view(V, -1)
+        da = ops.sk_mix_bwd_streams(l, dout, dg, f)
+        dconv, _ = self.batch_norm_relu.backward(da)
+        return self.conv2d_fixed_padding.backward(dconv, fuse_bn=fuse_bn)
+
+
 class _Shortcut(Layer):
-    """Projection shortcut: Conv2dFixedPadding 1x1 (stride s) + BatchNormRelu(relu=False)
-    (tf2/resnet.py:339-349, 409-423).  The BN *apply* is deferred into the block's fused tail."""
+    """Projection shortcut (tf2/resnet.py:328-349, 398-423): Conv2dFixedPadding 1x1 (stride s) +
+    BatchNormRelu(relu=False); with sk_ratio>0 the ResNet-D form: [FixedPadding(2)] ->
+    AveragePooling2D(2, s) -> 1x1 conv stride 1.  The BN *apply* is deferred into the block's fused tail."""
 
     def __init__(self, filters_out, strides, data_format):
-        if FLAGS.sk_ratio > 0:
-            raise NotImplementedError('ResNet-D shortcut (sk_ratio>0, tf2/resnet.py:330-338) not built yet')
-        self.conv = Conv2dFixedPadding(filters=filters_out, kernel_size=1, strides=strides,
+        self.resnet_d = FLAGS.sk_ratio > 0
+        self.strides = strides
+        self.conv = Conv2dFixedPadding(filters=filters_out, kernel_size=1, strides=1 if self.resnet_d else strides,
                                        data_format=data_format)
         self.bn = BatchNormRelu(relu=False, data_format=data_format)
 
     def __call__(self, inputs, training):
+        if self.resnet_d:
+            self._hw = inputs.t.shape[1:3]
+            inputs = Act(ops.avgpool2_fwd(inputs.t, self.strides), c=inputs.c)
         raw = self.conv(inputs, training)
         scale, shift = self.bn.prepare(raw, training)
         return raw.t, (scale, shift)
 
     def backward(self, d_sum):
         d_raw, _ = self.bn.backward(d_sum, mask_mode=0)
-        return self.conv.backward(d_raw)
+        d = self.conv.backward(d_raw)
+        if self.resnet_d:
+            d = ops.avgpool2_bwd(d, self._hw[0], self._hw[1], self.strides)
+        return d
 
 
 class ResidualBlock(Layer):  # tf2/resnet.py:314-382
@@ -423,14 +524,18 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         _no_dropblock(dropblock_keep_prob, dropblock_size)
         if FLAGS.se_ratio > 0:
             raise NotImplementedError('SE_Layer (tf2/resnet.py:280-311) not built')
-        if FLAGS.sk_ratio > 0:
-            raise NotImplementedError('SK_Conv2D (tf2/resnet.py:217-277) not built yet')
         with scope(RT.unique('bottleneck_block')):
             self.shortcut = _Shortcut(4 * filters, strides, data_format) if use_projection else None
             self.conv1 = Conv2dFixedPadding(filters=filters, kernel_size=1, strides=1, data_format=data_format)
             self.bn1 = BatchNormRelu(data_format=data_format)
-            self.conv2 = Conv2dFixedPadding(filters=filters, kernel_size=3, strides=strides, data_format=data_format)
-            self.bn2 = BatchNormRelu(data_format=data_format)
+            self.sk = None
+            if FLAGS.sk_ratio > 0:                                                  # :442-444
+                self.sk = SK_Conv2D(filters, strides, FLAGS.sk_ratio, data_format=data_format)
+                self.conv2 = self.bn2 = None
+            else:                                                                   # :446-453
+                self.conv2 = Conv2dFixedPadding(filters=filters, kernel_size=3, strides=strides,
+                                                data_format=data_format)
+                self.bn2 = BatchNormRelu(data_format=data_format)
             self.conv3 = Conv2dFixedPadding(filters=4 * filters, kernel_size=1, strides=1, data_format=data_format)
             self.bn3 = BatchNormRelu(relu=False, init_zero=True, data_format=data_format)
 
@@ -440,7 +545,10 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         else:
             sc, sc_bn = inputs.t, None
         h = self.bn1(self.conv1(inputs, training), training)
-        h = self.bn2(self.conv2(h, training), training)
+        if self.sk is not None:
+            h = self.sk(h, training)
+        else:
+            h = self.bn2(self.conv2(h, training), training)
         h = self.conv3(h, training)
         out = self.bn3(h, training, relu=True, add=sc, add_bn=sc_bn)     # relu(inputs + shortcut), :487
         self.out = out.t
@@ -457,13 +565,21 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
             dh3, dsum = self.bn3.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
         self.out = None
         dx = self.shortcut.backward(dsum) if self.shortcut is not None else dsum
-        dm2, part2 = self.conv3.backward(dh3, fuse_bn=self.bn2.fusion_info())
-        dh2 = self.bn2.backward_fused(dm2, part2)
-        if self.conv2.strides == 1:
-            dm1, part1 = self.conv2.backward(dh2, fuse_bn=self.bn1.fusion_info())
-            dh1 = self.bn1.backward_fused(dm1, part1)
+        if self.sk is not None:
+            dsk = self.conv3.backward(dh3)
+            if self.sk.strides == 1:
+                dm1, part1 = self.sk.backward(dsk, fuse_bn=self.bn1.fusion_info())
+                dh1 = self.bn1.backward_fused(dm1, part1)
+            else:
+                dh1, _ = self.bn1.backward(self.sk.backward(dsk))
         else:
-            dh1, _ = self.bn1.backward(self.conv2.backward(dh2))
+            dm2, part2 = self.conv3.backward(dh3, fuse_bn=self.bn2.fusion_info())
+            dh2 = self.bn2.backward_fused(dm2, part2)
+            if self.conv2.strides == 1:
+                dm1, part1 = self.conv2.backward(dh2, fuse_bn=self.bn1.fusion_info())
+                dh1 = self.bn1.backward_fused(dm1, part1)
+            else:
+                dh1, _ = self.bn1.backward(self.conv2.backward(dh2))
         if prev_tail is not None:
             return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
         self.conv1.backward(dh1, dx_out=dx, accumulate=True)
@@ -505,12 +621,22 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
             raise ValueError('dropblock_keep_probs is not valid:', dropblock_keep_probs)   # :546-547
         if FLAGS.train_mode == 'finetune' and FLAGS.fine_tune_after_block != -1:
             raise NotImplementedError('layer freezing (fine_tune_after_block) is outside the pretraining hot path')
-        if FLAGS.sk_ratio > 0:
-            raise NotImplementedError('ResNet-D stem / SK (sk_ratio>0, tf2/resnet.py:566-591) not built yet')
         self.cifar_stem = cifar_stem
+        self.resnet_d = (not cifar_stem) and FLAGS.sk_ratio > 0
         self.endpoints = {}
         with scope('resnet'):
+            self.stem_pre = []      # ResNet-D: two extra (conv, BN+ReLU) pairs before the last stem conv
             if cifar_stem:                                                       # :551-564
+                self.stem_conv = Conv2dFixedPadding(filters=64 * width_multiplier, kernel_size=3, strides=1,
+                                                    data_format=data_format)
+            elif self.resnet_d:                                                  # :566-591
+                c0 = Conv2dFixedPadding(filters=64 * width_multiplier // 2, kernel_size=3, strides=2,
+                                        data_format=data_format)
+                b0 = BatchNormRelu(data_format=data_format)
+                c1 = Conv2dFixedPadding(filters=64 * width_multiplier // 2, kernel_size=3, strides=1,
+                                        data_format=data_format)
+                b1 = BatchNormRelu(data_format=data_format)
+                self.stem_pre = [c0, b0, c1, b1]
                 self.stem_conv = Conv2dFixedPadding(filters=64 * width_multiplier, kernel_size=3, strides=1,
                                                     data_format=data_format)
             else:                                                                # :593-599
@@ -527,13 +653,19 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
 
     @property
     def stem_kernel_stride(self):
-        return (3, 1) if self.cifar_stem else (7, 2)
+        """(kernel, stride) of the conv that reads the 3-channel image."""
+        if self.cifar_stem:
+            return (3, 1)
+        return (3, 2) if self.resnet_d else (7, 2)
 
     def __call__(self, inputs, training):
         """inputs: PackedInput (from Model) or an NHWC float32 tensor [B,H,W,3]."""
         if not isinstance(inputs, PackedInput):
             k, s = self.stem_kernel_stride
             inputs = PackedInput(inputs.contiguous(), 1, k, s, RT.dtype)
+        if self.stem_pre:
+            c0, b0, c1, b1 = self.stem_pre
+            inputs = b1(c1(b0(c0(inputs, training), training), training), training)
         raw = self.stem_conv(inputs, training)
         self.endpoints['initial_conv'] = raw.t
         if self.cifar_stem:
@@ -571,7 +703,13 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
             self._pool = None
         else:
             draw, _ = self.stem_bn.backward(d)
-        self.stem_conv.backward(draw, need_dx=False)
+        if self.stem_pre:
+            c0, b0, c1, b1 = self.stem_pre
+            dm, part = self.stem_conv.backward(draw, fuse_bn=b1.fusion_info())
+            dm, part = c1.backward(b1.backward_fused(dm, part), fuse_bn=b0.fusion_info())
+            c0.backward(b0.backward_fused(dm, part), need_dx=False)
+        else:
+            self.stem_conv.backward(draw, need_dx=False)
         if on_stage is not None:
             on_stage(0)
         self.endpoints = {}

@@ -97,6 +97,10 @@ def test_model_constructs_on_cpu_and_names_layers():
     assert RT.counters['conv2d'] == 53 and RT.counters['sync_batch_normalization'] == 56
     assert RT.counters['bottleneck_block'] == 16 and RT.counters['dense'] == 4
     FLAGS.update(sk_ratio=0.0625); RT.reset()
+    model_lib.Model(1000)        # SK + ResNet-D: 16 SK units, 2 extra stem convs, 32 bare 1x1 convs
+    assert RT.counters['sk__conv2d'] == 16 and RT.counters['conv2d_fixed_padding'] == 55
+    assert RT.counters['conv2d'] == 87
+    FLAGS.update(sk_ratio=0.0, se_ratio=0.25); RT.reset()
     with pytest.raises(NotImplementedError):
         model_lib.Model(1000)
     FLAGS.reset(); RT.reset()

@@ -153,6 +153,27 @@ def test_train_step_bf16():
                                 randomize_bn=False))
 
 
+@pytest.mark.parametrize('H,stride', [(8, 2), (7, 2), (7, 1), (6, 1)])
+def test_avgpool2_resnet_d_shortcut(H, stride):
+    from tests import gpu_checks as gc
+    _assert(gc.check_avgpool2(2, H, 64, stride, F32) + gc.check_avgpool2(2, H, 64, stride, BF))
+
+
+def test_train_step_resnet50_sk_f32():
+    """Selective kernels + ResNet-D stem/shortcut (BASELINE configs 4/5 family)."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_train_step(depth=50, image_size=64, batch=4, compute_dtype='f32', num_classes=1000,
+                                randomize_bn=False, sk_ratio=0.0625))
+
+
+def test_train_step_resnet50_2x_sk_randomized_and_bf16():
+    from tests import gpu_checks as gc
+    _assert(gc.check_train_step(depth=50, image_size=64, batch=4, compute_dtype='f32', num_classes=1000,
+                                randomize_bn=True, sk_ratio=0.0625, width_multiplier=2))
+    _assert(gc.check_train_step(depth=50, image_size=64, batch=4, compute_dtype='bf16', num_classes=1000,
+                                randomize_bn=False, sk_ratio=0.0625))
+
+
 def test_model_api_shapes_and_errors():
     """Drop-in surface: Model()(inputs, training) -> ([2b, 128] float32, logits), endpoints, errors."""
     from simclr_amd import model as model_lib

@@ -23,6 +23,12 @@ m = gc.probe_ds_read_tr16()
 print(m[:20].tolist(), m[60:].tolist())
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump(m.tolist(), open('gpurun_out/ds_read_tr16_map.json', 'w'))
+for r in gc.check_avgpool2(2, 8, 64, 2, torch.float32) + gc.check_avgpool2(2, 7, 64, 2, torch.float32) + gc.check_avgpool2(2, 7, 64, 1, torch.bfloat16) + gc.check_avgpool2(3, 6, 128, 1, torch.float32):
+    print('ok' if r['ok'] else 'FAIL', r['name'], r['err'], r['tol'])
+run(depth=50, image_size=64, batch=4, compute_dtype='f32', num_classes=1000, randomize_bn=False, sk_ratio=0.0625)
+run(depth=50, image_size=64, batch=4, compute_dtype='f32', num_classes=1000, randomize_bn=True, sk_ratio=0.0625, width_multiplier=2)
+run(depth=50, image_size=64, batch=4, compute_dtype='bf16', num_classes=1000, randomize_bn=False, sk_ratio=0.0625)
+run(depth=18, image_size=64, batch=8, compute_dtype='f32', sk_ratio=0.0625)
 run(depth=18, image_size=32, batch=16, compute_dtype='f32', steps=2)
 run(depth=18, image_size=32, batch=16, compute_dtype='bf16')
 run(depth=18, image_size=32, batch=16, compute_dtype='bf16', randomize_bn=False)
