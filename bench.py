@@ -65,6 +65,9 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--resnet_depth', type=int, default=50)
     ap.add_argument('--image_size', type=int, default=224)
+    ap.add_argument('--width_multiplier', type=int, default=1)
+    ap.add_argument('--sk_ratio', type=float, default=0.0)
+    ap.add_argument('--use_blur', action='store_true', help='include the on-device batch_random_blur (reference default)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_kernel_events', action='store_true')
     args = ap.parse_args()
@@ -83,8 +86,8 @@ def main():
 
     global_batch = args.per_gpu_batch * world
     FLAGS.reset()
-    FLAGS.update(resnet_depth=args.resnet_depth, width_multiplier=1, image_size=args.image_size,
-                 train_batch_size=global_batch, compute_dtype=args.dtype, use_blur=False,
+    FLAGS.update(resnet_depth=args.resnet_depth, width_multiplier=args.width_multiplier, image_size=args.image_size,
+                 sk_ratio=args.sk_ratio, train_batch_size=global_batch, compute_dtype=args.dtype, use_blur=args.use_blur,
                  learning_rate=0.075, learning_rate_scaling='sqrt', weight_decay=1e-6,
                  temperature=0.1, hidden_norm=True, global_bn=True, lineareval_while_pretraining=True)
     RT.reset()
@@ -159,13 +162,14 @@ def main():
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
         'data': 'synthetic',
-        'config': {'workload': 'ResNet-%d 1x, %dx%d, 2 views/image, per-GPU batch %d, global batch %d, '
-                               'NT-Xent T=0.1 + linear-eval head + LARS, global BN, dp%d'
-                               % (args.resnet_depth, args.image_size, args.image_size, args.per_gpu_batch,
-                                  global_batch, world),
+        'config': {'workload': 'ResNet-%d %dx%s, %dx%d, 2 views/image, per-GPU batch %d, global batch %d, '
+                               'NT-Xent T=0.1 + linear-eval head + LARS, global BN%s, dp%d'
+                               % (args.resnet_depth, args.width_multiplier, '+SK' if args.sk_ratio > 0 else '',
+                                  args.image_size, args.image_size, args.per_gpu_batch,
+                                  global_batch, ', on-device blur' if args.use_blur else '', world),
                    'global_batch': global_batch, 'parallelism': 'dp%d' % world},
         'step_mfma_frac': round(value * FLOP_PER_IMAGE / (world * peak * 1e12), 4)
-        if args.resnet_depth == 50 and args.image_size == 224 else None,
+        if args.resnet_depth == 50 and args.image_size == 224 and args.width_multiplier == 1 and args.sk_ratio == 0 else None,
         'roofline': roofline,
         'kernels': kernels,
         'train_metrics': {k: round(v, 5) for k, v in metrics.items()},

@@ -142,6 +142,10 @@ int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int 
 int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, int V, int HW, int C,
                               int dtype, simclr_stream_t stream);
 
+/* ---- on-device augmentation: batch_random_blur, tf2/data_util.py:323-361,413-440 (tf2/model.py:255-258) ---- */
+int simclr_batch_blur(const float* images, float* tmp, float* out, const float* filt, const float* selector,
+                      int b, int H, int W, int nviews, int K, simclr_stream_t stream);
+
 /* ---- ResNet-D shortcut pool (tf2/resnet.py:330-338,400-408) and selective-kernel unit (:266-277) ---- */
 int simclr_avgpool2_fwd(const void* x, void* y, int V, int H, int W, int C, int stride, int dtype,
                         simclr_stream_t stream);

@@ -169,6 +169,46 @@ __global__ void global_avgpool_bwd(const T* __restrict__ dy, const T* __restrict
   }
 }
 
+// ---- batch_random_blur (tf2/data_util.py:323-361, 413-440; called on device from tf2/model.py:255-258).
+// One 1-D pass of the separable depthwise Gaussian (SAME zero padding) over a float32 [b,H,W,C] batch;
+// channel c belongs to view c/3, which has its own filter (one sigma per view per batch) and a per-image
+// 0/1 selector.  Unselected images are copied.  CLIP: clip_by_value(., 0, 1) on the last pass.
+template <bool VERT, bool CLIP>
+__global__ void blur1d(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ filt,
+                       const float* __restrict__ selector, int b, int H, int W, int C, int K) {
+  const long long total = (long long)b * H * W * C;
+  const int r = K / 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int x = (int)((i / C) % W);
+    const int y = (int)((i / ((long long)C * W)) % H);
+    const int n = (int)(i / ((long long)C * W * H));
+    const int view = c / 3;
+    float v;
+    if (selector[view * b + n] == 0.f) {
+      v = in[i];
+    } else {
+      const float* f = filt + view * K;
+      float acc = 0.f;
+      if (VERT) {
+        for (int t = 0; t < K; ++t) {
+          const int yy = y + t - r;
+          if ((unsigned)yy < (unsigned)H) acc = fmaf(f[t], in[i + (long long)(t - r) * W * C], acc);
+        }
+      } else {
+        for (int t = 0; t < K; ++t) {
+          const int xx = x + t - r;
+          if ((unsigned)xx < (unsigned)W) acc = fmaf(f[t], in[i + (long long)(t - r) * C], acc);
+        }
+      }
+      v = acc;
+    }
+    if (CLIP) v = fminf(fmaxf(v, 0.f), 1.f);
+    out[i] = v;
+  }
+}
+
 // ---- ResNet-D shortcut: AveragePooling2D(2, strides, SAME if strides==1 else VALID after FixedPadding(2))
 // (tf2/resnet.py:330-338, 400-408).  stride 2: windows rows 2oy..2oy+1 (the (0,1) zero pad is part of
 // the tensor -> divisor always 4); stride 1 SAME: pad (0,1), TF divides by the number of VALID cells.
@@ -507,6 +547,21 @@ int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, in
   return 0;
 }
 
+
+/* batch_random_blur (tf2/data_util.py:413-440): images f32 [b,H,W,3*nviews] -> out (same shape); tmp: scratch of
+ * the same size.  filt [nviews][K] (normalised Gaussian per view, K odd), selector [nviews][b] in {0,1}. */
+int simclr_batch_blur(const float* images, float* tmp, float* out, const float* filt, const float* selector,
+                      int b, int H, int W, int nviews, int K, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(b > 0 && nviews > 0 && K > 0 && (K & 1), "batch_blur: bad shape (K must be odd)");
+  const int C = 3 * nviews;
+  const long long total = (long long)b * H * W * C;
+  hipLaunchKernelGGL((blur1d<false, false>), dim3(grid_for(total)), dim3(256), 0, stream, images, tmp, filt,
+                     selector, b, H, W, C, K);
+  hipLaunchKernelGGL((blur1d<true, true>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)tmp, out,
+                     filt, selector, b, H, W, C, K);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
 
 /* ResNet-D shortcut average pool (tf2/resnet.py:330-338, 400-408): 2x2, stride 1 (SAME, TF valid-count
  * divisor) or 2 (after FixedPadding(2)); OH = H (stride 1) or (H+1)/2. */

@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from . import lars_optimizer, ops, resnet
+from . import data_util, lars_optimizer, ops, resnet
 from .flags import FLAGS
 from .lars_optimizer import Variable
 from .resnet import RT, Act, Layer, PackedInput, scope
@@ -253,9 +253,8 @@ class Model(Layer):
         if FLAGS.train_mode == 'finetune':
             raise NotImplementedError('train_mode=finetune is outside the pretraining hot path')
         if FLAGS.use_blur and training and FLAGS.train_mode == 'pretrain':
-            raise NotImplementedError(
-                'on-device batch_random_blur (tf2/model.py:255-258) is a "next" row of the scope table; '
-                'run with --use_blur=False (blur can be applied in the input pipeline)')
+            # batch_random_blur on the device (tf2/model.py:255-258), fused over the k views
+            inputs = data_util.batch_random_blur_tensor(inputs, FLAGS.image_size, FLAGS.image_size)
         num_transforms = inputs.shape[3] // 3
         k, s = self.resnet_model.stem_kernel_stride
         packed = PackedInput(inputs.contiguous(), num_transforms, k, s, RT.dtype)   # split + concat, :250-259

@@ -402,6 +402,17 @@ def global_avgpool_bwd(dy, H, W, mask_src=None):
     return dx
 
 
+def batch_blur(images, filt, selector):
+    """images f32 [b,H,W,3k]; filt [k,K]; selector [k,b] of 0/1."""
+    b, H, W, C = images.shape
+    k, K = filt.shape
+    assert C == 3 * k and images.dtype == torch.float32
+    tmp = torch.empty_like(images)
+    out = torch.empty_like(images)
+    lib().batch_blur(_p(images), _p(tmp), _p(out), _p(filt), _p(selector), b, H, W, k, K, _s())
+    return out
+
+
 def avgpool2_fwd(x, stride):
     V, H, W, C = x.shape
     OH, OW = (H, W) if stride == 1 else ((H + 1) // 2, (W + 1) // 2)

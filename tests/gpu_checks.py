@@ -438,6 +438,21 @@ def _flat(d, keys, like):
     return torch.cat([(d[k] if d[k] is not None else torch.zeros_like(like[k])).double().reshape(-1).cpu() for k in keys])
 
 
+def check_blur(b, H, k=2, seed=0):
+    """simclr_batch_blur vs the oracle restatement of tf2/data_util.py gaussian_blur / batch_random_blur."""
+    from oracle import blur as oblur
+    from simclr_amd import data_util
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(b, H, H, 3 * k, generator=g)
+    sigmas = [0.1 + 1.9 * float(torch.rand(1, generator=g)) for _ in range(k)]
+    sel = (torch.rand(k, b, generator=g) < 0.5).float()
+    ref = oblur.batch_random_blur([x[..., 3 * i:3 * i + 3].numpy() for i in range(k)], H, sigmas, sel.numpy())
+    ref = np.concatenate(ref, axis=3)
+    y = data_util.batch_random_blur_tensor(x.to(DEV), H, H, sigmas=sigmas, selectors=sel)
+    torch.cuda.synchronize()
+    return [_res('batch_blur b%d %dpx k%d' % (b, H, k), y, ref, 0, 2e-6)]
+
+
 def check_avgpool2(V, H, C, stride, dtype, seed=0):
     """ResNet-D shortcut pool vs the oracle's restatement of AveragePooling2D (tf2/resnet.py:330-338)."""
     from oracle.model_torch import Builder, Config

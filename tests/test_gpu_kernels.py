@@ -153,6 +153,12 @@ def test_train_step_bf16():
                                 randomize_bn=False))
 
 
+@pytest.mark.parametrize('b,H', [(4, 32), (3, 224), (5, 45)])
+def test_batch_random_blur(b, H):
+    from tests import gpu_checks as gc
+    _assert(gc.check_blur(b, H))
+
+
 @pytest.mark.parametrize('H,stride', [(8, 2), (7, 2), (7, 1), (6, 1)])
 def test_avgpool2_resnet_d_shortcut(H, stride):
     from tests import gpu_checks as gc
@@ -198,7 +204,7 @@ def test_model_api_shapes_and_errors():
     assert logits_con.dense().shape == (4, 4) and labels_con.dense().sum() == 4
     with pytest.raises(ValueError):
         m(torch.rand(4, 64, 64, 5, device='cuda'), training=True)
-    FLAGS.update(use_blur=True)
-    with pytest.raises(NotImplementedError):
-        m(x, training=True)
+    FLAGS.update(use_blur=True)                 # reference default: on-device blur inside Model.__call__
+    proj_b, _ = m(x, training=True)
+    assert proj_b.shape == (8, 128) and torch.isfinite(proj_b).all()
     FLAGS.reset(); RT.reset()

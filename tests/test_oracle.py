@@ -189,3 +189,21 @@ def test_train_step_runs_and_updates_bn():
     assert info['grads'][k].abs().max() > 0
     mm = [n for n in s if 'moving_mean' in n][0]
     assert not torch.equal(ns[mm], s[mm])
+
+
+def test_blur_oracle_is_separable_gaussian_and_selector_semantics():
+    """gaussian_blur == 2-D convolution with the outer product of the 1-D filter (zero padding);
+    unselected images pass through (clipped)."""
+    from oracle import blur as oblur
+    g = np.random.default_rng(0)
+    x = g.random((2, 9, 9, 3))
+    y = oblur.gaussian_blur(x, 5, 0.8)
+    r = 2
+    t = np.arange(-r, r + 1)
+    f = np.exp(-t ** 2 / (2 * 0.8 ** 2)); f /= f.sum()
+    k2 = np.outer(f, f)
+    pad = np.zeros((2, 13, 13, 3)); pad[:, 2:11, 2:11] = x
+    ref = sum(k2[i, j] * pad[:, i:i + 9, j:j + 9] for i in range(5) for j in range(5))
+    assert np.abs(y - ref).max() < 1e-12
+    out = oblur.batch_random_blur([x * 1.5], 50, [1.0], [np.array([0.0, 1.0])])[0]
+    assert np.array_equal(out[0], np.clip(x[0] * 1.5, 0, 1)) and not np.array_equal(out[1], np.clip(x[1] * 1.5, 0, 1))
