@@ -110,9 +110,11 @@ int simclr_unpack_stem_dw(const float* src, float* dst, int KH, int KW, int Cin,
 
 /* ---- BatchNorm: tf2/resnet.py:31-78 (BatchNormRelu), residual tail :382/:487 ------------------- */
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, simclr_stream_t stream);
-int simclr_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
-                       float* moving_mean, float* moving_var, float decay, float eps, float* mean,
-                       float* rstd, float* scale, float* shift, simclr_stream_t stream);
+/* sums [2][C] fp64 (after the cross-replica all-reduce) OR partial [nslot][2][C] fp32 (single replica). */
+int simclr_bn_finalize(const double* sums, const float* partial, int nslot, double count, int C,
+                       const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                       float decay, float eps, float* mean, float* rstd, float* scale, float* shift,
+                       simclr_stream_t stream);
 int simclr_bn_apply(const void* x, const float* scale, const float* shift, const void* res,
                     const float* rscale, const float* rshift, void* y, long long rows, int C, int relu,
                     int dtype, simclr_stream_t stream);
@@ -120,9 +122,9 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
 int simclr_bn_bwd_reduce(const void* dy, const void* x, const void* mask_src, const float* scale,
                          const float* shift, const float* mean, const float* rstd, long long rows, int C,
                          int mask_mode, float* partial, int nslot, int dtype, simclr_stream_t stream);
-int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, double count, int C,
-                           float* dgamma, float* dbeta, int accumulate, float* c1, float* c2,
-                           simclr_stream_t stream);
+int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, const float* partial,
+                           int nslot, double count, int C, float* dgamma, float* dbeta, int accumulate,
+                           float* c1, float* c2, simclr_stream_t stream);
 int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, const float* scale,
                         const float* shift, const float* mean, const float* rstd, const float* c1,
                         const float* c2, long long rows, int C, int mask_mode, void* dx, void* dmasked,

@@ -27,8 +27,10 @@ __global__ void bn_reduce_slots(const float* __restrict__ partial, int nslot, in
   sums[i] = a;
 }
 
-// From global sums -> mean/rstd/scale/shift, moving-stat update.
-__global__ void bn_finalize(const double* __restrict__ sums, double count, int C,
+// From global sums -> mean/rstd/scale/shift, moving-stat update.  If `partial` is given (single
+// replica: no all-reduce between) the slot reduction is done here instead of a separate launch.
+__global__ void bn_finalize(const double* __restrict__ sums, const float* __restrict__ partial, int nslot,
+                            double count, int C,
                             const float* __restrict__ gamma, const float* __restrict__ beta,
                             float* __restrict__ moving_mean, float* __restrict__ moving_var,
                             float decay, float eps, float* __restrict__ mean_out,
@@ -36,8 +38,16 @@ __global__ void bn_finalize(const double* __restrict__ sums, double count, int C
                             float* __restrict__ shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = sums[c] / count;
-  double var = sums[C + c] / count - mean * mean;  // biased variance (Keras non-fused BN)
+  double s1, s2;
+  if (partial) {
+    s1 = 0.0; s2 = 0.0;
+    for (int s = 0; s < nslot; ++s) {
+      s1 += (double)partial[(long long)s * 2 * C + c];
+      s2 += (double)partial[(long long)s * 2 * C + C + c];
+    }
+  } else { s1 = sums[c]; s2 = sums[C + c]; }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;  // biased variance (Keras non-fused BN)
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f;
@@ -193,15 +203,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(
 
 // local sums -> dgamma/dbeta (+=), global sums/count -> c1 = mean(dy), c2 = mean(dy*x^)
 __global__ void bn_bwd_finalize(const double* __restrict__ local_sums,
-                                const double* __restrict__ global_sums, double count, int C,
+                                const double* __restrict__ global_sums, const float* __restrict__ partial,
+                                int nslot, double count, int C,
                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                 float* __restrict__ c1, float* __restrict__ c2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)local_sums[c];
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)local_sums[C + c];
-  c1[c] = (float)(global_sums[c] / count);
-  c2[c] = (float)(global_sums[C + c] / count);
+  double l1, l2, g1, g2;
+  if (partial) {           // single replica: local == global, reduce the slots here
+    l1 = 0.0; l2 = 0.0;
+    for (int s = 0; s < nslot; ++s) {
+      l1 += (double)partial[(long long)s * 2 * C + c];
+      l2 += (double)partial[(long long)s * 2 * C + C + c];
+    }
+    g1 = l1; g2 = l2;
+  } else { l1 = local_sums[c]; l2 = local_sums[C + c]; g1 = global_sums[c]; g2 = global_sums[C + c]; }
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)l1;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)l2;
+  c1[c] = (float)(g1 / count);
+  c2[c] = (float)(g2 / count);
 }
 
 // dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]; one channel chunk per thread, 2 rows in flight
@@ -294,14 +314,17 @@ int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums,
   return 0;
 }
 
-// sums [2][C] (global), count = global elements per channel.  gamma/beta nullable
+// sums [2][C] (global) OR partial [nslot][2][C] (single replica; slot reduction fused here), count =
+// global elements per channel.  gamma/beta nullable
 // (scale=False / center=False).  moving_* nullable (no update).
-int simclr_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
-                       float* moving_mean, float* moving_var, float decay, float eps, float* mean,
-                       float* rstd, float* scale, float* shift, hipStream_t stream) {
+int simclr_bn_finalize(const double* sums, const float* partial, int nslot, double count, int C,
+                       const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                       float decay, float eps, float* mean, float* rstd, float* scale, float* shift,
+                       hipStream_t stream) {
   SIMCLR_CHECK_ARG(C > 0 && count > 0, "bn_finalize: bad shape");
-  hipLaunchKernelGGL(bn_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, count, C, gamma, beta,
-                     moving_mean, moving_var, decay, eps, mean, rstd, scale, shift);
+  SIMCLR_CHECK_ARG((sums != nullptr) != (partial != nullptr), "bn_finalize: give sums OR partial slots");
+  hipLaunchKernelGGL(bn_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, partial, nslot, count, C,
+                     gamma, beta, moving_mean, moving_var, decay, eps, mean, rstd, scale, shift);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -352,11 +375,13 @@ int simclr_bn_bwd_reduce(const void* dy, const void* x, const void* mask_src, co
   return 0;
 }
 
-int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, double count, int C,
-                           float* dgamma, float* dbeta, int accumulate, float* c1, float* c2,
-                           hipStream_t stream) {
+int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, const float* partial,
+                           int nslot, double count, int C, float* dgamma, float* dbeta, int accumulate,
+                           float* c1, float* c2, hipStream_t stream) {
+  SIMCLR_CHECK_ARG((local_sums != nullptr && global_sums != nullptr) != (partial != nullptr),
+                   "bn_bwd_finalize: give (local, global) sums OR partial slots");
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, stream, local_sums, global_sums,
-                     count, C, dgamma, dbeta, accumulate, c1, c2);
+                     partial, nslot, count, C, dgamma, dbeta, accumulate, c1, c2);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

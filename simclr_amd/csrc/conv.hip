@@ -797,6 +797,7 @@ struct WgradP {
   int V, IH, IW, IC, OH, OW, N, KH, KW, stride, pad, pixpitch;
   int M, K, splits, chunks_per_split;
   int k_tiles, n_tiles;
+  int xcd_map;   // 1: all tiles of a pixel range on one XCD (big tensors); 0: plain interleaving
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -831,9 +832,24 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fl = lane & 15;
   const int wk = wave / WNN, wn = wave % WNN;
-  const int ktile = blockIdx.x % p.k_tiles;
-  const int ntile = (blockIdx.x / p.k_tiles) % p.n_tiles;
-  const int split = blockIdx.x / (p.k_tiles * p.n_tiles);
+  // XCD-aware mapping (workgroup b runs on XCD b%8): every (tap/k-tile, n-tile) workgroup of one
+  // pixel range ("split") sits on the SAME XCD, so the 9 taps x N-tiles that re-read the same
+  // activation / gradient rows are served by that XCD's L2 instead of 8 separate fabric fetches.
+  // Measured per layer (profiles/r01_notes.md): a win for the 56x56 layers and the 28x28 1x1 layers
+  // (tensors far larger than L2/MALL), a loss for the small-spatial ones -> chosen by the host.
+  const int tiles = p.k_tiles * p.n_tiles;
+  int tile, split;
+  if (p.xcd_map) {
+    const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+    tile = bidx % tiles;
+    split = (bidx / tiles) * 8 + xcd;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  if (split >= p.splits) return;
+  const int ktile = tile % p.k_tiles;
+  const int ntile = tile / p.k_tiles;
   const int kk0 = ktile * BKW;
   const int tap = kk0 / p.IC, ci0 = kk0 - tap * p.IC;
   const int ty = tap / p.KW, tx = tap - ty * p.KW;
@@ -1367,10 +1383,20 @@ size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int C
 static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int* chunks_per_split) {
   const int tiles = (K / bkw) * ceil_div(N, bnw);
   const int nchunks = ceil_div(M, br);
-  int splits = max(1, min(nchunks, 1024 / max(1, tiles)));
+  // ~1024-2048 workgroups in total; a multiple of 8 pixel ranges so that the XCD-aware mapping (one
+  // pixel range per XCD at a time) keeps all 8 XCDs equally loaded
+  int splits = max(1, min(nchunks, 1536 / max(1, tiles)));
+  if (nchunks >= 8) splits = min(nchunks / 8 * 8, max(8, (splits + 7) / 8 * 8));
   splits = min(splits, 256);
   *chunks_per_split = ceil_div(nchunks, splits);
-  return ceil_div(nchunks, *chunks_per_split);
+  int eff = ceil_div(nchunks, *chunks_per_split);
+  // keep the effective split count a multiple of 8 when possible
+  while (nchunks >= 8 && eff % 8 != 0 && *chunks_per_split > 1) {
+    --*chunks_per_split;
+    eff = ceil_div(nchunks, *chunks_per_split);
+    if (eff > 256) { ++*chunks_per_split; eff = ceil_div(nchunks, *chunks_per_split); break; }
+  }
+  return eff;
 }
 static void wgrad_tile(int Cin, int Cout, int* bkw, int* bnw) {
   *bkw = (Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : 32);
@@ -1407,7 +1433,8 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   p.splits = wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split);
   p.k_tiles = p.K / bkw;
   p.n_tiles = ceil_div(p.N, bnw);
-  const int grid = p.k_tiles * p.n_tiles * p.splits;
+  p.xcd_map = (p.M >= 1500000) || (p.M >= 500000 && KH * KW == 1 && stride == 1);
+  const int grid = p.k_tiles * p.n_tiles * (p.xcd_map ? ceil_div(p.splits, 8) * 8 : p.splits);
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
   const size_t lds = 2 * (size_t)br * (bkw + bnw) * esz;
 #define LW(TT, A, B) hipLaunchKernelGGL((conv_wgrad<TT, A, B>), dim3(grid), dim3(256), lds, stream, p)

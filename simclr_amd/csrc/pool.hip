@@ -173,39 +173,48 @@ __global__ void global_avgpool_bwd(const T* __restrict__ dy, const T* __restrict
 // One 1-D pass of the separable depthwise Gaussian (SAME zero padding) over a float32 [b,H,W,C] batch;
 // channel c belongs to view c/3, which has its own filter (one sigma per view per batch) and a per-image
 // 0/1 selector.  Unselected images are copied.  CLIP: clip_by_value(., 0, 1) on the last pass.
-template <bool VERT, bool CLIP>
-__global__ void blur1d(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ filt,
-                       const float* __restrict__ selector, int b, int H, int W, int C, int K) {
-  const long long total = (long long)b * H * W * C;
+// One thread per (image, pixel, view): 3 channels, taps along x (HORIZONTAL pass, only for selected
+// images, writes tmp) or along y (VERTICAL pass: reads tmp for selected images, the input itself for
+// unselected ones, clips and writes the result) -- unselected images are touched once.
+template <bool VERT>
+__global__ void blur1d(const float* __restrict__ in, const float* __restrict__ tmp, float* __restrict__ out,
+                       const float* __restrict__ filt, const float* __restrict__ selector, int b, int H, int W,
+                       int nviews, int K) {
+  const int C = 3 * nviews;
+  const long long total = (long long)b * H * W * nviews;
   const int r = K / 2;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int x = (int)((i / C) % W);
-    const int y = (int)((i / ((long long)C * W)) % H);
-    const int n = (int)(i / ((long long)C * W * H));
-    const int view = c / 3;
-    float v;
-    if (selector[view * b + n] == 0.f) {
-      v = in[i];
+    const int view = (int)(i % nviews);
+    const long long pix = i / nviews;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long long)W * H));
+    const bool sel = selector[view * b + n] != 0.f;
+    const long long e = pix * C + 3 * view;
+    float a0, a1, a2;
+    if (!sel) {
+      if (!VERT) continue;                       // horizontal pass skips unselected images
+      a0 = in[e]; a1 = in[e + 1]; a2 = in[e + 2];
     } else {
+      const float* src = VERT ? tmp : in;
       const float* f = filt + view * K;
-      float acc = 0.f;
-      if (VERT) {
-        for (int t = 0; t < K; ++t) {
-          const int yy = y + t - r;
-          if ((unsigned)yy < (unsigned)H) acc = fmaf(f[t], in[i + (long long)(t - r) * W * C], acc);
-        }
-      } else {
-        for (int t = 0; t < K; ++t) {
-          const int xx = x + t - r;
-          if ((unsigned)xx < (unsigned)W) acc = fmaf(f[t], in[i + (long long)(t - r) * C], acc);
-        }
+      a0 = a1 = a2 = 0.f;
+      const long long step = VERT ? (long long)W * C : C;
+      const int pos = VERT ? y : x, lim = VERT ? H : W;
+      const int t0 = max(0, r - pos), t1 = min(K, lim + r - pos);
+      const float* q = src + e + (long long)(t0 - r) * step;
+      for (int t = t0; t < t1; ++t, q += step) {
+        const float w = f[t];
+        a0 = fmaf(w, q[0], a0); a1 = fmaf(w, q[1], a1); a2 = fmaf(w, q[2], a2);
       }
-      v = acc;
     }
-    if (CLIP) v = fminf(fmaxf(v, 0.f), 1.f);
-    out[i] = v;
+    if (VERT) {                                  // clip_by_value(., 0, 1), tf2/data_util.py:437
+      a0 = fminf(fmaxf(a0, 0.f), 1.f); a1 = fminf(fmaxf(a1, 0.f), 1.f); a2 = fminf(fmaxf(a2, 0.f), 1.f);
+      out[e] = a0; out[e + 1] = a1; out[e + 2] = a2;
+    } else {
+      out[e] = a0; out[e + 1] = a1; out[e + 2] = a2;
+    }
   }
 }
 
@@ -553,12 +562,11 @@ int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, in
 int simclr_batch_blur(const float* images, float* tmp, float* out, const float* filt, const float* selector,
                       int b, int H, int W, int nviews, int K, hipStream_t stream) {
   SIMCLR_CHECK_ARG(b > 0 && nviews > 0 && K > 0 && (K & 1), "batch_blur: bad shape (K must be odd)");
-  const int C = 3 * nviews;
-  const long long total = (long long)b * H * W * C;
-  hipLaunchKernelGGL((blur1d<false, false>), dim3(grid_for(total)), dim3(256), 0, stream, images, tmp, filt,
-                     selector, b, H, W, C, K);
-  hipLaunchKernelGGL((blur1d<true, true>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)tmp, out,
-                     filt, selector, b, H, W, C, K);
+  const long long total = (long long)b * H * W * nviews;
+  hipLaunchKernelGGL((blur1d<false>), dim3(grid_for(total)), dim3(256), 0, stream, images, (const float*)nullptr, tmp,
+                     filt, selector, b, H, W, nviews, K);
+  hipLaunchKernelGGL((blur1d<true>), dim3(grid_for(total)), dim3(256), 0, stream, images, (const float*)tmp, out,
+                     filt, selector, b, H, W, nviews, K);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

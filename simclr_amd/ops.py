@@ -314,11 +314,14 @@ def bn_reduce_slots(partial):
     return sums
 
 
-def bn_finalize(sums, count, gamma, beta, moving_mean, moving_var, decay, eps=1e-5):
-    C = sums.shape[1]
-    dev = sums.device
+def bn_finalize(sums, count, gamma, beta, moving_mean, moving_var, decay, eps=1e-5, partial=None):
+    """sums [2,C] fp64 (cross-replica path) or partial [NSLOT,2,C] fp32 (single replica: fused reduce)."""
+    src = partial if partial is not None else sums
+    C = src.shape[-1]
+    dev = src.device
     mean, rstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
-    lib().bn_finalize(_p(sums), float(count), C, _p(gamma), _p(beta), _p(moving_mean), _p(moving_var),
+    lib().bn_finalize(_p(sums) if partial is None else None, _p(partial), partial.shape[0] if partial is not None else 0,
+                      float(count), C, _p(gamma), _p(beta), _p(moving_mean), _p(moving_var),
                       float(decay), float(eps), _p(mean), _p(rstd), _p(scale), _p(shift), _s())
     return mean, rstd, scale, shift
 
@@ -342,12 +345,14 @@ def bn_bwd_reduce(dy, x, mask_src, scale, shift, mean, rstd, mask_mode):
     return partial
 
 
-def bn_bwd_finalize(local_sums, global_sums, count, dgamma, dbeta, accumulate=False):
-    C = local_sums.shape[1]
-    c1 = torch.empty(C, device=local_sums.device, dtype=torch.float32)
-    c2 = torch.empty(C, device=local_sums.device, dtype=torch.float32)
-    lib().bn_bwd_finalize(_p(local_sums), _p(global_sums), float(count), C, _p(dgamma), _p(dbeta),
-                          int(accumulate), _p(c1), _p(c2), _s())
+def bn_bwd_finalize(local_sums, global_sums, count, dgamma, dbeta, accumulate=False, partial=None):
+    src = partial if partial is not None else local_sums
+    C = src.shape[-1]
+    c1 = torch.empty(C, device=src.device, dtype=torch.float32)
+    c2 = torch.empty(C, device=src.device, dtype=torch.float32)
+    lib().bn_bwd_finalize(_p(local_sums) if partial is None else None, _p(global_sums) if partial is None else None,
+                          _p(partial), partial.shape[0] if partial is not None else 0, float(count), C,
+                          _p(dgamma), _p(dbeta), int(accumulate), _p(c1), _p(c2), _s())
     return c1, c2
 
 

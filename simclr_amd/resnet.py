@@ -186,14 +186,18 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         if training:
             if inputs.stats is None:
                 raise NotImplementedError('BatchNormRelu input must come from a conv/dense epilogue')
-            sums = ops.bn_reduce_slots(inputs.stats)
             R = num_replicas(RT.strategy)
             count = rows
             if FLAGS.global_bn and R > 1:            # SyncBatchNormalization, :50-60
+                sums = ops.bn_reduce_slots(inputs.stats)
                 RT.strategy.all_reduce_sum(sums)
                 count = rows * R
-            mean, rstd, scale, shift = ops.bn_finalize(sums, count, g, b, self._pmm, self._pmv,
-                                                       FLAGS.batch_norm_decay, BATCH_NORM_EPSILON)
+                mean, rstd, scale, shift = ops.bn_finalize(sums, count, g, b, self._pmm, self._pmv,
+                                                           FLAGS.batch_norm_decay, BATCH_NORM_EPSILON)
+            else:                                    # single replica: slot reduction fused into finalize
+                mean, rstd, scale, shift = ops.bn_finalize(None, count, g, b, self._pmm, self._pmv,
+                                                           FLAGS.batch_norm_decay, BATCH_NORM_EPSILON,
+                                                           partial=inputs.stats)
         else:
             mean = self._pmm
             rstd = torch.rsqrt(self._pmv + BATCH_NORM_EPSILON)
@@ -228,17 +232,22 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         """Second half of the backward when the reduce was fused into the producing dgrad: dm is the
         already-masked gradient, partial the per-channel (sum dm, sum dm*x^) slots."""
         s = self.saved
-        local = ops.bn_reduce_slots(partial)
-        glob = local
-        R = num_replicas(RT.strategy)
-        if FLAGS.global_bn and R > 1:
-            glob = RT.strategy.all_reduce_sum(local.clone())
-        dgamma = self.gamma.ensure_grad() if self.gamma is not None and self.gamma.trainable else None
-        dbeta = self.beta.ensure_grad() if self.beta is not None and self.beta.trainable else None
-        c1, c2 = ops.bn_bwd_finalize(local, glob, s['count'], dgamma, dbeta)
+        c1, c2 = self._bwd_finalize(partial, s['count'])
         dx, _ = ops.bn_bwd_apply(dm, s['x'], None, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2, 0)
         self.saved = None
         return dx
+
+    def _bwd_finalize(self, partial, count):
+        """partial slots -> (dgamma, dbeta written) and the coefficients c1 = mean(dy), c2 = mean(dy*x^).
+        dgamma/dbeta take the LOCAL sums (the gradient all-reduce sums them), c1/c2 the GLOBAL ones."""
+        dgamma = self.gamma.ensure_grad() if self.gamma is not None and self.gamma.trainable else None
+        dbeta = self.beta.ensure_grad() if self.beta is not None and self.beta.trainable else None
+        R = num_replicas(RT.strategy)
+        if FLAGS.global_bn and R > 1:
+            local = ops.bn_reduce_slots(partial)
+            glob = RT.strategy.all_reduce_sum(local.clone())
+            return ops.bn_bwd_finalize(local, glob, count, dgamma, dbeta)
+        return ops.bn_bwd_finalize(None, None, count, dgamma, dbeta, partial=partial)
 
     def backward(self, dy, mask_src=None, mask_mode=None, want_masked=False):
         """dy: gradient wrt this layer's (activated) output.  Returns (dx, dy_masked)."""
@@ -250,14 +259,7 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
             mask_src = None
         x = s['x']
         part = ops.bn_bwd_reduce(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], mask_mode)
-        local = ops.bn_reduce_slots(part)
-        glob = local
-        R = num_replicas(RT.strategy)
-        if FLAGS.global_bn and R > 1:
-            glob = RT.strategy.all_reduce_sum(local.clone())
-        dgamma = self.gamma.ensure_grad() if self.gamma is not None and self.gamma.trainable else None
-        dbeta = self.beta.ensure_grad() if self.beta is not None and self.beta.trainable else None
-        c1, c2 = ops.bn_bwd_finalize(local, glob, s['count'], dgamma, dbeta)
+        c1, c2 = self._bwd_finalize(part, s['count'])
         dx, dmasked = ops.bn_bwd_apply(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2,
                                        mask_mode, want_masked=want_masked)
         self.saved = None
