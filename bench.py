@@ -151,13 +151,30 @@ def main():
         fl = sum(summ[m]['flops'] for m in members)
         nl = sum(summ[m]['launches'] for m in members)
         achieved = fl / (best_ms * 1e-3) / 1e12 if best_ms > 0 else 0.0
+        # HBM traffic per launch of the same kernel family: from the committed rocprofv3 --pmc passes
+        # (FETCH_SIZE / WRITE_SIZE collected separately, FETCH x2 for wide loads -- profiles/r01_pmc_traffic.json);
+        # PMC counters cannot be sampled from inside this process, so this is null when the file is absent
+        # or describes another kernel family / configuration.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+        default_cfg = (args.resnet_depth == 50 and args.image_size == 224 and args.width_multiplier == 1 and
+                       args.sk_ratio == 0 and args.per_gpu_batch == 512 and args.dtype == 'bf16')
+        if best == 'conv_igemm' and default_cfg and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = round(tj['traffic_bytes_per_launch'])
+                traffic_src = 'profiles/r01_pmc_traffic.json'
+            except Exception:
+                traffic = None
         roofline = dict(bound='mfma', kernel=best, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 4), traffic=None,
+                        frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=round(sum(summ[m]['bytes'] for m in members) / max(nl, 1)),
                         avg_launch_us=round(best_ms * 1e3 / max(nl, 1), 2),
                         flops_per_launch_avg=fl / max(nl, 1), launches_per_step=nl // args.steps,
                         ms_per_step=round(best_ms / args.steps, 3))
     line = {
-        'metric': 'images/sec (whole node), ResNet-50 1x SimCLR pretraining step @224px',
+        'metric': 'images/sec (whole node), ResNet-%d %dx%s SimCLR pretraining step @%dpx' % (
+            args.resnet_depth, args.width_multiplier, '+SK' if args.sk_ratio > 0 else '', args.image_size),
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
