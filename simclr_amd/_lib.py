@@ -10,7 +10,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsimclr_hip.so')
+# SIMCLR_HIP_LIB: alternative build of the SAME library (tools/diag_conv.py uses libsimclr_hip_diag.so)
+LIB_PATH = os.environ.get('SIMCLR_HIP_LIB') or os.path.join(_HERE, 'libsimclr_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'simclr_hip.h')
 
 DT_F32 = 0

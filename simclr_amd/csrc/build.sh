@@ -13,5 +13,11 @@ for f in runtime ntxent lars conv bn pool; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC build/runtime.o build/ntxent.o build/lars.o build/conv.o build/bn.o build/pool.o -o $OUT
 echo "built $(realpath $OUT)"
+if [ "$1" = "diag" ]; then
+  # diagnostic library (tools/diag_conv.py): conv kernels with run-time switches that skip pipeline parts
+  hipcc $FLAGS -DSIMCLR_DIAG -c conv.hip -o build/conv_diag.o
+  hipcc --offload-arch=gfx950 -shared -fPIC build/runtime.o build/ntxent.o build/lars.o build/conv_diag.o build/bn.o build/pool.o -o ../libsimclr_hip_diag.so
+  echo "built $(realpath ../libsimclr_hip_diag.so)"
+fi

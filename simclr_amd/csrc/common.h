@@ -40,14 +40,17 @@ void simclr_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __uint_as_float(((uint32_t)b) << 16);
 }
+// fp32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, one
+// instruction per PAIR); the integer emulation costs ~9 VALU instructions per value and made the
+// conv epilogues and the BN kernels instruction-bound.
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2_t));
 }
 
 // Element traits: storage type T is float or uint16_t (bf16 bits).

@@ -52,7 +52,17 @@ struct ConvP {
   const void* bn_mask;
   const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
   int bn_mode;     // 0 off, 1 mask tensor, 2 recompute
+  int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
 };
+
+// Diagnostic build (build.sh diag -> libsimclr_hip_diag.so): parts of a kernel can be switched off at run time
+// (env SIMCLR_DIAG) to attribute time to loads / MFMA / epilogue.  Results are WRONG by design; the product
+// library compiles every DIAG(..) to `false`.
+#ifdef SIMCLR_DIAG
+#define DIAG(b) ((p.diag & (b)) != 0)
+#else
+#define DIAG(b) false
+#endif
 
 template <typename T> struct MMA;
 template <> struct MMA<uint16_t> {
@@ -488,6 +498,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   }
   // ti = tap index, ci = k-tile index inside the tap (both tracked incrementally: no divisions)
   auto issue_tile = [&](int ti, int ci, int buf) __attribute__((always_inline)) {
+    if (DIAG(2)) return;
     const int ci0 = ci * BK;
     const int k0 = (int)((p.tap_w >> (4 * ti)) & 15) * p.IC + ci0;
     unsigned char* a_dst = (unsigned char*)(As + buf * STG) + wave * AJ * 1024;
@@ -570,6 +581,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         __syncthreads();
       }
       if (issued < total) issue_next();
+      if (!DIAG(1))
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4 af[MI], bf[NI];
@@ -592,6 +604,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       ++consumed;
     }
     const int m0 = (mslot + ct * mslots) * BM;
+    if (DIAG(4)) {
+      if (acc[0][0][0] == 12345.678f) Y[0] = (T)0;     // keeps the accumulators live
+      continue;
+    }
     auto row_off = [&](int m) __attribute__((always_inline)) -> long long {
       if (m >= p.M) return -1;
       if (flat) return (long long)m * p.N;
@@ -626,26 +642,54 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         }
       }
       __syncthreads();
+      // All global operands of this thread's ER rows (previous value / BN input / mask) are requested
+      // back to back with branch-free addresses, so the row pass pays ONE memory round trip per tile
+      // instead of one per row pair.
+      constexpr int ER = BM / RPP;
       const int ncol = n0 + e_cc * 8;
-#pragma unroll 2
-      for (int r = tid / CPR; r < BM; r += RPP) {
-        const long long off = rowoff[r];
-        if (off < 0 || ncol >= p.N) continue;
+      long long eoff[ER];
+      bool erok[ER];
+#pragma unroll
+      for (int i = 0; i < ER; ++i) {
+        const long long off = rowoff[tid / CPR + i * RPP];
+        erok[i] = off >= 0 && ncol < p.N;
+        eoff[i] = erok[i] ? off + ncol : 0;       // masked rows read (and ignore) element 0
+      }
+      long long eld[ER];
+#pragma unroll
+      for (int i = 0; i < ER; ++i) eld[i] = DIAG(8) ? 0 : eoff[i];
+      u32x4 e_ov[ER], e_xv[ER], e_mv[ER];
+      if (p.accumulate) {
+#pragma unroll
+        for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
+      }
+      if (BNEPI) {
+#pragma unroll
+        for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
+        if (p.bn_mode == 1) {
+#pragma unroll
+          for (int i = 0; i < ER; ++i) e_mv[i] = *(const u32x4*)((const uint16_t*)p.bn_mask + eld[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < ER; ++i) {
+        if (!erok[i]) continue;
+        const int r = tid / CPR + i * RPP;
         const u32x4 cv = *(const u32x4*)(Cs + r * (BN * 2) + (((e_cc * 2) ^ ((r & 7) << 1)) << 3));
-        uint16_t* dst = (uint16_t*)Y + off + ncol;
+        uint16_t* dst = (uint16_t*)Y + eoff[i];
         float v[8];
         chunk_to_f32<uint16_t>(cv, v);
         if (p.accumulate) {
           float o[8];
-          chunk_to_f32<uint16_t>(*(const u32x4*)dst, o);
+          chunk_to_f32<uint16_t>(e_ov[i], o);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += o[e];
         }
         if (BNEPI) {
           float xf[8], mk[8];
-          chunk_to_f32<uint16_t>(*(const u32x4*)((const uint16_t*)p.bn_x + off + ncol), xf);
+          chunk_to_f32<uint16_t>(e_xv[i], xf);
           if (p.bn_mode == 1) {
-            chunk_to_f32<uint16_t>(*(const u32x4*)((const uint16_t*)p.bn_mask + off + ncol), mk);
+            chunk_to_f32<uint16_t>(e_mv[i], mk);
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) mk[e] = fmaf(xf[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
@@ -657,6 +701,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
             e_q[e] += v[e] * (xf[e] - bnp[2 * BN + e_cc * 8 + e]) * bnp[3 * BN + e_cc * 8 + e];
           }
         }
+        if (DIAG(16)) continue;
         if (p.accumulate || BNEPI) *(u32x4*)dst = f32_to_chunk<uint16_t>(v);
         else *(u32x4*)dst = cv;
       }
@@ -798,6 +843,7 @@ struct WgradP {
   int M, K, splits, chunks_per_split;
   int k_tiles, n_tiles;
   int xcd_map;   // 1: all tiles of a pixel range on one XCD (big tensors); 0: plain interleaving
+  int diag;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -868,11 +914,18 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   const int c_end = min(nchunks, c_begin + p.chunks_per_split);
 
   u32x4 ra[A_CH], rb[B_CH];
+#ifdef SIMCLR_DIAG
+#pragma unroll
+  for (int j = 0; j < A_CH; ++j) ra[j] = zero16();
+#pragma unroll
+  for (int j = 0; j < B_CH; ++j) rb[j] = zero16();
+#endif
   // 1x1 stride-1 (and Dense): reduction pixel m reads input pixel m -- no decode
   const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.IH == p.OH && p.IW == p.OW;
   const int ohow = p.OH * p.OW;
   const float inv_ow = 1.0f / (float)p.OW;
   auto load_chunk = [&](int c) {
+    if (DIAG(2)) return;
     const int mbase = c * BR;
     // (image, pixel-in-image) of the chunk's first pixel: ONE division per chunk (uniform), the
     // per-lane pixel then needs at most two wrap steps and a reciprocal multiply (exact: rem < 2^14)
@@ -909,6 +962,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
     }
   };
   auto store_chunk = [&](int buf) {
+    if (DIAG(4)) return;
     unsigned char* As = smem + buf * BUF;
     unsigned char* Bs = As + BR * A_RB;
 #pragma unroll
@@ -932,6 +986,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
     return px * RB + (((byte >> 5) ^ (px_key<T>(px) & (NBLK - 1))) << 5) + (byte & 31);
   };
   auto compute = [&](int buf) {
+    if (DIAG(1)) return;
     const unsigned char* As = smem + buf * BUF;
     const unsigned char* Bs = As + BR * A_RB;
     if (sizeof(T) == 2) {
@@ -1207,6 +1262,9 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   p.m_tiles = ceil_div(p.M, 128);
   p.n_tiles = ceil_div(p.N, BN);
   if (p.M <= 0) return;
+#ifdef SIMCLR_DIAG
+  { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
+#endif
   const int grid = ceil_div(p.m_tiles, 8) * 8 * p.n_tiles;
   size_t lds = 2 * (128 + BN) * 128;
   const size_t epi = 128 * (BN * 2 + 8) + 128 * sizeof(long long);
@@ -1434,6 +1492,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   p.k_tiles = p.K / bkw;
   p.n_tiles = ceil_div(p.N, bnw);
   p.xcd_map = (p.M >= 1500000) || (p.M >= 500000 && KH * KW == 1 && stride == 1);
+#ifdef SIMCLR_DIAG
+  { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
+#endif
   const int grid = p.k_tiles * p.n_tiles * (p.xcd_map ? ceil_div(p.splits, 8) * 8 : p.splits);
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
   const size_t lds = 2 * (size_t)br * (bkw + bnw) * esz;
