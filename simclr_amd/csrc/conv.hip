@@ -52,6 +52,8 @@ struct ConvP {
   const void* bn_mask;
   const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
   int bn_mode;     // 0 off, 1 mask tensor, 2 recompute
+  const void* zero;  // 16 zero bytes in device memory (source of padding chunks for direct-to-LDS loads):
+                     // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
 };
 
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
   int mt, nt;
   if (!tile_of_block(p.m_tiles, p.n_tiles, mt, nt)) return;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR (LDS bases, M0)
   const int g = lane >> 4, fl = lane & 15;
   const int wm = wave / WN, wn = wave % WN;
   const T* __restrict__ X = (const T*)p.x;
@@ -207,13 +210,13 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
       }
       ok = ok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
       const void* src = ok ? (const void*)(X + ((a_img[j] + (long long)iy * p.IW + ix) * p.pixpitch + ci0 + kc * EPC))
-                           : (const void*)&g_zero16;
+                           : p.zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int n = n0 + b_row(j);
-      const void* src = (n < p.N) ? (const void*)(Wt + ((long long)n * p.K + k0 + kc * EPC)) : (const void*)&g_zero16;
+      const void* src = (n < p.N) ? (const void*)(Wt + ((long long)n * p.K + k0 + kc * EPC)) : p.zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
     }
   };
@@ -422,7 +425,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR (LDS bases, M0)
   const int g = lane >> 4, fl = lane & 15;
   const int wm = wave / WN, wn = wave % WN;
   const T* __restrict__ X = (const T*)p.x;
@@ -505,12 +509,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
     unsigned char* b_dst = (unsigned char*)(Bs + buf * STG) + wave * BJ * 1024;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const void* src = a_tok[j] ? (const void*)(a_tp[j] + ci0) : (const void*)&g_zero16;
+      const void* src = a_tok[j] ? (const void*)(a_tp[j] + ci0) : p.zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const void* src = b_ok[j] ? (const void*)(b_src[j] + k0) : (const void*)&g_zero16;
+      const void* src = b_ok[j] ? (const void*)(b_src[j] + k0) : p.zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
     }
   };
@@ -843,6 +847,7 @@ struct WgradP {
   int M, K, splits, chunks_per_split;
   int k_tiles, n_tiles;
   int xcd_map;   // 1: all tiles of a pixel range on one XCD (big tensors); 0: plain interleaving
+  const void* zero;   // 16 zero bytes (padding source for the direct-to-LDS loads)
   int diag;
 };
 
@@ -875,7 +880,8 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   constexpr int BUF = BR * (A_RB + B_RB);     // bytes per LDS buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR (LDS bases, M0)
   const int g = lane >> 4, fl = lane & 15;
   const int wk = wave / WNN, wn = wave % WNN;
   // XCD-aware mapping (workgroup b runs on XCD b%8): every (tap/k-tile, n-tile) workgroup of one
@@ -1067,6 +1073,251 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// conv_wgrad_dma: same tiling / LDS layout / MFMA schedule as conv_wgrad, but the operands travel
+// global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, the XOR block permutation applied to the
+// SOURCE address) through a STAGES-deep ring, and every per-lane source address is advanced
+// INCREMENTALLY from chunk to chunk (one division per lane at kernel start, none in the loop).
+// The register-staged version spent ~5x more VALU cycles on address generation per chunk than the
+// MFMA pipe needed for the chunk's math (profiles/r01_notes.md, tools/diag_conv.py).
+//   BRM: reduction chunk = BRM * 4 * EPC pixels (bf16: 32 / 64, f32: 16 / 32).
+// ------------------------------------------------------------------------------------
+template <typename T, int BKW, int BNW, int BRM, int STAGES>
+__global__ __launch_bounds__(256, (STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2)
+void conv_wgrad_dma(const WgradP p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BR = BRM * 4 * EPC;           // pixels per reduction chunk
+  constexpr int WNN = 2;                      // 2 x 2 waves
+  constexpr int KI = BKW / 2 / 16;            // 16-row fragments per wave along k
+  constexpr int NI = BNW / WNN / 16;
+  constexpr int A_RB = BKW * sizeof(T);       // row bytes
+  constexpr int B_RB = BNW * sizeof(T);
+  constexpr int A_CPR = A_RB / 16;            // 16-byte chunks per pixel row
+  constexpr int B_CPR = B_RB / 16;
+  constexpr int A_BLK = A_RB / 32;            // 32-byte blocks per pixel row
+  constexpr int B_BLK = B_RB / 32;
+  constexpr int A_RPI = 64 / A_CPR;           // pixel rows covered by one wave-wide 1024-byte DMA instruction
+  constexpr int B_RPI = 64 / B_CPR;
+  constexpr int AJ = BR / A_RPI / 4;          // DMA instructions per wave per chunk
+  constexpr int BJ = BR / B_RPI / 4;
+  static_assert(AJ >= 1 && BJ >= 1 && A_CPR <= 64 && B_CPR <= 64, "tile / chunk configuration");
+  constexpr int BUF = BR * (A_RB + B_RB);     // bytes per stage: [A tile | B tile]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, fl = lane & 15;
+  const int wk = wave / WNN, wn = wave % WNN;
+  const int tiles = p.k_tiles * p.n_tiles;
+  int tile, split;
+  if (p.xcd_map) {
+    const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+    tile = bidx % tiles;
+    split = (bidx / tiles) * 8 + xcd;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  if (split >= p.splits) return;
+  const int ktile = tile % p.k_tiles;
+  const int ntile = tile / p.k_tiles;
+  const int kk0 = ktile * BKW;
+  const int tap = kk0 / p.IC, ci0 = kk0 - tap * p.IC;
+  const int ty = tap / p.KW, tx = tap - ty * p.KW;
+  const int n0 = ntile * BNW;
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ DY = (const T*)p.dy;
+
+  f32x4 acc[KI][NI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (p.M + BR - 1) / BR;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+  const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.IH == p.OH && p.IW == p.OW;
+  const bool shift = !flat && p.stride == 1 && p.IH == p.OH && p.IW == p.OW;
+  const int ohow = p.OH * p.OW;
+  // decomposition of one chunk step (BR pixels) into whole images / rows / columns
+  const int dq = BR / ohow, drem = BR - dq * ohow, drow = drem / p.OW, dcol = drem - drow * p.OW;
+
+  // ---- per-lane source state (fixed LDS slot per lane and instruction; only the pixel advances) ----
+  int a_m[AJ], a_v[AJ], a_oy[AJ], a_ox[AJ];
+  const T* a_ptr[AJ];        // flat: current source; otherwise X + channel offset (pixel part recomputed)
+  int b_m[BJ];
+  const T* b_ptr[BJ];
+  bool b_cok[BJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int px = (wave * AJ + j) * A_RPI + lane / A_CPR, pc = lane % A_CPR;
+    const int lc = (((pc >> 1) ^ (px_key<T>(px) & (A_BLK - 1))) << 1) | (pc & 1);   // logical chunk held by this slot
+    const int m = c_begin * BR + px;
+    a_m[j] = m;
+    if (flat) {
+      a_ptr[j] = X + (long long)m * p.pixpitch + ci0 + lc * EPC;
+      a_v[j] = a_oy[j] = a_ox[j] = 0;
+    } else {
+      const int v = m / ohow, rem = m - v * ohow;
+      a_v[j] = v; a_oy[j] = rem / p.OW; a_ox[j] = rem - a_oy[j] * p.OW;
+      a_ptr[j] = X + ci0 + lc * EPC;
+      if (shift) a_ptr[j] += ((long long)m + (ty - p.pad) * p.IW + (tx - p.pad)) * p.pixpitch;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int px = (wave * BJ + j) * B_RPI + lane / B_CPR, pc = lane % B_CPR;
+    const int lc = (((pc >> 1) ^ (px_key<T>(px) & (B_BLK - 1))) << 1) | (pc & 1);
+    const int m = c_begin * BR + px;
+    b_m[j] = m;
+    b_cok[j] = n0 + lc * EPC < p.N;
+    b_ptr[j] = DY + (long long)m * p.N + n0 + lc * EPC;
+  }
+  const long long a_step = (long long)BR * p.pixpitch, b_step = (long long)BR * p.N;
+
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    if (DIAG(2)) return;
+    unsigned char* a_dst = smem + stage * BUF + wave * (AJ * 1024);
+    unsigned char* b_dst = smem + stage * BUF + BR * A_RB + wave * (BJ * 1024);
+    if (flat) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const void* src = a_m[j] < p.M ? (const void*)a_ptr[j] : p.zero;
+        a_ptr[j] += a_step;
+        a_m[j] += BR;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
+      }
+    } else if (shift) {
+      // stride-1 "same" convolution: the tap's input pixel is output pixel m + constant, so the source
+      // pointer advances linearly; only the border test needs the (row, column) of the pixel
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int iy = a_oy[j] - p.pad + ty, ix = a_ox[j] - p.pad + tx;
+        const bool ok = a_m[j] < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const void* src = ok ? (const void*)a_ptr[j] : p.zero;
+        a_ptr[j] += a_step;
+        a_ox[j] += dcol;
+        if (a_ox[j] >= p.OW) { a_ox[j] -= p.OW; ++a_oy[j]; }
+        a_oy[j] += drow;
+        if (a_oy[j] >= p.OH) a_oy[j] -= p.OH;
+        a_m[j] += BR;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int iy = a_oy[j] * p.stride - p.pad + ty, ix = a_ox[j] * p.stride - p.pad + tx;
+        const bool ok = a_m[j] < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int pix = (a_v[j] * p.IH + iy) * p.IW + ix;
+        const void* src = ok ? (const void*)(a_ptr[j] + (long long)pix * p.pixpitch) : p.zero;
+        a_ox[j] += dcol;
+        if (a_ox[j] >= p.OW) { a_ox[j] -= p.OW; ++a_oy[j]; }
+        a_oy[j] += drow;
+        if (a_oy[j] >= p.OH) { a_oy[j] -= p.OH; ++a_v[j]; }
+        a_v[j] += dq;
+        a_m[j] += BR;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const void* src = (b_m[j] < p.M && b_cok[j]) ? (const void*)b_ptr[j] : p.zero;
+      b_ptr[j] += b_step;
+      b_m[j] += BR;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
+    }
+  };
+  auto elem_off = [&](int RB, int NBLK, int px, int ch) -> int {
+    const int byte = ch * (int)sizeof(T);
+    return px * RB + (((byte >> 5) ^ (px_key<T>(px) & (NBLK - 1))) << 5) + (byte & 31);
+  };
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    if (DIAG(1)) return;
+    const unsigned char* As = smem + stage * BUF;
+    const unsigned char* Bs = As + BR * A_RB;
+    if (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < BR / 32; ++ks) {
+        u32x4 af[KI], bf[NI];
+        const int px0 = ks * 32 + g * 8 + (fl >> 2);
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+          const int ch = wk * (KI * 16) + i * 16 + (fl & 3) * 4;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(As + elem_off(A_RB, A_BLK, px0, ch)));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(As + elem_off(A_RB, A_BLK, px0 + 4, ch)));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          af[i] = (u32x4){l2[0], l2[1], h2[0], h2[1]};
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int ch = wn * (NI * 16) + i * 16 + (fl & 3) * 4;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bs + elem_off(B_RB, B_BLK, px0, ch)));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bs + elem_off(B_RB, B_BLK, px0 + 4, ch)));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          bf[i] = (u32x4){l2[0], l2[1], h2[0], h2[1]};
+        }
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, bf[ni]), __builtin_bit_cast(bf16x8, af[ki]), acc[ki][ni], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < BR / 4; ++ks) {
+        float af[KI], bf[NI];
+        const int px = ks * 4 + g;
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+          af[i] = *(const float*)(As + elem_off(A_RB, A_BLK, px, wk * (KI * 16) + i * 16 + fl));
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          bf[i] = *(const float*)(Bs + elem_off(B_RB, B_BLK, px, wn * (NI * 16) + i * 16 + fl));
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni], af[ki], acc[ki][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  // ring: chunk c lives in stage (c - c_begin) % STAGES; STAGES-1 chunks are in flight ahead of the math
+  int issued = c_begin;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (issued < c_end) { issue(s); ++issued; }
+  int cs = 0, is = STAGES - 1;          // compute stage, next issue stage
+  for (int c = c_begin; c < c_end; ++c) {
+    // chunk c must have landed; newer chunks may stay in flight (each wave issued AJ+BJ loads per chunk)
+    const int ahead = issued - c - 1;
+    if (STAGES >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AJ + BJ)) : "memory");
+    else if (STAGES >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (issued < c_end) { issue(is); ++issued; is = (is + 1 == STAGES) ? 0 : is + 1; }
+    compute(cs);
+    cs = (cs + 1 == STAGES) ? 0 : cs + 1;
+  }
+  // D[n = g*4+reg][k row = fl]  ->  slab[split][kk][n .. n+3]
+  float* slab = p.dw + (long long)split * p.K * p.N;
+#pragma unroll
+  for (int ki = 0; ki < KI; ++ki) {
+    const int kk = kk0 + wk * (KI * 16) + ki * 16 + fl;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (NI * 16) + ni * 16 + g * 4;
+      if (kk < p.K && n < p.N)
+        *(float4*)(slab + (long long)kk * p.N + n) =
+            make_float4(acc[ki][ni][0], acc[ki][ni][1], acc[ki][ni][2], acc[ki][ni][3]);
+    }
+  }
+}
+
 // dw[i] = sum_s slabs[s][i]  (+ dw[i] if accumulate)
 __global__ void slab_reduce(const float* __restrict__ slabs, int splits, long long numel,
                             float* __restrict__ out, int accumulate) {
@@ -1108,7 +1359,8 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
   constexpr int KSTEP = 4 * EPC;     // elements per MFMA k-step
   constexpr int BN = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR (LDS bases, M0)
   const int g = lane >> 4, fl = lane & 15;
   const int n0 = blockIdx.y * BN;
   const int pitch = p.KP * (int)sizeof(T) + 16;  // bytes per weight row in LDS (+16: bank spread)
@@ -1265,6 +1517,11 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
 #ifdef SIMCLR_DIAG
   { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
 #endif
+  {
+    static void* zero_page = nullptr;
+    if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero16)) != hipSuccess) zero_page = nullptr;
+    p.zero = zero_page;
+  }
   const int grid = ceil_div(p.m_tiles, 8) * 8 * p.n_tiles;
   size_t lds = 2 * (128 + BN) * 128;
   const size_t epi = 128 * (BN * 2 + 8) + 128 * sizeof(long long);
@@ -1466,8 +1723,9 @@ size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int C
                                            int dtype) {
   int bkw, bnw, cps;
   wgrad_tile(Cin, Cout, &bkw, &bnw);
-  const int br = dtype == SIMCLR_DT_BF16 ? 64 : 32;
-  const int splits = wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, br, &cps);
+  // the bf16 kernel variants reduce in chunks of 64 or 32 pixels: size for whichever needs more slabs
+  int splits = wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps);
+  splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, 32, &cps));
   return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
 }
 
@@ -1487,7 +1745,22 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   p.M = V * OH * OW; p.K = KH * KW * Cin;
   int bkw, bnw;
   wgrad_tile(Cin, Cout, &bkw, &bnw);
-  const int br = dtype == SIMCLR_DT_BF16 ? 64 : 32;
+  // kernel variant: 1 = LDS-DMA ring, 64-pixel chunks x 2 stages; 2 = 32-pixel chunks x 3 stages for the
+  // 128x128 tile (3 workgroups/CU), 3 stages elsewhere; 3 = 32-pixel chunks x 4 stages; 0 = register-staged
+  // kernel (kept for A/B runs: SIMCLR_WGRAD_CFG).
+#ifdef SIMCLR_DIAG
+  const int cfg_env = getenv("SIMCLR_WGRAD_CFG") ? atoi(getenv("SIMCLR_WGRAD_CFG")) : -1;   // per launch: sweeps
+#else
+  static const int cfg_env = getenv("SIMCLR_WGRAD_CFG") ? atoi(getenv("SIMCLR_WGRAD_CFG")) : -1;
+#endif
+  int cfg = cfg_env >= 0 ? cfg_env : 1;
+  if (dtype != SIMCLR_DT_BF16 && cfg > 1) cfg = 1;
+  // the stem's packed input (pixel pitch 4 elements) gives 8-byte-aligned sources: keep the register-staged kernel
+  if (bkw == 32 || (pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0) cfg = 0;
+  const bool big = bkw == 128 && bnw == 128;
+  const int brm = (cfg >= 2 && big) ? 1 : 2;
+  const int stages = cfg <= 1 ? 2 : (big ? (cfg == 2 ? 3 : 4) : 3);
+  const int br = (dtype == SIMCLR_DT_BF16 ? 32 : 16) * brm;
   p.splits = wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split);
   p.k_tiles = p.K / bkw;
   p.n_tiles = ceil_div(p.N, bnw);
@@ -1495,23 +1768,52 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
 #ifdef SIMCLR_DIAG
   { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
 #endif
+  {
+    static void* zero_page = nullptr;
+    if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero16)) != hipSuccess) zero_page = nullptr;
+    SIMCLR_CHECK_ARG(zero_page != nullptr, "conv2d_wgrad: zero page symbol not found");
+    p.zero = zero_page;
+  }
   const int grid = p.k_tiles * p.n_tiles * (p.xcd_map ? ceil_div(p.splits, 8) * 8 : p.splits);
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
-  const size_t lds = 2 * (size_t)br * (bkw + bnw) * esz;
+  const size_t lds = (size_t)(cfg == 0 ? 2 : stages) * br * (bkw + bnw) * esz;
 #define LW(TT, A, B) hipLaunchKernelGGL((conv_wgrad<TT, A, B>), dim3(grid), dim3(256), lds, stream, p)
-  if (dtype == SIMCLR_DT_BF16) {
-    if (bkw == 128 && bnw == 128) LW(uint16_t, 128, 128);
-    else if (bkw == 128) LW(uint16_t, 128, 64);
-    else if (bkw == 64 && bnw == 128) LW(uint16_t, 64, 128);
-    else if (bkw == 64) LW(uint16_t, 64, 64);
-    else LW(uint16_t, 32, 64);
+#define LD(TT, A, B, M_, S_) hipLaunchKernelGGL((conv_wgrad_dma<TT, A, B, M_, S_>), dim3(grid), dim3(256), lds, stream, p)
+  if (cfg == 0) {
+    if (dtype == SIMCLR_DT_BF16) {
+      if (bkw == 128 && bnw == 128) LW(uint16_t, 128, 128);
+      else if (bkw == 128) LW(uint16_t, 128, 64);
+      else if (bkw == 64 && bnw == 128) LW(uint16_t, 64, 128);
+      else if (bkw == 64) LW(uint16_t, 64, 64);
+      else LW(uint16_t, 32, 64);
+    } else {
+      if (bkw == 128 && bnw == 128) LW(float, 128, 128);
+      else if (bkw == 128) LW(float, 128, 64);
+      else if (bkw == 64 && bnw == 128) LW(float, 64, 128);
+      else if (bkw == 64) LW(float, 64, 64);
+      else LW(float, 32, 64);
+    }
+  } else if (dtype != SIMCLR_DT_BF16) {
+    if (bkw == 128 && bnw == 128) LD(float, 128, 128, 2, 2);
+    else if (bkw == 128) LD(float, 128, 64, 2, 2);
+    else if (bkw == 64 && bnw == 128) LD(float, 64, 128, 2, 2);
+    else if (bkw == 64) LD(float, 64, 64, 2, 2);
+    else LD(float, 32, 64, 2, 2);
+  } else if (stages == 2) {
+    if (bkw == 128 && bnw == 128) LD(uint16_t, 128, 128, 2, 2);
+    else if (bkw == 128) LD(uint16_t, 128, 64, 2, 2);
+    else if (bkw == 64 && bnw == 128) LD(uint16_t, 64, 128, 2, 2);
+    else if (bkw == 64) LD(uint16_t, 64, 64, 2, 2);
+    else LD(uint16_t, 32, 64, 2, 2);
   } else {
-    if (bkw == 128 && bnw == 128) LW(float, 128, 128);
-    else if (bkw == 128) LW(float, 128, 64);
-    else if (bkw == 64 && bnw == 128) LW(float, 64, 128);
-    else if (bkw == 64) LW(float, 64, 64);
-    else LW(float, 32, 64);
+    if (big && stages == 3) LD(uint16_t, 128, 128, 1, 3);
+    else if (big) LD(uint16_t, 128, 128, 1, 4);
+    else if (bkw == 128) LD(uint16_t, 128, 64, 2, 3);
+    else if (bkw == 64 && bnw == 128) LD(uint16_t, 64, 128, 2, 3);
+    else if (bkw == 64) LD(uint16_t, 64, 64, 2, 3);
+    else LD(uint16_t, 32, 64, 2, 3);
   }
+#undef LD
 #undef LW
   SIMCLR_CHECK_LAUNCH();
   const long long numel = (long long)p.K * p.N;

@@ -48,8 +48,33 @@ def sweep(fn, modes):
     return out
 
 
+def wgrad_cfg_sweep():
+    """Every distinct ResNet-50 conv shape: wgrad time under each kernel variant (SIMCLR_WGRAD_CFG 0..3)."""
+    from tools.microbench import R50
+    dev, dt, V = 'cuda', torch.bfloat16, 1024
+    tot = [0.0] * 4
+    print('%-26s %8s %8s %8s %8s' % ('wgrad layer', 'cfg0', 'cfg1', 'cfg2', 'cfg3'))
+    for (H, Cin, Cout, k, s, cnt) in R50:
+        pad = (k - 1) // 2
+        OH = (H + (k - 1) - k) // s + 1
+        x = torch.randn(V, H, H, Cin, device=dev).to(dt)
+        dy = torch.randn(V, OH, OH, Cout, device=dev).to(dt)
+        dw = torch.empty(k * k * Cin, Cout, device=dev)
+        ts = []
+        for cfg in range(4):
+            os.environ['SIMCLR_WGRAD_CFG'] = str(cfg)
+            ts.append(timeit(lambda: ops.conv2d_wgrad(x, dy, k, k, s, pad, out=dw)))
+            tot[cfg] += cnt * ts[-1]
+        print('%-26s %8.0f %8.0f %8.0f %8.0f' % ('%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt), *ts), flush=True)
+        del x, dy
+    os.environ.pop('SIMCLR_WGRAD_CFG')
+    print('per-step totals (ms): ' + ' '.join('%.2f' % (t / 1e3) for t in tot), flush=True)
+
+
 def main():
-    assert 'diag' in _lib.LIB_PATH, 'run with SIMCLR_HIP_LIB=simclr_amd/libsimclr_hip_diag.so'
+    assert 'diag' in _lib.LIB_PATH
+    if '--wgrad' in sys.argv:
+        return wgrad_cfg_sweep(), 'run with SIMCLR_HIP_LIB=simclr_amd/libsimclr_hip_diag.so'
     dev, dt, V = 'cuda', torch.bfloat16, 1024
     print('igemm modes', IGEMM_MODES, ' wgrad modes', WGRAD_MODES)
     for (H, Cin, Cout, k) in LAYERS:
