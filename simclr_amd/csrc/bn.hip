@@ -74,13 +74,20 @@ __device__ __forceinline__ void load_params(const float* __restrict__ p, int c0,
 // Every thread owns ONE channel chunk (grid*256 is a multiple of chunks-per-row), so the
 // per-channel parameters are loaded once; rows are walked 4 at a time to keep 4-8 16-byte
 // loads in flight per lane.
-template <typename T, int RES>   // RES: 0 none, 1 plain residual, 2 residual with its own BN
+// streaming 16-byte accesses, optionally with the non-temporal cache policy (tensors far larger than L2 + MALL)
+template <bool NT> __device__ __forceinline__ u32x4 ldg16(const void* p) {
+  return NT ? __builtin_nontemporal_load((const u32x4*)p) : *(const u32x4*)p;
+}
+template <bool NT> __device__ __forceinline__ void stg16(void* p, const u32x4& v) {
+  if (NT) __builtin_nontemporal_store(v, (u32x4*)p); else *(u32x4*)p = v;
+}
+
+template <typename T, int RES, int U, bool NT>   // RES: 0 none, 1 plain residual, 2 residual with its own BN
 __global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const float* __restrict__ scale,
                          const float* __restrict__ shift, const T* __restrict__ res,
                          const float* __restrict__ rscale, const float* __restrict__ rshift,
                          T* __restrict__ y, long long rows, int C, int relu) {
   constexpr int EPC = Elem<T>::EPC;
-  constexpr int U = 4;
   const int cpr = C / EPC;
   const long long gtid = blockIdx.x * 256ll + threadIdx.x;
   const long long rstride = (gridDim.x * 256ll) / cpr;
@@ -97,8 +104,8 @@ __global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const f
     for (int u = 0; u < U; ++u) {
       const long long rr = r + u * rstride;
       if (rr < rows) {
-        xv[u] = *(const u32x4*)(x + (rr * cpr + cc) * EPC);
-        if (RES) rv[u] = *(const u32x4*)(res + (rr * cpr + cc) * EPC);
+        xv[u] = ldg16<NT>(x + (rr * cpr + cc) * EPC);
+        if (RES) rv[u] = ldg16<NT>(res + (rr * cpr + cc) * EPC);
       }
     }
 #pragma unroll
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const f
           if (RES == 2) o += fmaf(q[e], rsc[e], rsh[e]);
           v[e] = relu ? fmaxf(o, 0.f) : o;
         }
-        *(u32x4*)(y + (rr * cpr + cc) * EPC) = f32_to_chunk<T>(v);
+        stg16<NT>(y + (rr * cpr + cc) * EPC, f32_to_chunk<T>(v));
       }
     }
   }
@@ -225,7 +232,7 @@ __global__ void bn_bwd_finalize(const double* __restrict__ local_sums,
 }
 
 // dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]; one channel chunk per thread, 2 rows in flight
-template <typename T>
+template <typename T, int U, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                              const T* __restrict__ mask_src, const float* __restrict__ scale,
                              const float* __restrict__ shift, const float* __restrict__ mean,
@@ -233,7 +240,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
                              const float* __restrict__ c2, long long rows, int C, int mask_mode,
                              T* __restrict__ dx, T* __restrict__ dmasked) {
   constexpr int EPC = Elem<T>::EPC;
-  constexpr int U = 2;
   const int cpr = C / EPC;
   const long long gtid = blockIdx.x * 256ll + threadIdx.x;
   const long long rstride = (gridDim.x * 256ll) / cpr;
@@ -253,9 +259,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
       const long long rr = r + u * rstride;
       if (rr < rows) {
         const long long i = (rr * cpr + cc) * EPC;
-        dv[u] = *(const u32x4*)(dy + i);
-        xv[u] = *(const u32x4*)(x + i);
-        if (mask_mode == 1) mv[u] = *(const u32x4*)(mask_src + i);
+        dv[u] = ldg16<NT>(dy + i);
+        xv[u] = ldg16<NT>(x + i);
+        if (mask_mode == 1) mv[u] = ldg16<NT>(mask_src + i);
       }
     }
 #pragma unroll
@@ -280,8 +286,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
           const float xh = (xf[e] - mu[e]) * rs[e];
           o[e] = sc[e] * (d[e] - k1[e] - xh * k2[e]);
         }
-        *(u32x4*)(dx + i) = f32_to_chunk<T>(o);
-        if (dmasked) *(u32x4*)(dmasked + i) = f32_to_chunk<T>(d);
+        stg16<NT>(dx + i, f32_to_chunk<T>(o));
+        if (dmasked) stg16<NT>(dmasked + i, f32_to_chunk<T>(d));
       }
     }
   }
@@ -336,16 +342,21 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_apply: C=%d must be a multiple of %d", C, epc);
   SIMCLR_CHECK_ARG(!rscale || res, "bn_apply: rscale needs res");
-  const int grid = grid_rows(rows, C / epc, 4);
+  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 0;   // bit0: non-temporal, bit1: 8 rows in flight
+  const bool nt = (cfg & 1) != 0, u8 = (cfg & 2) != 0;
+  const int grid = grid_rows(rows, C / epc, u8 ? 8 : 4);
   const int mode = res ? (rscale ? 2 : 1) : 0;
-#define LA(TT, RR)                                                                                      \
-  hipLaunchKernelGGL((bn_apply<TT, RR>), dim3(grid), dim3(256), 0, stream, (const TT*)x, scale, shift, \
+#define LA(TT, RR, UU, NN)                                                                                      \
+  hipLaunchKernelGGL((bn_apply<TT, RR, UU, NN>), dim3(grid), dim3(256), 0, stream, (const TT*)x, scale, shift, \
                      (const TT*)res, rscale, rshift, (TT*)y, rows, C, relu)
+#define LB(TT, RR) do { if (u8) { if (nt) LA(TT, RR, 8, true); else LA(TT, RR, 8, false); } \
+                        else { if (nt) LA(TT, RR, 4, true); else LA(TT, RR, 4, false); } } while (0)
   if (dtype == SIMCLR_DT_BF16) {
-    if (mode == 0) LA(uint16_t, 0); else if (mode == 1) LA(uint16_t, 1); else LA(uint16_t, 2);
+    if (mode == 0) LB(uint16_t, 0); else if (mode == 1) LB(uint16_t, 1); else LB(uint16_t, 2);
   } else {
-    if (mode == 0) LA(float, 0); else if (mode == 1) LA(float, 1); else LA(float, 2);
+    if (mode == 0) LA(float, 0, 4, false); else if (mode == 1) LA(float, 1, 4, false); else LA(float, 2, 4, false);
   }
+#undef LB
 #undef LA
   SIMCLR_CHECK_LAUNCH();
   return 0;
@@ -392,15 +403,20 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
                         int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, epc);
-  const int grid = grid_rows(rows, C / epc, 2);
-  if (dtype == SIMCLR_DT_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply<uint16_t>), dim3(grid), dim3(256), 0, stream,
-                       (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)mask_src, scale, shift, mean,
-                       rstd, c1, c2, rows, C, mask_mode, (uint16_t*)dx, (uint16_t*)dmasked);
-  else
-    hipLaunchKernelGGL((bn_bwd_apply<float>), dim3(grid), dim3(256), 0, stream, (const float*)dy,
+  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 0;
+  const bool nt = (cfg & 1) != 0, u4 = (cfg & 2) != 0;
+  const int grid = grid_rows(rows, C / epc, u4 ? 4 : 2);
+#define LBW(UU, NN) hipLaunchKernelGGL((bn_bwd_apply<uint16_t, UU, NN>), dim3(grid), dim3(256), 0, stream, \
+                       (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)mask_src, scale, shift, mean, \
+                       rstd, c1, c2, rows, C, mask_mode, (uint16_t*)dx, (uint16_t*)dmasked)
+  if (dtype == SIMCLR_DT_BF16) {
+    if (u4) { if (nt) LBW(4, true); else LBW(4, false); }
+    else { if (nt) LBW(2, true); else LBW(2, false); }
+  } else
+    hipLaunchKernelGGL((bn_bwd_apply<float, 2, false>), dim3(grid), dim3(256), 0, stream, (const float*)dy,
                        (const float*)x, (const float*)mask_src, scale, shift, mean, rstd, c1, c2, rows, C,
                        mask_mode, (float*)dx, (float*)dmasked);
+#undef LBW
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

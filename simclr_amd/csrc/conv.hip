@@ -1700,7 +1700,8 @@ static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int
   const int nchunks = ceil_div(M, br);
   // ~1024-2048 workgroups in total; a multiple of 8 pixel ranges so that the XCD-aware mapping (one
   // pixel range per XCD at a time) keeps all 8 XCDs equally loaded
-  int splits = max(1, min(nchunks, 1536 / max(1, tiles)));
+  static const int target = getenv("SIMCLR_WGRAD_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD_BLOCKS")) : 1536;
+  int splits = max(1, min(nchunks, target / max(1, tiles)));
   if (nchunks >= 8) splits = min(nchunks / 8 * 8, max(8, (splits + 7) / 8 * 8));
   splits = min(splits, 256);
   *chunks_per_split = ceil_div(nchunks, splits);
