@@ -88,7 +88,8 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
 /* dgrad whose output is the gradient wrt a BatchNormRelu output (tf2/resnet.py:74-78): the ReLU mask and
  * the BatchNorm-backward reductions sum(dm), sum(dm*x^) are fused into the epilogue; dx receives
  * dm = dx*mask.  stats float[nslot][2][Cin] zeroed by the caller.  mask_mode 1: bn_mask>0 (tensor after the
- * ReLU, e.g. the block output of resnet.py:487); 2: bn_x*scale+shift>0.  stride 1 only. */
+ * ReLU, e.g. the block output of resnet.py:487); 2: bn_x*scale+shift>0; 3: bn_mask = the bit tensor written by
+ * simclr_bn_apply(relu_bits) (16x less traffic than mode 1).  stride 1 only. */
 int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumulate, const void* bn_x,
                            const void* bn_mask, const float* bn_scale, const float* bn_shift,
                            const float* bn_mean, const float* bn_rstd, int mask_mode, float* stats, int nslot,
@@ -115,9 +116,13 @@ int simclr_bn_finalize(const double* sums, const float* partial, int nslot, doub
                        const float* gamma, const float* beta, float* moving_mean, float* moving_var,
                        float decay, float eps, float* mean, float* rstd, float* scale, float* shift,
                        simclr_stream_t stream);
+/* y = [relu]( x*scale+shift [+ res | + res*rscale+rshift] ).  relu_bits (nullable): receives the ReLU mask
+ * (y > 0) as one byte per 16-byte chunk of y (bit e = element e of the chunk: 8 channels bf16, 4 channels f32),
+ * i.e. unsigned char [rows][C/8] (bf16) or [rows][C/4] (f32) -- what simclr_conv2d_dgrad_bn mask_mode 3 reads
+ * instead of the whole block output. */
 int simclr_bn_apply(const void* x, const float* scale, const float* shift, const void* res,
-                    const float* rscale, const float* rshift, void* y, long long rows, int C, int relu,
-                    int dtype, simclr_stream_t stream);
+                    const float* rscale, const float* rshift, void* y, unsigned char* relu_bits,
+                    long long rows, int C, int relu, int dtype, simclr_stream_t stream);
 /* mask_mode: 0 none, 1 (mask_src > 0), 2 (x*scale+shift > 0)  -- the ReLU gradient */
 int simclr_bn_bwd_reduce(const void* dy, const void* x, const void* mask_src, const float* scale,
                          const float* shift, const float* mean, const float* rstd, long long rows, int C,

@@ -86,7 +86,8 @@ template <typename T, int RES, int U, bool NT>   // RES: 0 none, 1 plain residua
 __global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const float* __restrict__ scale,
                          const float* __restrict__ shift, const T* __restrict__ res,
                          const float* __restrict__ rscale, const float* __restrict__ rshift,
-                         T* __restrict__ y, long long rows, int C, int relu) {
+                         T* __restrict__ y, long long rows, int C, int relu,
+                         unsigned char* __restrict__ relu_bits) {
   constexpr int EPC = Elem<T>::EPC;
   const int cpr = C / EPC;
   const long long gtid = blockIdx.x * 256ll + threadIdx.x;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const f
         float v[EPC], q[EPC];
         chunk_to_f32<T>(xv[u], v);
         if (RES) chunk_to_f32<T>(rv[u], q);
+        unsigned bits = 0;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
           float o = fmaf(v[e], sc[e], sh[e]);
@@ -122,7 +124,16 @@ __global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const f
           if (RES == 2) o += fmaf(q[e], rsc[e], rsh[e]);
           v[e] = relu ? fmaxf(o, 0.f) : o;
         }
-        stg16<NT>(y + (rr * cpr + cc) * EPC, f32_to_chunk<T>(v));
+        const u32x4 packed = f32_to_chunk<T>(v);
+        stg16<NT>(y + (rr * cpr + cc) * EPC, packed);
+        if (relu_bits) {
+          // bit e = (stored y[e] > 0): the ReLU mask the backward needs, 1 byte per 16-byte chunk
+          float w[EPC];
+          chunk_to_f32<T>(packed, w);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) bits |= (w[e] > 0.f ? 1u : 0u) << e;
+          relu_bits[rr * cpr + cc] = (unsigned char)bits;
+        }
       }
     }
   }
@@ -337,8 +348,8 @@ int simclr_bn_finalize(const double* sums, const float* partial, int nslot, doub
 
 // y = act(x*scale+shift [+ res | + res*rscale+rshift]); rows x C, T = dtype
 int simclr_bn_apply(const void* x, const float* scale, const float* shift, const void* res,
-                    const float* rscale, const float* rshift, void* y, long long rows, int C, int relu,
-                    int dtype, hipStream_t stream) {
+                    const float* rscale, const float* rshift, void* y, unsigned char* relu_bits, long long rows,
+                    int C, int relu, int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_apply: C=%d must be a multiple of %d", C, epc);
   SIMCLR_CHECK_ARG(!rscale || res, "bn_apply: rscale needs res");
@@ -348,7 +359,7 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
   const int mode = res ? (rscale ? 2 : 1) : 0;
 #define LA(TT, RR, UU, NN)                                                                                      \
   hipLaunchKernelGGL((bn_apply<TT, RR, UU, NN>), dim3(grid), dim3(256), 0, stream, (const TT*)x, scale, shift, \
-                     (const TT*)res, rscale, rshift, (TT*)y, rows, C, relu)
+                     (const TT*)res, rscale, rshift, (TT*)y, rows, C, relu, relu_bits)
 #define LB(TT, RR) do { if (u8) { if (nt) LA(TT, RR, 8, true); else LA(TT, RR, 8, false); } \
                         else { if (nt) LA(TT, RR, 4, true); else LA(TT, RR, 4, false); } } while (0)
   if (dtype == SIMCLR_DT_BF16) {

@@ -673,6 +673,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         if (p.bn_mode == 1) {
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_mv[i] = *(const u32x4*)((const uint16_t*)p.bn_mask + eld[i]);
+        } else if (p.bn_mode == 3) {       // one mask byte per 8-channel chunk (written by simclr_bn_apply)
+#pragma unroll
+          for (int i = 0; i < ER; ++i) e_mv[i][0] = ((const unsigned char*)p.bn_mask)[eld[i] >> 3];
         }
       }
 #pragma unroll
@@ -694,6 +697,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
           chunk_to_f32<uint16_t>(e_xv[i], xf);
           if (p.bn_mode == 1) {
             chunk_to_f32<uint16_t>(e_mv[i], mk);
+          } else if (p.bn_mode == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mk[e] = ((e_mv[i][0] >> e) & 1u) ? 1.f : 0.f;
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) mk[e] = fmaf(xf[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
@@ -749,7 +755,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
               xf[0] = __uint_as_float(xv[0] << 16); xf[1] = __uint_as_float(xv[0] & 0xffff0000u);
               xf[2] = __uint_as_float(xv[1] << 16); xf[3] = __uint_as_float(xv[1] & 0xffff0000u);
             }
-            if (p.bn_mode == 1) {
+            if (p.bn_mode == 3) {
+              const unsigned mb = ((const unsigned char*)p.bn_mask)[(off + n) / EPC] >> (n % EPC);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mk[r] = ((mb >> r) & 1u) ? 1.f : 0.f;
+            } else if (p.bn_mode == 1) {
               if (sizeof(T) == 4) {
                 const float4 mv = *(const float4*)((const float*)p.bn_mask + off + n);
                 mk[0] = mv.x; mk[1] = mv.y; mk[2] = mv.z; mk[3] = mv.w;
@@ -1675,9 +1685,9 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   SIMCLR_CHECK_ARG(Cin % 4 == 0, "conv2d_dgrad_bn: Cin=%d must be a multiple of 4", Cin);
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad_bn: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9 && stride == 1, "conv2d_dgrad_bn: stride-1 convolutions with <= 9 taps only");
-  SIMCLR_CHECK_ARG(mask_mode == 1 || mask_mode == 2, "conv2d_dgrad_bn: mask_mode must be 1 or 2");
+  SIMCLR_CHECK_ARG(mask_mode >= 1 && mask_mode <= 3, "conv2d_dgrad_bn: mask_mode must be 1, 2 or 3");
   SIMCLR_CHECK_ARG(bn_x && bn_mean && bn_rstd && stats && nslot > 0, "conv2d_dgrad_bn: null BN argument");
-  SIMCLR_CHECK_ARG(mask_mode != 1 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 needs bn_mask");
+  SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 / 3 need bn_mask");
   SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn: mask_mode 2 needs scale/shift");
   ConvP p = {};
   p.x = dy; p.w = w_d; p.y = dx; p.stats = stats; p.nslot = nslot; p.accumulate = accumulate;

@@ -48,10 +48,14 @@ __global__ void bnrelu_maxpool_fwd(const T* __restrict__ x, const float* __restr
   const long long total = (long long)V * OH * OW * cpr;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cpr);
-    const long long pix = i / cpr;
-    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), v = (int)(pix / ((long long)OW * OH));
+    const unsigned pix = (unsigned)(i / cpr);            // V*OH*OW < 2^31 (checked by the caller)
+    const int cc = (int)(i - (long long)pix * cpr);
+    const unsigned row = pix / (unsigned)OW;
+    const int ox = (int)(pix - row * OW), v = (int)(row / (unsigned)OH), oy = (int)(row - (unsigned)v * OH);
     const int c0 = cc * EPC;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
     float best[EPC];
     int bi[EPC];
 #pragma unroll
@@ -66,14 +70,20 @@ __global__ void bnrelu_maxpool_fwd(const T* __restrict__ x, const float* __restr
         chunk_to_f32<T>(*(const u32x4*)(x + (((long long)v * H + iy) * W + ix) * C + c0), xv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          const float a = fmaxf(fmaf(xv[e], scale[c0 + e], shift[c0 + e]), 0.f);
+          const float a = fmaxf(fmaf(xv[e], sc[e], sh[e]), 0.f);
           if (a > best[e]) { best[e] = a; bi[e] = ky * ksz + kx; }
         }
       }
     }
-    *(u32x4*)(y + pix * C + c0) = f32_to_chunk<T>(best);
+    *(u32x4*)(y + (long long)pix * C + c0) = f32_to_chunk<T>(best);
+    // tap ids of the EPC channels as ONE 4- or 8-byte store
+    uint32_t w[EPC / 4];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) arg[pix * C + c0 + e] = (uint8_t)bi[e];
+    for (int q = 0; q < EPC / 4; ++q)
+      w[q] = (uint32_t)bi[4 * q] | ((uint32_t)bi[4 * q + 1] << 8) | ((uint32_t)bi[4 * q + 2] << 16) | ((uint32_t)bi[4 * q + 3] << 24);
+    uint32_t* ap = (uint32_t*)(arg + (long long)pix * C + c0);
+#pragma unroll
+    for (int q = 0; q < EPC / 4; ++q) ap[q] = w[q];
   }
 }
 
@@ -87,9 +97,10 @@ __global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict_
   const long long total = (long long)V * H * W * cpr;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cpr);
-    const long long pix = i / cpr;
-    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), v = (int)(pix / ((long long)W * H));
+    const unsigned pix = (unsigned)(i / cpr);            // V*H*W < 2^31 (checked by the caller)
+    const int cc = (int)(i - (long long)pix * cpr);
+    const unsigned row = pix / (unsigned)W;
+    const int ix = (int)(pix - row * W), v = (int)(row / (unsigned)H), iy = (int)(row - (unsigned)v * H);
     const int c0 = cc * EPC;
     float acc[EPC];
 #pragma unroll
@@ -107,13 +118,18 @@ __global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict_
         const long long op = (((long long)v * OH + oy) * OW + ox) * C + c0;
         float d[EPC];
         chunk_to_f32<T>(*(const u32x4*)(dy + op), d);
-        const int tapid = ky * ksz + kx;
+        const uint32_t tapid = (uint32_t)(ky * ksz + kx);
+        const uint32_t* ap = (const uint32_t*)(arg + op);       // EPC tap ids: one 4-byte load per 4 channels
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          if (arg[op + e] == tapid) acc[e] += d[e];
+        for (int q = 0; q < EPC / 4; ++q) {
+          const uint32_t w = ap[q];
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (((w >> (8 * b)) & 0xffu) == tapid) acc[4 * q + b] += d[4 * q + b];
+        }
       }
     }
-    *(u32x4*)(dx + pix * C + c0) = f32_to_chunk<T>(acc);
+    *(u32x4*)(dx + (long long)pix * C + c0) = f32_to_chunk<T>(acc);
   }
 }
 
@@ -499,6 +515,7 @@ int simclr_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* sh
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bnrelu_maxpool_fwd: C %% %d != 0", epc);
   SIMCLR_CHECK_ARG(ksz * ksz <= 255, "bnrelu_maxpool_fwd: window too large");
+  SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31) && (long long)V * OH * OW < (1ll << 31), "bnrelu_maxpool_fwd: pixel count overflows int32");
   const long long total = (long long)V * OH * OW * (C / epc);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((bnrelu_maxpool_fwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
@@ -516,6 +533,7 @@ int simclr_maxpool_bwd(const void* dy, const unsigned char* arg, void* dx, int V
                        hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "maxpool_bwd: C %% %d != 0", epc);
+  SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "maxpool_bwd: pixel count overflows int32");
   const long long total = (long long)V * H * W * (C / epc);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((maxpool_bwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,

@@ -326,14 +326,17 @@ def bn_finalize(sums, count, gamma, beta, moving_mean, moving_var, decay, eps=1e
     return mean, rstd, scale, shift
 
 
-def bn_apply(x, scale, shift, relu, res=None, rscale=None, rshift=None, out=None):
+def bn_apply(x, scale, shift, relu, res=None, rscale=None, rshift=None, out=None, want_bits=False):
+    """want_bits: also return the ReLU mask (out > 0) as uint8 [rows, C/epc], one byte per 16-byte chunk
+    (the operand of conv2d_dgrad_bn mode 3)."""
     C = x.shape[-1]
     rows = x.numel() // C
     if out is None:
         out = torch.empty_like(x)
-    lib().bn_apply(_p(x), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift), _p(out), rows, C,
+    bits = torch.empty(rows, C // (16 // x.element_size()), device=x.device, dtype=torch.uint8) if want_bits else None
+    lib().bn_apply(_p(x), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift), _p(out), _p(bits), rows, C,
                    int(relu), dt(x), _s())
-    return out
+    return (out, bits) if want_bits else out
 
 
 def bn_bwd_reduce(dy, x, mask_src, scale, shift, mean, rstd, mask_mode):

@@ -207,13 +207,18 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         self.saved = dict(x=x, mean=mean, rstd=rstd, scale=scale, shift=shift, count=count, y=None, c=inputs.c)
         return scale, shift
 
-    def __call__(self, inputs, training, relu=None, add=None, add_bn=None):
+    def __call__(self, inputs, training, relu=None, add=None, add_bn=None, want_bits=False):
         """BN (+ReLU).  `add` (a tensor) / `add_bn` ((scale, shift) of a projection shortcut) fuse
-        the residual tail relu(bn(x)+shortcut) of resnet.py:382,487 into the same pass."""
+        the residual tail relu(bn(x)+shortcut) of resnet.py:382,487 into the same pass.  want_bits: also
+        keep the ReLU mask as a bit tensor (self.relu_bits) for the fused backward of the tail."""
         relu = self.relu if relu is None else relu
         scale, shift = self.prepare(inputs, training)
         rs, rb = add_bn if add_bn is not None else (None, None)
-        y = ops.bn_apply(inputs.t, scale, shift, relu, res=add, rscale=rs, rshift=rb)
+        self.relu_bits = None
+        if want_bits and relu:
+            y, self.relu_bits = ops.bn_apply(inputs.t, scale, shift, relu, res=add, rscale=rs, rshift=rb, want_bits=True)
+        else:
+            y = ops.bn_apply(inputs.t, scale, shift, relu, res=add, rscale=rs, rshift=rb)
         self.saved['y'] = y
         self.saved['masked'] = bool(relu)
         return Act(y, c=inputs.c)
@@ -224,6 +229,8 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         -> mask from the block output (mode 1)."""
         s = self.saved
         if mask_src is not None:
+            if getattr(self, 'relu_bits', None) is not None:    # 1 bit per element instead of the whole tensor
+                return dict(x=s['x'], mask=self.relu_bits, mean=s['mean'], rstd=s['rstd'], mode=3)
             return dict(x=s['x'], mask=mask_src, mean=s['mean'], rstd=s['rstd'], mode=1)
         assert s.get('masked'), 'fusion_info without mask_src needs a BN+ReLU layer'
         return dict(x=s['x'], scale=s['scale'], shift=s['shift'], mean=s['mean'], rstd=s['rstd'], mode=2)
@@ -495,7 +502,7 @@ class ResidualBlock(Layer):  # tf2/resnet.py:314-382
             sc, sc_bn = inputs.t, None
         h = self.bn1(self.conv1(inputs, training), training)
         h = self.conv2(h, training)
-        out = self.bn2(h, training, relu=True, add=sc, add_bn=sc_bn)     # relu(inputs + shortcut), :382
+        out = self.bn2(h, training, relu=True, add=sc, add_bn=sc_bn, want_bits=training)     # relu(inputs + shortcut), :382
         self.out = out.t
         return out
 
@@ -552,7 +559,7 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         else:
             h = self.bn2(self.conv2(h, training), training)
         h = self.conv3(h, training)
-        out = self.bn3(h, training, relu=True, add=sc, add_bn=sc_bn)     # relu(inputs + shortcut), :487
+        out = self.bn3(h, training, relu=True, add=sc, add_bn=sc_bn, want_bits=training)     # relu(inputs + shortcut), :487
         self.out = out.t
         return out
 

@@ -250,7 +250,7 @@ def check_dgrad_bn(V, H, Cin, Cout, k, dtype, mask_mode, accumulate, seed=0):
     da = xr.grad.permute(0, 2, 3, 1)
     if accumulate:
         da = da + prev.double()
-    if mask_mode == 1:
+    if mask_mode in (1, 3):
         m = mask_t.double() > 0
     else:
         m = (x_raw.float() * scale + shift).double() > 0          # fp32 fma like the kernel
@@ -259,7 +259,14 @@ def check_dgrad_bn(V, H, Cin, Cout, k, dtype, mask_mode, accumulate, seed=0):
     s1 = dm_ref.sum((0, 1, 2)); s2 = (dm_ref * xh).sum((0, 1, 2))
     # device
     w_d = ops.prep_weights(w.float().to(DEV), 1, dtype)
-    bn = dict(x=x_raw.to(DEV), mask=mask_t.to(DEV) if mask_mode == 1 else None, scale=scale.to(DEV),
+    mask_arg = None
+    if mask_mode == 1:
+        mask_arg = mask_t.to(DEV)
+    elif mask_mode == 3:      # one byte per 16-byte chunk, bit e = element e (the layout simclr_bn_apply writes)
+        epc = 8 if dtype == torch.bfloat16 else 4
+        mb = (mask_t > 0).reshape(-1, Cin // epc, epc).to(torch.int32)
+        mask_arg = (mb << torch.arange(epc, dtype=torch.int32)).sum(-1).to(torch.uint8).to(DEV)
+    bn = dict(x=x_raw.to(DEV), mask=mask_arg, scale=scale.to(DEV),
               shift=shift.to(DEV), mean=mean.to(DEV), rstd=rstd.to(DEV), mode=mask_mode)
     out = prev.to(DEV).clone() if accumulate else None
     dm, part = ops.conv2d_dgrad_bn(dy.to(DEV), w_d, k, k, pad, H, H, bn, out=out, accumulate=accumulate)
@@ -349,7 +356,8 @@ def check_bn(rows_shape, C, dtype, relu, residual, seed=0):
     mean_d, rstd_d, scale, shift = ops.bn_finalize(sums, m, gd, bd, mmd, mvd, 0.9)
     rs = torch.full((C,), 1.5, device=DEV) if residual == 'bn' else None
     rb = torch.full((C,), -0.25, device=DEV) if residual == 'bn' else None
-    yd = ops.bn_apply(xd, scale, shift, relu, res=res_t.to(DEV) if residual else None, rscale=rs, rshift=rb)
+    yd, bits = ops.bn_apply(xd, scale, shift, relu, res=res_t.to(DEV) if residual else None, rscale=rs, rshift=rb,
+                            want_bits=True)
     mask_mode = 1 if relu else 0
     dyd = dy.to(DEV)
     p = ops.bn_bwd_reduce(dyd, xd, yd, scale, shift, mean_d, rstd_d, mask_mode)
@@ -367,6 +375,11 @@ def check_bn(rows_shape, C, dtype, relu, residual, seed=0):
            _res('bn_dgamma ' + tag, dgamma, gr.grad, 2e-4 if dtype == torch.float32 else 2e-3),
            _res('bn_dbeta ' + tag, dbeta, br.grad, 2e-4 if dtype == torch.float32 else 2e-3),
            _res('bn_dx ' + tag, dx, xr.grad, 5e-5 if dtype == torch.float32 else 1e-2)]
+    # the ReLU bit tensor must be exactly (stored y > 0), one byte per 16-byte chunk, LSB = first element
+    epc = 8 if dtype == torch.bfloat16 else 4
+    yb = (yd.reshape(-1, C // epc, epc) > 0).to(torch.int32)
+    want_bits = (yb << torch.arange(epc, dtype=torch.int32, device=DEV)).sum(-1).to(torch.uint8)
+    out.append(_res('bn_relu_bits ' + tag, bits.reshape(-1, C // epc).float(), want_bits.float(), 0.0, 0.0))
     if residual == 'identity':
         out.append(_res('bn_dmasked ' + tag, dmask, rr.grad, t))
     if p2 is not None and relu:
