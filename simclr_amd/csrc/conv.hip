@@ -1092,13 +1092,16 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
 // MFMA pipe needed for the chunk's math (profiles/r01_notes.md, tools/diag_conv.py).
 //   BRM: reduction chunk = BRM * 4 * EPC pixels (bf16: 32 / 64, f32: 16 / 32).
 // ------------------------------------------------------------------------------------
-template <typename T, int BKW, int BNW, int BRM, int STAGES>
-__global__ __launch_bounds__(256, (STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2)
+//   WK x WNN waves: 2 x 2 (128 x 128 and smaller tiles, 2-3 workgroups per CU) or 2 x 4 (256 x 256 tile, one
+//   8-wave workgroup per CU: half the L2->LDS bytes per FLOP for the layers whose reduction is short).
+template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2>
+__global__ __launch_bounds__(WK * WNN * 64,
+                             WK * WNN == 8 ? 1 : ((STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
 void conv_wgrad_dma(const WgradP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BR = BRM * 4 * EPC;           // pixels per reduction chunk
-  constexpr int WNN = 2;                      // 2 x 2 waves
-  constexpr int KI = BKW / 2 / 16;            // 16-row fragments per wave along k
+  constexpr int NW = WK * WNN;
+  constexpr int KI = BKW / WK / 16;           // 16-row fragments per wave along k
   constexpr int NI = BNW / WNN / 16;
   constexpr int A_RB = BKW * sizeof(T);       // row bytes
   constexpr int B_RB = BNW * sizeof(T);
@@ -1108,8 +1111,8 @@ void conv_wgrad_dma(const WgradP p) {
   constexpr int B_BLK = B_RB / 32;
   constexpr int A_RPI = 64 / A_CPR;           // pixel rows covered by one wave-wide 1024-byte DMA instruction
   constexpr int B_RPI = 64 / B_CPR;
-  constexpr int AJ = BR / A_RPI / 4;          // DMA instructions per wave per chunk
-  constexpr int BJ = BR / B_RPI / 4;
+  constexpr int AJ = BR / A_RPI / NW;         // DMA instructions per wave per chunk
+  constexpr int BJ = BR / B_RPI / NW;
   static_assert(AJ >= 1 && BJ >= 1 && A_CPR <= 64 && B_CPR <= 64, "tile / chunk configuration");
   constexpr int BUF = BR * (A_RB + B_RB);     // bytes per stage: [A tile | B tile]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1710,7 +1713,9 @@ static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int
   const int nchunks = ceil_div(M, br);
   // ~1024-2048 workgroups in total; a multiple of 8 pixel ranges so that the XCD-aware mapping (one
   // pixel range per XCD at a time) keeps all 8 XCDs equally loaded
-  static const int target = getenv("SIMCLR_WGRAD_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD_BLOCKS")) : 1536;
+  static const int target_env = getenv("SIMCLR_WGRAD_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD_BLOCKS")) : 1536;
+  // 256 x 256 tiles run one 8-wave workgroup per CU: two rounds of 256 instead of three rounds of 512
+  const int target = bkw == 256 ? 512 : target_env;
   int splits = max(1, min(nchunks, target / max(1, tiles)));
   if (nchunks >= 8) splits = min(nchunks / 8 * 8, max(8, (splits + 7) / 8 * 8));
   splits = min(splits, 256);
@@ -1724,16 +1729,30 @@ static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int
   }
   return eff;
 }
-static void wgrad_tile(int Cin, int Cout, int* bkw, int* bnw) {
+static bool wgrad_use_256() {
+#ifdef SIMCLR_DIAG
+  const char* e = getenv("SIMCLR_WGRAD_256");       // per launch: sweeps
+  return !e || atoi(e) != 0;
+#else
+  static const bool on = !getenv("SIMCLR_WGRAD_256") || atoi(getenv("SIMCLR_WGRAD_256")) != 0;
+  return on;
+#endif
+}
+static void wgrad_tile(int Cin, int Cout, int dtype, long long M, int taps, int* bkw, int* bnw) {
   *bkw = (Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : 32);
   *bnw = (Cout % 128 == 0 || Cout > 128) ? 128 : 64;
   if (*bkw == 32) *bnw = 64;
+  // 256 x 256 tile (one 8-wave workgroup per CU, half the L2->LDS bytes per FLOP): measured per layer
+  // (tools/diag_conv.py --wgrad) a win for the long reductions and the 256-channel 3x3 layers, a loss
+  // for the short ones (7x7, 14x14 1x1) where it leaves too few workgroups.
+  if (dtype == SIMCLR_DT_BF16 && Cin % 256 == 0 && Cout % 256 == 0 && wgrad_use_256() &&
+      (M >= 500000 || (taps == 9 && M >= 150000 && Cin == 256))) { *bkw = 256; *bnw = 256; }
 }
 
 size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int Cout, int KH, int KW,
                                            int dtype) {
   int bkw, bnw, cps;
-  wgrad_tile(Cin, Cout, &bkw, &bnw);
+  wgrad_tile(Cin, Cout, dtype, (long long)V * OH * OW, KH * KW, &bkw, &bnw);
   // the bf16 kernel variants reduce in chunks of 64 or 32 pixels: size for whichever needs more slabs
   int splits = wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps);
   splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, 32, &cps));
@@ -1755,7 +1774,8 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = pixpitch;
   p.M = V * OH * OW; p.K = KH * KW * Cin;
   int bkw, bnw;
-  wgrad_tile(Cin, Cout, &bkw, &bnw);
+  wgrad_tile(Cin, Cout, dtype, p.M, KH * KW, &bkw, &bnw);
+  if ((pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0 && bkw == 256) { bkw = 128; bnw = 128; }
   // kernel variant: 1 = LDS-DMA ring, 64-pixel chunks x 2 stages; 2 = 32-pixel chunks x 3 stages for the
   // 128x128 tile (3 workgroups/CU), 3 stages elsewhere; 3 = 32-pixel chunks x 4 stages; 0 = register-staged
   // kernel (kept for A/B runs: SIMCLR_WGRAD_CFG).
@@ -1769,15 +1789,20 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   // the stem's packed input (pixel pitch 4 elements) gives 8-byte-aligned sources: keep the register-staged kernel
   if (bkw == 32 || (pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0) cfg = 0;
   const bool big = bkw == 128 && bnw == 128;
-  const int brm = (cfg >= 2 && big) ? 1 : 2;
-  const int stages = cfg <= 1 ? 2 : (big ? (cfg == 2 ? 3 : 4) : 3);
+  const bool big256 = bkw == 256;
+  if (big256 && cfg == 0) cfg = 1;
+  const int brm = ((cfg >= 2 && big) || big256) ? 1 : 2;
+  const int stages = big256 ? 4 : (cfg <= 1 ? 2 : (big ? (cfg == 2 ? 3 : 4) : 3));
   const int br = (dtype == SIMCLR_DT_BF16 ? 32 : 16) * brm;
   p.splits = wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split);
   p.k_tiles = p.K / bkw;
   p.n_tiles = ceil_div(p.N, bnw);
-  p.xcd_map = (p.M >= 1500000) || (p.M >= 500000 && KH * KW == 1 && stride == 1);
+  // XCD-aware mapping: with the LDS-DMA kernel a win (or neutral) on every ResNet-50 layer; the register-staged
+  // kernel (cfg 0: stem) keeps the old size rule
+  p.xcd_map = cfg != 0 || (p.M >= 1500000) || (p.M >= 500000 && KH * KW == 1 && stride == 1);
 #ifdef SIMCLR_DIAG
   { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
+  { const char* e = getenv("SIMCLR_WGRAD_XCD"); if (e && atoi(e) >= 0) p.xcd_map = atoi(e); }
 #endif
   {
     static void* zero_page = nullptr;
@@ -1790,7 +1815,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   const size_t lds = (size_t)(cfg == 0 ? 2 : stages) * br * (bkw + bnw) * esz;
 #define LW(TT, A, B) hipLaunchKernelGGL((conv_wgrad<TT, A, B>), dim3(grid), dim3(256), lds, stream, p)
 #define LD(TT, A, B, M_, S_) hipLaunchKernelGGL((conv_wgrad_dma<TT, A, B, M_, S_>), dim3(grid), dim3(256), lds, stream, p)
-  if (cfg == 0) {
+  if (big256) {
+    hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 256, 1, 4, 2, 4>), dim3(grid), dim3(512), lds, stream, p);
+  } else if (cfg == 0) {
     if (dtype == SIMCLR_DT_BF16) {
       if (bkw == 128 && bnw == 128) LW(uint16_t, 128, 128);
       else if (bkw == 128) LW(uint16_t, 128, 64);

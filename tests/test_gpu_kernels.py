@@ -77,7 +77,8 @@ def test_lars_vs_oracle(classic, nesterov):
 
 
 CONV_CASES = [(2, 8, 64, 64, 1, 1), (3, 14, 64, 128, 3, 1), (2, 15, 128, 64, 3, 2), (2, 16, 64, 256, 1, 2),
-              (3, 9, 128, 192, 3, 1), (130, 1, 128, 64, 1, 1), (2, 12, 256, 128, 3, 2), (1, 7, 64, 64, 3, 2)]
+              (3, 9, 128, 192, 3, 1), (130, 1, 128, 64, 1, 1), (2, 12, 256, 128, 3, 2), (1, 7, 64, 64, 3, 2),
+              (2, 6, 256, 256, 3, 1), (3, 5, 512, 256, 1, 1), (2, 8, 256, 512, 1, 2)]   # 256 x 256 wgrad tile
 
 
 @pytest.mark.parametrize('dtype', [F32, BF])

@@ -52,8 +52,9 @@ def wgrad_cfg_sweep():
     """Every distinct ResNet-50 conv shape: wgrad time under each kernel variant (SIMCLR_WGRAD_CFG 0..3)."""
     from tools.microbench import R50
     dev, dt, V = 'cuda', torch.bfloat16, 1024
-    tot = [0.0] * 4
-    print('%-26s %8s %8s %8s %8s' % ('wgrad layer', 'cfg0', 'cfg1', 'cfg2', 'cfg3'))
+    variants = [('128 auto', 1, 0, -1), ('128 xcd0', 1, 0, 0), ('128 xcd1', 1, 0, 1), ('256 xcd0', 1, 1, 0), ('256 xcd1', 1, 1, 1)]
+    tot = [0.0] * len(variants)
+    print('%-26s ' % 'wgrad layer' + ' '.join('%9s' % v[0] for v in variants))
     for (H, Cin, Cout, k, s, cnt) in R50:
         pad = (k - 1) // 2
         OH = (H + (k - 1) - k) // s + 1
@@ -61,13 +62,15 @@ def wgrad_cfg_sweep():
         dy = torch.randn(V, OH, OH, Cout, device=dev).to(dt)
         dw = torch.empty(k * k * Cin, Cout, device=dev)
         ts = []
-        for cfg in range(4):
+        for vi, (_, cfg, t256, xcd) in enumerate(variants):
             os.environ['SIMCLR_WGRAD_CFG'] = str(cfg)
+            os.environ['SIMCLR_WGRAD_256'] = str(t256)
+            os.environ['SIMCLR_WGRAD_XCD'] = str(xcd)
             ts.append(timeit(lambda: ops.conv2d_wgrad(x, dy, k, k, s, pad, out=dw)))
-            tot[cfg] += cnt * ts[-1]
-        print('%-26s %8.0f %8.0f %8.0f %8.0f' % ('%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt), *ts), flush=True)
+            tot[vi] += cnt * ts[-1]
+        print('%-26s ' % ('%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt)) + ' '.join('%9.0f' % t for t in ts), flush=True)
         del x, dy
-    os.environ.pop('SIMCLR_WGRAD_CFG')
+    os.environ.pop('SIMCLR_WGRAD_CFG'); os.environ.pop('SIMCLR_WGRAD_256'); os.environ.pop('SIMCLR_WGRAD_XCD')
     print('per-step totals (ms): ' + ' '.join('%.2f' % (t / 1e3) for t in tot), flush=True)
 
 
