@@ -82,8 +82,18 @@ class _Lib:
         full = name if name.startswith('simclr_') else 'simclr_' + name
         fn = getattr(self._dll, full)
         if full in self._int_fns and full not in self._no_check:
+            trace = os.environ.get('SIMCLR_TRACE_SYNC') == '1'    # debugging aid: name + device sync around every call
+
             def checked(*args, _fn=fn, _full=full):
-                rc = _fn(*args)
+                if trace:
+                    import sys
+                    import torch
+                    sys.stderr.write('[simclr] %s %r\n' % (_full, [a if isinstance(a, (int, float)) else '*' for a in args]))
+                    sys.stderr.flush()
+                    rc = _fn(*args)
+                    torch.cuda.synchronize()
+                else:
+                    rc = _fn(*args)
                 if rc != 0:
                     raise SimclrHipError('%s failed (rc=%d): %s' % (_full, rc, self.last_error()))
                 return rc

@@ -71,10 +71,11 @@ __device__ __forceinline__ void load_params(const float* __restrict__ p, int c0,
 }
 
 // y = act(x*scale + shift [+ r] [+ r*rscale + rshift])
-// Every thread owns ONE channel chunk (grid*256 is a multiple of chunks-per-row), so the
-// per-channel parameters are loaded once; rows are walked 4 at a time to keep 4-8 16-byte
-// loads in flight per lane.
-// streaming 16-byte accesses, optionally with the non-temporal cache policy (tensors far larger than L2 + MALL)
+// Streaming shape (tools/probes/bn_probe.hip, profiles/r01_notes.md): every workgroup owns ONE contiguous run
+// of 256*U 16-byte chunks and every thread touches chunk base + u*256 -- a plain linear sweep of memory in
+// dispatch order.  This reaches ~6.2 TB/s (read+write) on MI355X; the former grid-stride walk (a fixed grid
+// striding through the tensor) stalled at ~4.4 TB/s.  U = 2 when 256 is a multiple of the chunks per row
+// (every standard ResNet width), so the per-channel parameters are fetched once per thread; U = 1 otherwise.
 template <bool NT> __device__ __forceinline__ u32x4 ldg16(const void* p) {
   return NT ? __builtin_nontemporal_load((const u32x4*)p) : *(const u32x4*)p;
 }
@@ -86,54 +87,50 @@ template <typename T, int RES, int U, bool NT>   // RES: 0 none, 1 plain residua
 __global__ __launch_bounds__(256) void bn_apply(const T* __restrict__ x, const float* __restrict__ scale,
                          const float* __restrict__ shift, const T* __restrict__ res,
                          const float* __restrict__ rscale, const float* __restrict__ rshift,
-                         T* __restrict__ y, long long rows, int C, int relu,
+                         T* __restrict__ y, long long nchunks, int C, int relu,
                          unsigned char* __restrict__ relu_bits) {
   constexpr int EPC = Elem<T>::EPC;
-  const int cpr = C / EPC;
-  const long long gtid = blockIdx.x * 256ll + threadIdx.x;
-  const long long rstride = (gridDim.x * 256ll) / cpr;
-  const int cc = (int)(gtid % cpr);
-  const int c0 = cc * EPC;
+  const unsigned cpr = (unsigned)(C / EPC);
+  const long long base = (long long)blockIdx.x * (256 * U) + threadIdx.x;
+  u32x4 xv[U], rv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long i = base + u * 256;
+    if (i < nchunks) {
+      xv[u] = ldg16<NT>(x + i * EPC);
+      if (RES) rv[u] = ldg16<NT>(res + i * EPC);
+    }
+  }
+  // U == 2 is only launched when 256 % cpr == 0: both chunks of a thread sit in the same channel chunk
+  const int c0 = (int)((unsigned long long)base % cpr) * EPC;
   float sc[EPC], sh[EPC], rsc[EPC], rsh[EPC];
   load_params<EPC>(scale, c0, sc);
   load_params<EPC>(shift, c0, sh);
   if (RES == 2) { load_params<EPC>(rscale, c0, rsc); load_params<EPC>(rshift, c0, rsh); }
-  long long r = gtid / cpr;
-  for (; r < rows; r += U * rstride) {
-    u32x4 xv[U], rv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long rr = r + u * rstride;
-      if (rr < rows) {
-        xv[u] = ldg16<NT>(x + (rr * cpr + cc) * EPC);
-        if (RES) rv[u] = ldg16<NT>(res + (rr * cpr + cc) * EPC);
+  for (int u = 0; u < U; ++u) {
+    const long long i = base + u * 256;
+    if (i < nchunks) {
+      float v[EPC], q[EPC];
+      chunk_to_f32<T>(xv[u], v);
+      if (RES) chunk_to_f32<T>(rv[u], q);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float o = fmaf(v[e], sc[e], sh[e]);
+        if (RES == 1) o += q[e];
+        if (RES == 2) o += fmaf(q[e], rsc[e], rsh[e]);
+        v[e] = relu ? fmaxf(o, 0.f) : o;
       }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long rr = r + u * rstride;
-      if (rr < rows) {
-        float v[EPC], q[EPC];
-        chunk_to_f32<T>(xv[u], v);
-        if (RES) chunk_to_f32<T>(rv[u], q);
+      const u32x4 packed = f32_to_chunk<T>(v);
+      stg16<NT>(y + i * EPC, packed);
+      if (relu_bits) {
+        // bit e = (stored y[e] > 0): the ReLU mask the backward needs, 1 byte per 16-byte chunk
+        float w[EPC];
+        chunk_to_f32<T>(packed, w);
         unsigned bits = 0;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          float o = fmaf(v[e], sc[e], sh[e]);
-          if (RES == 1) o += q[e];
-          if (RES == 2) o += fmaf(q[e], rsc[e], rsh[e]);
-          v[e] = relu ? fmaxf(o, 0.f) : o;
-        }
-        const u32x4 packed = f32_to_chunk<T>(v);
-        stg16<NT>(y + (rr * cpr + cc) * EPC, packed);
-        if (relu_bits) {
-          // bit e = (stored y[e] > 0): the ReLU mask the backward needs, 1 byte per 16-byte chunk
-          float w[EPC];
-          chunk_to_f32<T>(packed, w);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) bits |= (w[e] > 0.f ? 1u : 0u) << e;
-          relu_bits[rr * cpr + cc] = (unsigned char)bits;
-        }
+        for (int e = 0; e < EPC; ++e) bits |= (w[e] > 0.f ? 1u : 0u) << e;
+        relu_bits[i] = (unsigned char)bits;
       }
     }
   }
@@ -242,20 +239,28 @@ __global__ void bn_bwd_finalize(const double* __restrict__ local_sums,
   c2[c] = (float)(g2 / count);
 }
 
-// dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]; one channel chunk per thread, 2 rows in flight
+// dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]; same block-contiguous streaming shape as bn_apply
 template <typename T, int U, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                              const T* __restrict__ mask_src, const float* __restrict__ scale,
                              const float* __restrict__ shift, const float* __restrict__ mean,
                              const float* __restrict__ rstd, const float* __restrict__ c1,
-                             const float* __restrict__ c2, long long rows, int C, int mask_mode,
+                             const float* __restrict__ c2, long long nchunks, int C, int mask_mode,
                              T* __restrict__ dx, T* __restrict__ dmasked) {
   constexpr int EPC = Elem<T>::EPC;
-  const int cpr = C / EPC;
-  const long long gtid = blockIdx.x * 256ll + threadIdx.x;
-  const long long rstride = (gridDim.x * 256ll) / cpr;
-  const int cc = (int)(gtid % cpr);
-  const int c0 = cc * EPC;
+  const unsigned cpr = (unsigned)(C / EPC);
+  const long long base = (long long)blockIdx.x * (256 * U) + threadIdx.x;
+  u32x4 dv[U], xv[U], mv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long i = base + u * 256;
+    if (i < nchunks) {
+      dv[u] = ldg16<NT>(dy + i * EPC);
+      xv[u] = ldg16<NT>(x + i * EPC);
+      if (mask_mode == 1) mv[u] = ldg16<NT>(mask_src + i * EPC);
+    }
+  }
+  const int c0 = (int)((unsigned long long)base % cpr) * EPC;
   float sc[EPC], sh[EPC], mu[EPC], rs[EPC], k1[EPC], k2[EPC];
   load_params<EPC>(scale, c0, sc);
   load_params<EPC>(mean, c0, mu);
@@ -263,61 +268,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
   load_params<EPC>(c1, c0, k1);
   load_params<EPC>(c2, c0, k2);
   if (mask_mode == 2) load_params<EPC>(shift, c0, sh);
-  for (long long r = gtid / cpr; r < rows; r += U * rstride) {
-    u32x4 dv[U], xv[U], mv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long rr = r + u * rstride;
-      if (rr < rows) {
-        const long long i = (rr * cpr + cc) * EPC;
-        dv[u] = ldg16<NT>(dy + i);
-        xv[u] = ldg16<NT>(x + i);
-        if (mask_mode == 1) mv[u] = ldg16<NT>(mask_src + i);
+  for (int u = 0; u < U; ++u) {
+    const long long i = base + u * 256;
+    if (i < nchunks) {
+      float d[EPC], xf[EPC], o[EPC];
+      chunk_to_f32<T>(dv[u], d);
+      chunk_to_f32<T>(xv[u], xf);
+      if (mask_mode == 1) {
+        float mk[EPC];
+        chunk_to_f32<T>(mv[u], mk);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) d[e] = mk[e] > 0.f ? d[e] : 0.f;
+      } else if (mask_mode == 2) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) d[e] = fmaf(xf[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
       }
-    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long rr = r + u * rstride;
-      if (rr < rows) {
-        const long long i = (rr * cpr + cc) * EPC;
-        float d[EPC], xf[EPC], o[EPC];
-        chunk_to_f32<T>(dv[u], d);
-        chunk_to_f32<T>(xv[u], xf);
-        if (mask_mode == 1) {
-          float mk[EPC];
-          chunk_to_f32<T>(mv[u], mk);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) d[e] = mk[e] > 0.f ? d[e] : 0.f;
-        } else if (mask_mode == 2) {
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) d[e] = fmaf(xf[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          const float xh = (xf[e] - mu[e]) * rs[e];
-          o[e] = sc[e] * (d[e] - k1[e] - xh * k2[e]);
-        }
-        stg16<NT>(dx + i, f32_to_chunk<T>(o));
-        if (dmasked) stg16<NT>(dmasked + i, f32_to_chunk<T>(d));
+      for (int e = 0; e < EPC; ++e) {
+        const float xh = (xf[e] - mu[e]) * rs[e];
+        o[e] = sc[e] * (d[e] - k1[e] - xh * k2[e]);
       }
+      stg16<NT>(dx + i * EPC, f32_to_chunk<T>(o));
+      if (dmasked) stg16<NT>(dmasked + i * EPC, f32_to_chunk<T>(d));
     }
   }
 }
-
-// grid such that grid*256 is a multiple of chunks-per-row (every thread keeps one channel chunk)
-int grid_rows(long long rows, int cpr, int unroll) {
-  int g = 1, t = cpr;
-  // m = cpr / gcd(cpr, 256)
-  int a = cpr, b = 256;
-  while (b) { int q = a % b; a = b; b = q; }
-  const int m = cpr / a;
-  long long want = (rows * cpr + 256ll * unroll - 1) / (256ll * unroll);
-  want = max(1ll, min(want, 4096ll));
-  g = (int)((want + m - 1) / m * m);
-  (void)t;
-  return g;
-}
-
 
 }  // namespace
 
@@ -353,19 +329,26 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_apply: C=%d must be a multiple of %d", C, epc);
   SIMCLR_CHECK_ARG(!rscale || res, "bn_apply: rscale needs res");
-  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 0;   // bit0: non-temporal, bit1: 8 rows in flight
-  const bool nt = (cfg & 1) != 0, u8 = (cfg & 2) != 0;
-  const int grid = grid_rows(rows, C / epc, u8 ? 8 : 4);
+  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 0;   // bit0: non-temporal policy
+  const bool nt = (cfg & 1) != 0;
+  const int cpr = C / epc;
+  const long long nchunks = rows * cpr;
+  const bool two = 256 % cpr == 0 && !(cfg & 2);    // both chunks of a thread in the same channel chunk
+  const long long blocks = (nchunks + (two ? 512 : 256) - 1) / (two ? 512 : 256);
+  SIMCLR_CHECK_ARG(blocks < (1ll << 23), "bn_apply: tensor too large for one launch");
+  const int grid = (int)blocks;
   const int mode = res ? (rscale ? 2 : 1) : 0;
 #define LA(TT, RR, UU, NN)                                                                                      \
   hipLaunchKernelGGL((bn_apply<TT, RR, UU, NN>), dim3(grid), dim3(256), 0, stream, (const TT*)x, scale, shift, \
-                     (const TT*)res, rscale, rshift, (TT*)y, rows, C, relu, relu_bits)
-#define LB(TT, RR) do { if (u8) { if (nt) LA(TT, RR, 8, true); else LA(TT, RR, 8, false); } \
-                        else { if (nt) LA(TT, RR, 4, true); else LA(TT, RR, 4, false); } } while (0)
-  if (dtype == SIMCLR_DT_BF16) {
-    if (mode == 0) LB(uint16_t, 0); else if (mode == 1) LB(uint16_t, 1); else LB(uint16_t, 2);
-  } else {
-    if (mode == 0) LA(float, 0, 4, false); else if (mode == 1) LA(float, 1, 4, false); else LA(float, 2, 4, false);
+                     (const TT*)res, rscale, rshift, (TT*)y, nchunks, C, relu, relu_bits)
+#define LB(TT, RR) do { if (two) { if (nt) LA(TT, RR, 2, true); else LA(TT, RR, 2, false); } \
+                        else { if (nt) LA(TT, RR, 1, true); else LA(TT, RR, 1, false); } } while (0)
+  if (grid > 0) {
+    if (dtype == SIMCLR_DT_BF16) {
+      if (mode == 0) LB(uint16_t, 0); else if (mode == 1) LB(uint16_t, 1); else LB(uint16_t, 2);
+    } else {
+      if (mode == 0) LB(float, 0); else if (mode == 1) LB(float, 1); else LB(float, 2);
+    }
   }
 #undef LB
 #undef LA
@@ -415,18 +398,22 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, epc);
   static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 0;
-  const bool nt = (cfg & 1) != 0, u4 = (cfg & 2) != 0;
-  const int grid = grid_rows(rows, C / epc, u4 ? 4 : 2);
-#define LBW(UU, NN) hipLaunchKernelGGL((bn_bwd_apply<uint16_t, UU, NN>), dim3(grid), dim3(256), 0, stream, \
-                       (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)mask_src, scale, shift, mean, \
-                       rstd, c1, c2, rows, C, mask_mode, (uint16_t*)dx, (uint16_t*)dmasked)
-  if (dtype == SIMCLR_DT_BF16) {
-    if (u4) { if (nt) LBW(4, true); else LBW(4, false); }
-    else { if (nt) LBW(2, true); else LBW(2, false); }
-  } else
-    hipLaunchKernelGGL((bn_bwd_apply<float, 2, false>), dim3(grid), dim3(256), 0, stream, (const float*)dy,
-                       (const float*)x, (const float*)mask_src, scale, shift, mean, rstd, c1, c2, rows, C,
-                       mask_mode, (float*)dx, (float*)dmasked);
+  const bool nt = (cfg & 1) != 0;
+  const int cpr = C / epc;
+  const long long nchunks = rows * cpr;
+  const bool two = 256 % cpr == 0 && !(cfg & 2);
+  const long long blocks = (nchunks + (two ? 512 : 256) - 1) / (two ? 512 : 256);
+  SIMCLR_CHECK_ARG(blocks < (1ll << 23), "bn_bwd_apply: tensor too large for one launch");
+  const int grid = (int)blocks;
+#define LBW(TT, UU, NN) hipLaunchKernelGGL((bn_bwd_apply<TT, UU, NN>), dim3(grid), dim3(256), 0, stream, \
+                       (const TT*)dy, (const TT*)x, (const TT*)mask_src, scale, shift, mean, \
+                       rstd, c1, c2, nchunks, C, mask_mode, (TT*)dx, (TT*)dmasked)
+#define LBX(TT) do { if (two) { if (nt) LBW(TT, 2, true); else LBW(TT, 2, false); } \
+                     else { if (nt) LBW(TT, 1, true); else LBW(TT, 1, false); } } while (0)
+  if (grid > 0) {
+    if (dtype == SIMCLR_DT_BF16) LBX(uint16_t); else LBX(float);
+  }
+#undef LBX
 #undef LBW
   SIMCLR_CHECK_LAUNCH();
   return 0;
