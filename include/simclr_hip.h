@@ -75,6 +75,9 @@ int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long
  * (dgrad), 2: stem [Cout][KHP][KWP][4] zero padded.  CinP/CoutP (0 = none): zero-padded channel dims. */
 int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,
                         int KHP, int KWP, int CinP, int CoutP, int dtype, simclr_stream_t stream);
+/* modes 0 (dst_t) and 1 (dst_d) of the same weight in one launch. */
+int simclr_prep_weights_pair(const float* w_hwio, void* dst_t, void* dst_d, int KH, int KW, int Cin, int Cout,
+                             int CinP, int CoutP, int dtype, simclr_stream_t stream);
 /* y[V,OH,OW,Cout] = conv(x[V,IH,IW,Cin], w), explicit symmetric padding `pad` (resnet.py:167-180).
  * stats (nullable) float[nslot][2][Cout], zeroed by caller: per-channel partial (sum, sum sq) of y
  * for BatchNorm (resnet.py:50-78).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0. */

@@ -1331,15 +1331,26 @@ void conv_wgrad_dma(const WgradP p) {
   }
 }
 
-// dw[i] = sum_s slabs[s][i]  (+ dw[i] if accumulate)
-__global__ void slab_reduce(const float* __restrict__ slabs, int splits, long long numel,
-                            float* __restrict__ out, int accumulate) {
+// dw[i] = sum_s slabs[s][i]  (+ dw[i] if accumulate).  One float4 per thread; the slab loop is unrolled by 8
+// with independent loads so that eight 16-byte requests per lane are in flight (a plain dependent loop keeps
+// one).  Summation order is fixed (s ascending), so the result does not depend on the launch geometry.
+__global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ slabs, int splits, long long numel,
+                                                   float* __restrict__ out, int accumulate) {
   const long long n4 = numel / 4;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < splits; ++s) {
-      const float4 v = *(const float4*)(slabs + (long long)s * numel + i * 4);
+    const float* src = slabs + i * 4;
+    int s = 0;
+    for (; s + 8 <= splits; s += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *(const float4*)(src + (long long)(s + j) * numel);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    for (; s < splits; ++s) {
+      const float4 v = *(const float4*)(src + (long long)s * numel);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     if (accumulate) {
@@ -1504,6 +1515,23 @@ __global__ void prep_weights(const float* __restrict__ w, T* __restrict__ dst, i
       if (kh < KH && kw < KW && ci < CI && co < CO) v = w[(((long long)kh * KW + kw) * CI + ci) * CO + co];
     }
     Elem<T>::st(dst + i, v);
+  }
+}
+
+// both compute copies of one conv weight in one launch: dst_t[co][(tap)*CIP+ci] (fwd) and dst_d[ci][(tap)*COP+co]
+// (dgrad); threads walk the padded (tap, ci, co) index space, co fastest (coalesced source reads and dst_d writes)
+template <typename T>
+__global__ void prep_weights_pair(const float* __restrict__ w, T* __restrict__ dst_t, T* __restrict__ dst_d,
+                                  int taps, int CI, int CO, int CIP, int COP) {
+  const long long total = (long long)taps * CIP * COP;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % COP);
+    const long long r = i / COP;
+    const int ci = (int)(r % CIP), tap = (int)(r / CIP);
+    const float v = (ci < CI && co < CO) ? w[((long long)tap * CI + ci) * CO + co] : 0.f;
+    Elem<T>::st(dst_t + (long long)co * taps * CIP + (long long)tap * CIP + ci, v);
+    Elem<T>::st(dst_d + (long long)ci * taps * COP + (long long)tap * COP + co, v);
   }
 }
 
@@ -1855,7 +1883,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
 #undef LW
   SIMCLR_CHECK_LAUNCH();
   const long long numel = (long long)p.K * p.N;
-  hipLaunchKernelGGL(slab_reduce, dim3(min(2048, ceil_div(numel / 4, 256))), dim3(256), 0, stream,
+  hipLaunchKernelGGL(slab_reduce, dim3(max(1, min(1 << 20, ceil_div(numel / 4, 256)))), dim3(256), 0, stream,
                      (const float*)workspace, p.splits, numel, dw, accumulate);
   SIMCLR_CHECK_LAUNCH();
   return 0;
@@ -1906,6 +1934,25 @@ int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin,
   else
     hipLaunchKernelGGL((prep_weights<float>), dim3(grid), dim3(256), 0, stream, w_hwio, (float*)dst, KH,
                        KW, Cin, Cout, mode, KHP, KWP, CinP, CoutP);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// modes 0 and 1 of simclr_prep_weights for the same weight in ONE launch (one per conv layer and step).
+int simclr_prep_weights_pair(const float* w_hwio, void* dst_t, void* dst_d, int KH, int KW, int Cin, int Cout,
+                             int CinP, int CoutP, int dtype, hipStream_t stream) {
+  if (CinP <= 0) CinP = Cin;
+  if (CoutP <= 0) CoutP = Cout;
+  SIMCLR_CHECK_ARG(CinP >= Cin && CoutP >= Cout, "prep_weights_pair: padded dims smaller than real dims");
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "prep_weights_pair: bad dtype %d", dtype);
+  const long long total = (long long)KH * KW * CinP * CoutP;
+  const int grid = (int)max(1ll, min(1ll << 20, (total + 255) / 256));
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((prep_weights_pair<uint16_t>), dim3(grid), dim3(256), 0, stream, w_hwio, (uint16_t*)dst_t,
+                       (uint16_t*)dst_d, KH * KW, Cin, Cout, CinP, CoutP);
+  else
+    hipLaunchKernelGGL((prep_weights_pair<float>), dim3(grid), dim3(256), 0, stream, w_hwio, (float*)dst_t,
+                       (float*)dst_d, KH * KW, Cin, Cout, CinP, CoutP);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

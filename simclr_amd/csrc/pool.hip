@@ -105,16 +105,15 @@ __global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict_
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    for (int ky = 0; ky < ksz; ++ky) {
-      const int t = iy + pad_t - ky;
-      if (t < 0 || t % stride) continue;
-      const int oy = t / stride;
-      if (oy >= OH) continue;
-      for (int kx = 0; kx < ksz; ++kx) {
-        const int u = ix + pad_l - kx;
-        if (u < 0 || u % stride) continue;
-        const int ox = u / stride;
-        if (ox >= OW) continue;
+    // windows that contain (iy, ix): oy*stride - pad_t <= iy <= oy*stride - pad_t + ksz - 1  (at most
+    // ceil(ksz/stride)^2 of them -- 4 for the 3x3 stride-2 stem pool), enumerated directly
+    const int ty = iy + pad_t, tx = ix + pad_l;
+    const int oy_hi = min(OH - 1, ty / stride), ox_hi = min(OW - 1, tx / stride);
+    const int oy_lo = max(0, (ty - ksz + stride) / stride), ox_lo = max(0, (tx - ksz + stride) / stride);
+    for (int oy = oy_hi; oy >= oy_lo; --oy) {          // ky ascending, kx ascending: fixed summation order
+      const int ky = ty - oy * stride;
+      for (int ox = ox_hi; ox >= ox_lo; --ox) {
+        const int kx = tx - ox * stride;
         const long long op = (((long long)v * OH + oy) * OW + ox) * C + c0;
         float d[EPC];
         chunk_to_f32<T>(*(const u32x4*)(dy + op), d);

@@ -136,6 +136,16 @@ def prep_weights(w_hwio, mode, dtype, khp=0, kwp=0, out=None, cin_p=0, cout_p=0)
     return out
 
 
+def prep_weights_pair(w_hwio, dtype, cin_p=0, cout_p=0):
+    """(w_t [cop, KH*KW*cip], w_d [cip, KH*KW*cop]) -- prep_weights modes 0 and 1 in one launch."""
+    KH, KW, CI, CO = w_hwio.shape
+    cip, cop = cin_p or CI, cout_p or CO
+    w_t = torch.empty(cop, KH * KW * cip, device=w_hwio.device, dtype=dtype)
+    w_d = torch.empty(cip, KH * KW * cop, device=w_hwio.device, dtype=dtype)
+    lib().prep_weights_pair(_p(w_hwio), _p(w_t), _p(w_d), KH, KW, CI, CO, cip, cop, dt(w_t), _s())
+    return w_t, w_d
+
+
 def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None):
     V, IH, IW, Cin = x.shape
     Cout = w_t.shape[0]

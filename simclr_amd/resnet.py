@@ -314,8 +314,7 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         if stem_geo is not None:
             self.w_s = ops.prep_weights(w, 2, RT.dtype, stem_geo['KHP'], stem_geo['KWP'], cout_p=self.cout_p)
         else:
-            self.w_t = ops.prep_weights(w, 0, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
-            self.w_d = ops.prep_weights(w, 1, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
+            self.w_t, self.w_d = ops.prep_weights_pair(w, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
         self._version = RT.weights_version
         self._dtype = RT.dtype
 

@@ -226,6 +226,13 @@ def check_conv(V, H, W, Cin, Cout, k, stride, dtype, seed=0):
            _res('conv_dgrad ' + tag, dx, dx_ref, t),
            _res('conv_dgrad_acc ' + tag, dx2, 2 * dx_ref, 2 * t),
            _res('conv_wgrad ' + tag, dw.view(k, k, Cin, Cout), dw_ref, 2e-5 if dtype == torch.float32 else 1e-4)]
+    # the one-launch pair must be bit-identical to the two single-layout copies (with and without channel padding)
+    for (cip, cop) in [(0, 0), (Cin + 64, Cout + 64)]:
+        pt, pd = ops.prep_weights_pair(wd32, dtype, cin_p=cip, cout_p=cop)
+        rt_ = ops.prep_weights(wd32, 0, dtype, cin_p=cip, cout_p=cop)
+        rd_ = ops.prep_weights(wd32, 1, dtype, cin_p=cip, cout_p=cop)
+        res.append(_res('prep_pair_t pad%d ' % cip + tag, pt.float(), rt_.float(), 0.0))
+        res.append(_res('prep_pair_d pad%d ' % cip + tag, pd.float(), rd_.float(), 0.0))
     return res
 
 
