@@ -1549,6 +1549,13 @@ __global__ void unpack_stem_dw(const float* __restrict__ src, float* __restrict_
   }
 }
 
+// device address of g_zero16 (looked up once); nullptr if the lookup fails -- entry points refuse to launch then
+static const void* zero_page() {
+  static void* zp = nullptr;
+  if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess) zp = nullptr;
+  return zp;
+}
+
 template <typename T, int MODE>
 void launch_igemm_one(ConvP p, hipStream_t stream) {
   const int BN = (p.N <= 64) ? 64 : 128;
@@ -1558,11 +1565,6 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
 #ifdef SIMCLR_DIAG
   { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
 #endif
-  {
-    static void* zero_page = nullptr;
-    if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero16)) != hipSuccess) zero_page = nullptr;
-    p.zero = zero_page;
-  }
   const int grid = ceil_div(p.m_tiles, 8) * 8 * p.n_tiles;
   size_t lds = 2 * (128 + BN) * 128;
   const size_t epi = 128 * (BN * 2 + 8) + 128 * sizeof(long long);
@@ -1668,6 +1670,8 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   SIMCLR_CHECK_ARG(!stats || nslot > 0, "conv2d_fwd: nslot must be > 0 with stats");
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd: at most 9 taps (got %dx%d)", KH, KW);
   ConvP p = {};
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = x; p.w = w_t; p.y = y; p.stats = stats; p.nslot = nslot;
   p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
@@ -1690,6 +1694,8 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9 && stride <= 2, "conv2d_dgrad: at most 9 taps and stride <= 2");
   ConvP p = {};
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = dy; p.w = w_d; p.y = dx; p.stats = nullptr; p.nslot = 1; p.accumulate = accumulate;
   p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cout;
@@ -1721,6 +1727,8 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 / 3 need bn_mask");
   SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn: mask_mode 2 needs scale/shift");
   ConvP p = {};
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = dy; p.w = w_d; p.y = dx; p.stats = stats; p.nslot = nslot; p.accumulate = accumulate;
   p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cout;
@@ -1832,12 +1840,8 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
   { const char* e = getenv("SIMCLR_WGRAD_XCD"); if (e && atoi(e) >= 0) p.xcd_map = atoi(e); }
 #endif
-  {
-    static void* zero_page = nullptr;
-    if (!zero_page && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero16)) != hipSuccess) zero_page = nullptr;
-    SIMCLR_CHECK_ARG(zero_page != nullptr, "conv2d_wgrad: zero page symbol not found");
-    p.zero = zero_page;
-  }
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d_wgrad: zero page symbol not found");
   const int grid = p.k_tiles * p.n_tiles * (p.xcd_map ? ceil_div(p.splits, 8) * 8 : p.splits);
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
   const size_t lds = (size_t)(cfg == 0 ? 2 : stages) * br * (bkw + bnw) * esz;
