@@ -32,6 +32,56 @@ class Mean:
         return float(self._sum.item()) / self._count
 
 
+class Accuracy:
+    """tf.keras.metrics.Accuracy: running mean of (y_true == y_pred) over all samples seen."""
+
+    def __init__(self, name):
+        self.name = name
+        self.reset_states()
+
+    def reset_states(self):
+        self._hits = None
+        self._count = 0
+
+    def update_state(self, y_true, y_pred):
+        h = (y_true.reshape(-1) == y_pred.reshape(-1)).sum().to(torch.float64).reshape(1)
+        self._hits = h if self._hits is None else self._hits + h
+        self._count += y_true.numel()
+
+    def totals(self):
+        """(hits, count) as a fp64 tensor -- what a multi-replica eval all-reduces."""
+        dev = self._hits.device if self._hits is not None else 'cpu'
+        h = self._hits if self._hits is not None else torch.zeros(1, dtype=torch.float64)
+        return torch.cat([h.to(dev), torch.tensor([float(self._count)], dtype=torch.float64, device=dev)])
+
+    def result(self):
+        t = self.totals()
+        return float(t[0].item()) / max(float(t[1].item()), 1.0)
+
+
+class TopKCategoricalAccuracy(Accuracy):
+    """tf.keras.metrics.TopKCategoricalAccuracy(k): one-hot labels, a sample counts when its target class is
+    among the k largest predictions (ties resolved like tf.math.in_top_k: strictly-greater count < k)."""
+
+    def __init__(self, k, name):
+        self.k = k
+        super().__init__(name)
+
+    def update_state(self, y_true, y_pred):
+        target = y_true.argmax(1)
+        tv = y_pred.gather(1, target[:, None])
+        hit = (y_pred > tv).sum(1) < self.k
+        h = hit.sum().to(torch.float64).reshape(1)
+        self._hits = h if self._hits is None else self._hits + h
+        self._count += y_true.shape[0]
+
+
+def update_finetune_metrics_eval(label_top_1_accuracy_metrics, label_top_5_accuracy_metrics, outputs, labels):
+    """tf2/metrics.py:58-62.  outputs: dense logits [b, C]; labels: one-hot [b, C]."""
+    label_top_1_accuracy_metrics.update_state(labels.argmax(1), outputs.argmax(1))
+    label_top_5_accuracy_metrics.update_state(labels, outputs)
+
+
 def update_pretrain_metrics_train(contrast_loss, contrast_acc, contrast_entropy, loss, logits_con, labels_con):
     """Updated pretraining metrics (tf2/metrics.py:23-36).  The accuracy (argmax(labels) ==
     argmax(logits_ab), :28-31) and the entropy of softmax(logits_ab) (:33-35) come fused out of

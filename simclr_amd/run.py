@@ -160,43 +160,162 @@ def init_distributed():
     return Strategy()
 
 
+def json_serializable(val):      # tf2/run.py:340-345
+    try:
+        json.dumps(val)
+        return True
+    except TypeError:
+        return False
+
+
+def synthetic_eval_batches(batch, image_size, num_classes, device, seed=0, pool=2):
+    """Single-view eval batches [b, H, W, 3] + one-hot labels (the eval pipeline feeds one centre crop,
+    tf2/data.py:52-62 with is_training=False)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    feats = [torch.rand(batch, image_size, image_size, 3, generator=g).to(device) for _ in range(pool)]
+    labs = [torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes)
+            .float().to(device) for _ in range(pool)]
+    i = 0
+    while True:
+        yield feats[i % pool], {'labels': labs[i % pool]}
+        i += 1
+
+
+def perform_evaluation(model, data, eval_steps, ckpt, strategy, model_dir=None):
+    """tf2/run.py:348-432: restore `ckpt` (weights + global step), run `eval_steps` batches through
+    model(features, training=False), accumulate eval/label_top_1_accuracy, eval/label_top_5_accuracy and
+    eval/regularization_loss, write result.json, result_<step>.json and flags.json into model_dir.
+    `data`: iterator of (features [b,H,W,3], {'labels': one-hot}).  Returns the result dict (None when skipped)."""
+    from .checkpoint import Checkpoint
+    import os
+    if FLAGS.train_mode == 'pretrain' and not FLAGS.lineareval_while_pretraining:
+        logging.info('Skipping eval during pretraining without linear eval.')          # :350-352
+        return None
+    regularization_loss = metrics.Mean('eval/regularization_loss')
+    label_top_1_accuracy = metrics.Accuracy('eval/label_top_1_accuracy')
+    label_top_5_accuracy = metrics.TopKCategoricalAccuracy(5, 'eval/label_top_5_accuracy')
+    all_metrics = [regularization_loss, label_top_1_accuracy, label_top_5_accuracy]
+    global_step = 0
+    restored = False
+    for i in range(eval_steps):
+        features, labels = next(data)
+        _, supervised_head_outputs = model(features, training=False)                 # :379
+        assert supervised_head_outputs is not None
+        if not restored and ckpt:
+            # variables exist only after the first forward pass (lazy build): restore, then redo this batch
+            logging.info('Restoring from %s', ckpt)
+            c = Checkpoint(model=model)
+            c.restore(ckpt, model_only=False).expect_partial()                       # :369-373
+            global_step = c.global_step
+            restored = True
+            _, supervised_head_outputs = model(features, training=False)
+        restored = True
+        outputs = supervised_head_outputs.dense()
+        l = labels['labels']
+        metrics.update_finetune_metrics_eval(label_top_1_accuracy, label_top_5_accuracy, outputs, l)   # :383-384
+        reg_loss = model_lib.add_weight_decay(model, adjust_per_optimizer=True)      # :385
+        regularization_loss.update_state(reg_loss)
+        logging.info('Completed eval for %d / %d steps', i + 1, eval_steps)
+    # replicas evaluate disjoint shards: the accuracies are ratios of summed counts
+    if strategy is not None and num_replicas(strategy) > 1:
+        for m in (label_top_1_accuracy, label_top_5_accuracy):
+            t = m.totals().to(RT.device)
+            strategy.all_reduce_sum(t)
+            m._hits, m._count = t[:1], float(t[1].item())
+    metrics.log_and_write_metrics_to_summary(all_metrics, global_step)
+    result = {m.name: float(m.result()) for m in all_metrics}
+    result['global_step'] = int(global_step)
+    logging.info(result)
+    if model_dir and (strategy is None or strategy.rank == 0):
+        os.makedirs(model_dir, exist_ok=True)
+        for name in ('result.json', 'result_%d.json' % result['global_step']):       # :410-418
+            with open(os.path.join(model_dir, name), 'w') as f:
+                json.dump({k: float(v) for k, v in result.items()}, f)
+        with open(os.path.join(model_dir, 'flags.json'), 'w') as f:                  # :419-427
+            json.dump({k: v for k, v in FLAGS.flag_values_dict().items() if json_serializable(v)}, f)
+    return result
+
+
 def main(argv):
+    """tf2/run.py:450-664 for --dataset=synthetic: train (with checkpoints every checkpoint_steps /
+    checkpoint_epochs and resume from model_dir), eval, or train_then_eval."""
+    from .checkpoint import try_restore_from_checkpoint
+    import math
     FLAGS.parse(argv)
     logging.basicConfig(level=logging.INFO)
     strategy = init_distributed()
     R = num_replicas(strategy)
+    rank0 = strategy is None or strategy.rank == 0
     if FLAGS.dataset != 'synthetic':
         raise NotImplementedError('only --dataset=synthetic is available offline (no tfds); '
                                   'feed real data through make_single_step from your own pipeline')
     num_classes = 10 if FLAGS.image_size <= 32 else 1000
     num_train_examples = 50000 if FLAGS.image_size <= 32 else 1281167
+    num_eval_examples = 10000 if FLAGS.image_size <= 32 else 50000
     train_steps = model_lib.get_train_steps(num_train_examples)
+    eval_steps = FLAGS.eval_steps or int(math.ceil(num_eval_examples / FLAGS.eval_batch_size))   # :476-478
+    epoch_steps = int(round(num_train_examples / FLAGS.train_batch_size))                     # :479
+    checkpoint_steps = FLAGS.checkpoint_steps or (FLAGS.checkpoint_epochs * epoch_steps)      # :486-487
     RT.reset()
     RT.strategy = strategy
     RT.device = torch.device('cuda', torch.cuda.current_device())
     model = model_lib.Model(num_classes)
+    rep = 0 if strategy is None else strategy.rank
+
+    if FLAGS.mode == 'eval':                                                             # :482-496 (one pass over
+        from .checkpoint import CheckpointManager, Checkpoint                            #  the latest checkpoint)
+        mgr = CheckpointManager(Checkpoint(model=model), FLAGS.model_dir, FLAGS.keep_checkpoint_max)
+        ckpt = FLAGS.checkpoint or mgr.latest_checkpoint
+        data = synthetic_eval_batches(FLAGS.eval_batch_size // R, FLAGS.image_size, num_classes, RT.device, seed=100 + rep)
+        result = perform_evaluation(model, data, eval_steps, ckpt, strategy, FLAGS.model_dir)
+        if rank0:
+            print(json.dumps(result), flush=True)
+        return result
+
     learning_rate = model_lib.WarmUpAndCosineDecay(FLAGS.learning_rate, num_train_examples)
     optimizer = model_lib.build_optimizer(learning_rate)
     step_fn = make_single_step(model, optimizer, strategy)
     per_replica = FLAGS.train_batch_size // R                                   # tf2/data.py:45
-    data = synthetic_batches(per_replica, FLAGS.image_size, num_classes, RT.device,
-                             seed=(0 if strategy is None else strategy.rank))
+    data = synthetic_batches(per_replica, FLAGS.image_size, num_classes, RT.device, seed=rep)
+    manager = None
     log_every = FLAGS.checkpoint_steps or 10
     t0 = time.time()
-    for step in range(train_steps):
+    step = 0
+    while step < train_steps:
         features, labels = next(data)
         step_fn(features, labels)
-        if (step + 1) % log_every == 0:
+        step += 1
+        if manager is None and FLAGS.model_dir:
+            # variables (and LARS slots) exist after the first step: resume now if model_dir holds a checkpoint
+            # (tf2/run.py:520-521); the step just taken is overwritten by the restored state
+            manager, status = try_restore_from_checkpoint(model, optimizer, FLAGS.model_dir, FLAGS.checkpoint,
+                                                          FLAGS.keep_checkpoint_max, FLAGS.zero_init_logits_layer)
+            if status is not None:
+                step = int(optimizer.iterations) if manager.latest_checkpoint else step
+                logging.info('restored; continuing from step %d', step)
+        if step % log_every == 0:
             torch.cuda.synchronize()
             dt = time.time() - t0
             t0 = time.time()
-            if strategy is None or strategy.rank == 0:
+            if rank0:
                 vals = {k: v.result() for k, v in step_fn.metrics.items()}
-                vals.update(step=step + 1, images_per_sec=FLAGS.train_batch_size * log_every / dt,
+                vals.update(step=step, images_per_sec=FLAGS.train_batch_size * log_every / dt,
                             learning_rate=learning_rate(step))
                 print(json.dumps(vals), flush=True)
             for v in step_fn.metrics.values():
                 v.reset_states()
+        if manager is not None and (step % checkpoint_steps == 0 or step == train_steps):   # :640-648 (every steps_per_loop)
+            if rank0:
+                manager.save(step)
+            if strategy is not None:
+                dist.barrier()
+    if FLAGS.mode == 'train_then_eval' and manager is not None:                           # :657-660
+        edata = synthetic_eval_batches(FLAGS.eval_batch_size // R, FLAGS.image_size, num_classes, RT.device, seed=100 + rep)
+        result = perform_evaluation(model, edata, eval_steps, manager.latest_checkpoint, strategy, FLAGS.model_dir)
+        if rank0:
+            print(json.dumps(result), flush=True)
+        return result
+    return None
 
 
 if __name__ == '__main__':

@@ -210,3 +210,9 @@ def test_model_api_shapes_and_errors():
     proj_b, _ = m(x, training=True)
     assert proj_b.shape == (8, 128) and torch.isfinite(proj_b).all()
     FLAGS.reset(); RT.reset()
+
+
+def test_eval_mode_checkpoint_resume_and_perform_evaluation():
+    """eval forward vs oracle, checkpoint -> restore -> identical continuation, eval loop outputs."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_eval_and_checkpoint())
