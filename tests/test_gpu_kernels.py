@@ -88,6 +88,19 @@ def test_conv_fwd_dgrad_wgrad(V, H, Cin, Cout, k, s, dtype):
     _assert(gc.check_conv(V, H, H, Cin, Cout, k, s, dtype))
 
 
+@pytest.mark.parametrize('V,H,Cin,Cout', [(3, 14, 64, 128), (3, 9, 128, 192), (2, 16, 64, 64), (5, 8, 128, 64)])
+def test_conv_wgrad_multitap_3x3(V, H, Cin, Cout):
+    """The opt-in multi-tap 3x3 wgrad kernel (SIMCLR_WGRAD_3X3) forced on:
+    same parity bar as the per-tap kernels."""
+    import os
+    from tests import gpu_checks as gc
+    os.environ['SIMCLR_WGRAD_3X3'] = '1'
+    try:
+        _assert(gc.check_conv(V, H, H, Cin, Cout, 3, 1, BF))
+    finally:
+        os.environ.pop('SIMCLR_WGRAD_3X3')
+
+
 @pytest.mark.parametrize('dtype', [F32, BF])
 @pytest.mark.parametrize('V,H,Cin,Cout,k,mode,acc', [(3, 9, 128, 64, 1, 2, 0), (2, 14, 64, 128, 3, 2, 0),
                                                      (3, 8, 256, 64, 1, 1, 1), (2, 7, 64, 64, 3, 1, 0),
