@@ -104,3 +104,17 @@ def test_model_constructs_on_cpu_and_names_layers():
     with pytest.raises(NotImplementedError):
         model_lib.Model(1000)
     FLAGS.reset(); RT.reset()
+
+
+def test_header_is_plain_c():
+    """include/simclr_hip.h must be consumable by a C compiler (it is what cgo / JNI / ctypes-style bindings read)."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, 'hdr.c')
+        with open(src, 'w') as f:
+            f.write('#include "simclr_hip.h"\nint main(void) { return simclr_abi_version() == 0; }\n')
+        r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(root, 'include'), '-fsyntax-only', src],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
