@@ -177,7 +177,9 @@ int simclr_colsum(const void* x, int rows, int C, int cvalid, float* out, int ac
                   simclr_stream_t stream);
 
 /* ---- small helpers ------------------------------------------------------------------------------ */
+/* dtype hand-over between the fp32 heads / loss and the T-typed encoder (tf2/model.py:262-266) */
 int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out, simclr_stream_t stream);
+/* y += a*x: gradient of the supervised head's L2 term (tf2/model.py:49-60, run.py:609-612) */
 int simclr_axpy_f32(float a, const float* x, float* y, long long n, simclr_stream_t stream);
 int simclr_l2_loss_f32(const float* x, long long n, float* out, simclr_stream_t stream); /* tf.nn.l2_loss, model.py:49-60 */
 
