@@ -107,6 +107,30 @@ def update_finetune_metrics_train(supervised_loss_metric, supervised_acc_metric,
     supervised_acc_metric.update_state(acc)
 
 
+class JsonlSummaryWriter:
+    """Stand-in for tf.summary.create_file_writer(model_dir) (tf2/run.py:356, :526): every scalar becomes one JSON
+    line {"step": s, "tag": name, "value": v} in <model_dir>/summaries.jsonl (TensorBoard-importable, grep-able).
+    Callable as writer(name, value, step) -- the hook log_and_write_metrics_to_summary expects."""
+
+    def __init__(self, model_dir, filename='summaries.jsonl'):
+        import os
+        os.makedirs(model_dir, exist_ok=True)
+        self.path = os.path.join(model_dir, filename)
+        self._f = open(self.path, 'a')
+
+    def scalar(self, name, value, step):
+        import json
+        self._f.write(json.dumps({'step': int(step), 'tag': name, 'value': float(value)}) + '\n')
+
+    __call__ = scalar
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
 def _float_metric_value(metric):
     return float(metric.result())
 

@@ -222,7 +222,10 @@ def perform_evaluation(model, data, eval_steps, ckpt, strategy, model_dir=None):
             t = m.totals().to(RT.device)
             strategy.all_reduce_sum(t)
             m._hits, m._count = t[:1], float(t[1].item())
-    metrics.log_and_write_metrics_to_summary(all_metrics, global_step)
+    writer = metrics.JsonlSummaryWriter(model_dir) if (model_dir and (strategy is None or strategy.rank == 0)) else None
+    metrics.log_and_write_metrics_to_summary(all_metrics, global_step, writer)           # :400-403
+    if writer is not None:
+        writer.close()
     result = {m.name: float(m.result()) for m in all_metrics}
     result['global_step'] = int(global_step)
     logging.info(result)
@@ -278,6 +281,7 @@ def main(argv):
     per_replica = FLAGS.train_batch_size // R                                   # tf2/data.py:45
     data = synthetic_batches(per_replica, FLAGS.image_size, num_classes, RT.device, seed=rep)
     manager = None
+    summary_writer = metrics.JsonlSummaryWriter(FLAGS.model_dir) if (FLAGS.model_dir and rank0) else None   # :526
     log_every = FLAGS.checkpoint_steps or 10
     t0 = time.time()
     step = 0
@@ -302,6 +306,10 @@ def main(argv):
                 vals.update(step=step, images_per_sec=FLAGS.train_batch_size * log_every / dt,
                             learning_rate=learning_rate(step))
                 print(json.dumps(vals), flush=True)
+                if summary_writer is not None:                                              # :645-652
+                    metrics.log_and_write_metrics_to_summary(list(step_fn.metrics.values()), step, summary_writer)
+                    summary_writer.scalar('learning_rate', learning_rate(step), step)
+                    summary_writer.flush()
             for v in step_fn.metrics.values():
                 v.reset_states()
         if manager is not None and (step % checkpoint_steps == 0 or step == train_steps):   # :640-648 (every steps_per_loop)

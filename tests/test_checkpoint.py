@@ -116,3 +116,71 @@ def test_eval_metrics_match_keras_definitions():
     metrics.update_finetune_metrics_eval(top1, top5, logits[:1], labels[:1])
     assert top1.result() == pytest.approx(3 / 5)
     assert top1.totals().tolist() == [3.0, 5.0]
+
+
+def test_jsonl_summary_writer(tmp_path):
+    w = metrics.JsonlSummaryWriter(str(tmp_path / 'run'))
+    m = metrics.Mean('train/contrast_loss')
+    m.update_state(torch.tensor(2.0)); m.update_state(torch.tensor(4.0))
+    metrics.log_and_write_metrics_to_summary([m], 30, w)
+    w.scalar('learning_rate', 0.125, 30)
+    w.close()
+    lines = [json.loads(l) for l in open(os.path.join(str(tmp_path / 'run'), 'summaries.jsonl'))]
+    assert lines == [{'step': 30, 'tag': 'train/contrast_loss', 'value': 3.0}, {'step': 30, 'tag': 'learning_rate', 'value': 0.125}]
+
+
+def test_perform_evaluation_host_logic_with_a_stand_in_model(tmp_path):
+    """tf2/run.py:348-432 without kernels: restore-after-first-batch, metric accumulation, result / flags / summary files."""
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.run import perform_evaluation
+
+    class _Sup:
+        def __init__(self, z):
+            self.z = z
+
+        def dense(self):
+            return self.z
+
+    class _EvalToy(Layer):
+        def __init__(self):
+            self.scale = Variable('toy/scale:0', torch.ones(1), trainable=False)
+
+        def __call__(self, features, training):
+            assert training is False
+            # logits = per-class mean intensity of the image, scaled by a checkpointed variable
+            return None, _Sup(features.mean((1, 2)) * self.scale.value)
+
+    FLAGS.reset()
+    d = str(tmp_path / 'eval')
+    src = _EvalToy()
+    src.scale.value.fill_(-1.0)                     # the checkpoint flips the sign of every logit
+    ck = Checkpoint(model=src)
+    ck.global_step = 42
+    path = CheckpointManager(ck, d).save(42)
+
+    # three "classes" = the three colour channels; label = brightest channel -> after the restore (sign flip) the
+    # model predicts the DARKEST channel, so top-1 is 0 and top-5 (k > classes) is 1
+    g = torch.Generator().manual_seed(0)
+
+    def batches():
+        while True:
+            x = torch.rand(4, 8, 8, 3, generator=g)
+            lab = torch.nn.functional.one_hot(x.mean((1, 2)).argmax(1), 3).float()
+            yield x, {'labels': lab}
+
+    model = _EvalToy()
+    result = perform_evaluation(model, batches(), 3, path, None, model_dir=d)
+    assert float(model.scale.value) == -1.0
+    assert result['global_step'] == 42
+    assert result['eval/label_top_1_accuracy'] == 0.0 and result['eval/label_top_5_accuracy'] == 1.0
+    for f in ('result.json', 'result_42.json', 'flags.json', 'summaries.jsonl'):
+        assert os.path.exists(os.path.join(d, f)), f
+    assert json.load(open(os.path.join(d, 'result.json')))['global_step'] == 42.0
+    tags = [json.loads(l)['tag'] for l in open(os.path.join(d, 'summaries.jsonl'))]
+    assert tags == ['eval/regularization_loss', 'eval/label_top_1_accuracy', 'eval/label_top_5_accuracy']
+    flags = json.load(open(os.path.join(d, 'flags.json')))
+    assert flags['temperature'] == 0.1 and flags['train_mode'] == 'pretrain'
+    # pretraining without the linear-eval head: evaluation is skipped (run.py:350-352)
+    FLAGS.update(lineareval_while_pretraining=False)
+    assert perform_evaluation(model, batches(), 1, path, None, model_dir=d) is None
+    FLAGS.reset()
