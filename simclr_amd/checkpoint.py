@@ -141,27 +141,32 @@ class CheckpointManager:
     def latest_checkpoint(self):
         return self.checkpoints[-1] if self._paths else None
 
-    def save(self, checkpoint_number=None):
-        os.makedirs(self.directory, exist_ok=True)
+    def save(self, checkpoint_number=None, write=True):
+        """write=False (replicas other than 0 of a multi-replica job): only record the new checkpoint in this
+        manager's list, so that `latest_checkpoint` names the same file on every replica; replica 0 writes it."""
         if checkpoint_number is None:
             checkpoint_number = (self.checkpoint.optimizer.iterations if self.checkpoint.optimizer is not None
                                  else self.checkpoint.global_step)
         name = '%s-%d.pt' % (self.checkpoint_name, int(checkpoint_number))
-        self.checkpoint.write(os.path.join(self.directory, name))
+        if write:
+            os.makedirs(self.directory, exist_ok=True)
+            self.checkpoint.write(os.path.join(self.directory, name))
         if name in self._paths:
             self._paths.remove(name)
         self._paths.append(name)
         if self.max_to_keep:
             while len(self._paths) > self.max_to_keep:
                 old = self._paths.pop(0)
-                try:
-                    os.remove(os.path.join(self.directory, old))
-                except FileNotFoundError:
-                    pass
-        tmp = os.path.join(self.directory, INDEX_NAME + '.tmp')
-        with open(tmp, 'w') as f:
-            json.dump({'model_checkpoint_path': self._paths[-1], 'all_model_checkpoint_paths': self._paths}, f)
-        os.replace(tmp, os.path.join(self.directory, INDEX_NAME))
+                if write:
+                    try:
+                        os.remove(os.path.join(self.directory, old))
+                    except FileNotFoundError:
+                        pass
+        if write:
+            tmp = os.path.join(self.directory, INDEX_NAME + '.tmp')
+            with open(tmp, 'w') as f:
+                json.dump({'model_checkpoint_path': self._paths[-1], 'all_model_checkpoint_paths': self._paths}, f)
+            os.replace(tmp, os.path.join(self.directory, INDEX_NAME))
         return os.path.join(self.directory, name)
 
     def restore_or_initialize(self):

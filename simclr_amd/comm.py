@@ -15,44 +15,78 @@ import torch.distributed as dist
 
 
 class Strategy:
-    """Minimal replica context: num_replicas_in_sync, replica id and the collectives."""
+    """Minimal replica context: num_replicas_in_sync, replica id and the collectives.
 
-    def __init__(self, group=None):
+    Three communicators, so that the three kinds of traffic never queue behind each other on one RCCL stream:
+      group       -- collective A (hidden all-gather / reduce-scatter), latency-bound, on the loss critical path;
+      stat_group  -- collective C (SyncBN [2,C] sums), ~100 tiny all-reduces per step on the critical path;
+      grad_group  -- collective B (bucketed gradient all-reduce, tens of MB each), overlapped with the backward.
+    With a single communicator every small statistic all-reduce of the backward pass waits for the bucket that was
+    issued just before it."""
+
+    def __init__(self, group=None, separate_groups=True):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised; use strategy=None for one replica')
         self.group = group
         self.num_replicas_in_sync = dist.get_world_size(group)
         self.replica_id_in_sync_group = dist.get_rank(group)
+        self.stat_group = self.grad_group = group
+        if separate_groups and self.num_replicas_in_sync > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            self.stat_group = dist.new_group(ranks)        # collective: every replica constructs its Strategy
+            self.grad_group = dist.new_group(ranks)
+        self.stat_collectives = 0                          # counters (bench / tests): collectives issued so far
+        self.hidden_collectives = 0
 
     @property
     def rank(self):
         return self.replica_id_in_sync_group
 
     # -- collective A forward: concat of every replica's tensor in replica order
-    def all_gather_concat(self, tensor):
+    def all_gather_concat(self, tensor, async_op=False):
+        """async_op: returns (out, work); the collective runs on the communicator's own stream and `work.wait()`
+        makes the CURRENT stream wait for it -- whatever is enqueued in between overlaps with the transfer."""
         R = self.num_replicas_in_sync
         out = torch.empty((R * tensor.shape[0],) + tuple(tensor.shape[1:]), device=tensor.device,
                           dtype=tensor.dtype)
-        dist.all_gather_into_tensor(out, tensor.contiguous(), group=self.group)
-        return out
+        work = dist.all_gather_into_tensor(out, tensor.contiguous(), group=self.group, async_op=async_op)
+        self.hidden_collectives += 1
+        return (out, work) if async_op else out
 
     # -- collective A backward: SUM over replicas, keep this replica's slot
-    def reduce_scatter_sum(self, tensor):
+    def reduce_scatter_sum(self, tensor, async_op=False):
         R = self.num_replicas_in_sync
         n = tensor.shape[0] // R
         out = torch.empty((n,) + tuple(tensor.shape[1:]), device=tensor.device, dtype=tensor.dtype)
+        self.hidden_collectives += 1
         if dist.get_backend(self.group) == 'nccl':
-            dist.reduce_scatter_tensor(out, tensor.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
-        else:  # gloo has no reduce_scatter: all_reduce + slice (same result)
-            t = tensor.clone()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            out.copy_(t[self.rank * n:(self.rank + 1) * n])
-        return out
+            work = dist.reduce_scatter_tensor(out, tensor.contiguous(), op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=async_op)
+            return (out, work) if async_op else out
+        # gloo has no reduce_scatter: all_reduce + slice (same result)
+        t = tensor.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        out.copy_(t[self.rank * n:(self.rank + 1) * n])
+        return (out, None) if async_op else out
 
-    # -- collectives B and C
+    # -- collective C (SyncBN statistics): its own communicator
     def all_reduce_sum(self, tensor):
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.stat_group)
+        self.stat_collectives += 1
         return tensor
+
+    def all_reduce_sum_many(self, tensors):
+        """ONE all-reduce for several small tensors of one dtype (statistics of BatchNorms whose inputs do not
+        depend on each other, e.g. a projection shortcut's BN and bn1 of the same block)."""
+        if len(tensors) == 1:
+            return [self.all_reduce_sum(tensors[0])]
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        self.all_reduce_sum(flat)
+        out, o = [], 0
+        for t in tensors:
+            out.append(flat[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+        return out
 
 
 def num_replicas(strategy):
@@ -63,24 +97,42 @@ def replica_id(strategy):
     return 0 if strategy is None else strategy.replica_id_in_sync_group
 
 
-def gather_hidden(z_local, strategy):
+def gather_hidden(z_local, strategy, async_op=False):
     """[z1_local; z2_local] ([2n,D]) -> [z1_all; z2_all] ([2N,D]): one all_gather of the fused
-    block (both views together), then a re-layout from replica-major to view-major order."""
+    block (both views together), then a re-layout from replica-major to view-major order.
+    async_op: returns a zero-argument function that waits for the transfer and returns the gathered block."""
     R = num_replicas(strategy)
     if R <= 1:                               # tf2/objective.py:103-104
-        return z_local
+        return (lambda: z_local) if async_op else z_local
     n = z_local.shape[0] // 2
-    g = strategy.all_gather_concat(z_local)  # [R*2n, D] = r0:[z1;z2], r1:[z1;z2], ...
-    g = g.view(R, 2, n, -1).transpose(0, 1).reshape(2 * R * n, -1)
-    return g.contiguous()
+
+    def relayout(g):                         # [R*2n, D] = r0:[z1;z2], r1:[z1;z2], ...
+        return g.view(R, 2, n, -1).transpose(0, 1).reshape(2 * R * n, -1).contiguous()
+    if not async_op:
+        return relayout(strategy.all_gather_concat(z_local))
+    g, work = strategy.all_gather_concat(z_local, async_op=True)
+
+    def finish():
+        if work is not None:
+            work.wait()
+        return relayout(g)
+    return finish
 
 
-def scatter_hidden_grad(dz_all, strategy):
+def scatter_hidden_grad(dz_all, strategy, async_op=False):
     """Transpose of gather_hidden: [2N,D] key-side gradient -> SUM over replicas of the rows that
-    belong to this replica, as [2n,D] (= [dz1_slot; dz2_slot])."""
+    belong to this replica, as [2n,D] (= [dz1_slot; dz2_slot]).  async_op: returns a wait-and-get function."""
     R = num_replicas(strategy)
     if R <= 1:
-        return dz_all
+        return (lambda: dz_all) if async_op else dz_all
     n = dz_all.shape[0] // (2 * R)
     g = dz_all.view(2, R, n, -1).transpose(0, 1).reshape(R * 2 * n, -1).contiguous()
-    return strategy.reduce_scatter_sum(g)    # [2n, D]
+    if not async_op:
+        return strategy.reduce_scatter_sum(g)    # [2n, D]
+    out, work = strategy.reduce_scatter_sum(g, async_op=True)
+
+    def finish():
+        if work is not None:
+            work.wait()
+        return out
+    return finish

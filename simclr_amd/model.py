@@ -73,8 +73,10 @@ class WarmUpAndCosineDecay:
         total_steps = get_train_steps(self.num_examples)
         decay_steps = total_steps - warmup_steps
         # tf.keras.experimental.CosineDecay(scaled_lr, decay_steps)(step - warmup_steps), alpha=0
+        # decay_steps <= 0 (train_steps <= warmup_steps): the reference divides 0/0 here; the decay is then complete
         s = min(max(step - warmup_steps, 0), decay_steps)
-        cosine = scaled_lr * 0.5 * (1.0 + math.cos(math.pi * s / decay_steps))
+        frac = (s / decay_steps) if decay_steps > 0 else 1.0
+        cosine = scaled_lr * 0.5 * (1.0 + math.cos(math.pi * frac))
         return learning_rate if step < warmup_steps else cosine                       # :107-108
 
     def get_config(self):
@@ -267,13 +269,17 @@ class Model(Layer):
             sup_out = self.supervised_head(sup_in, training)                       # stop_gradient, :276-278
         return proj32, sup_out
 
-    def backward(self, d_proj, d_sup=None, on_stage=None):
-        """d_proj: float32 [k*b, proj_out_dim]; d_sup: gradient wrt the supervised logits."""
+    def backward_supervised(self, d_sup):
+        """Backward of the linear-eval head alone (its input is stop_gradient'ed, tf2/model.py:276-277)."""
         if d_sup is not None:
             self.supervised_head.backward(d_sup)
             if 'lars' in FLAGS.optimizer and FLAGS.weight_decay:   # d/dw of add_weight_decay, :49-60
                 k = self.supervised_head.linear_layer.kernel
                 ops.axpy_f32(FLAGS.weight_decay * self._wd_grad_scale, k.value, k.grad)
+
+    def backward(self, d_proj, d_sup=None, on_stage=None):
+        """d_proj: float32 [k*b, proj_out_dim]; d_sup: gradient wrt the supervised logits."""
+        self.backward_supervised(d_sup)
         d = ops.cast(d_proj, RT.dtype) if RT.dtype != torch.float32 else d_proj
         d = self._projection_head.backward(d)
         self.resnet_model.backward(d, on_stage=on_stage)

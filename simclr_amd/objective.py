@@ -18,14 +18,28 @@ LARGE_NUM = 1e9  # tf2/objective.py:24 (kept for reference; the kernel skips the
 
 
 class _Loss:
-    """A scalar loss living on the device, with the hand-written backward attached."""
+    """A scalar loss living on the device, with the hand-written backward attached.
+    backward() = backward_start() + backward_finish(): between the two the caller may enqueue independent work,
+    which then overlaps with the collective the first half launched (the reduce-scatter of the key-side gradient)."""
 
-    def __init__(self, value, backward_fn):
+    def __init__(self, value, backward_fn, start_fn=None, finish_fn=None):
         self.value = value            # 0-d / 1-element float32 device tensor
         self._backward = backward_fn
+        self._start, self._finish = start_fn, finish_fn
 
     def backward(self, grad_scale=1.0):
         return self._backward(grad_scale)
+
+    def backward_start(self, grad_scale=1.0):
+        if self._start is not None:
+            self._start(grad_scale)
+        else:
+            self._pending = self._backward(grad_scale)
+
+    def backward_finish(self):
+        if self._finish is not None:
+            return self._finish()
+        return self._pending
 
     def item(self):
         return float(self.value.item())
@@ -76,7 +90,7 @@ def tpu_cross_replica_concat(tensor, strategy=None):
     return strategy.all_gather_concat(tensor)
 
 
-def add_contrastive_loss(hidden, hidden_norm=True, temperature=1.0, strategy=None):
+def add_contrastive_loss(hidden, hidden_norm=True, temperature=1.0, strategy=None, overlap=None):
     """Compute loss for model (tf2/objective.py:35-89).
 
     Args:
@@ -84,8 +98,10 @@ def add_contrastive_loss(hidden, hidden_norm=True, temperature=1.0, strategy=Non
       hidden_norm: whether or not to use normalization on the hidden vector.
       temperature: a `floating` number for temperature scaling.
       strategy: replica context (simclr_amd.comm.Strategy) or None.
+      overlap: optional zero-argument callable run while the all-gather of the hidden block is in flight
+        (collective A runs on the communicator's side stream; north_star: overlap it with independent work).
     Returns:
-      A loss scalar (with .backward), the logits handle, the labels handle.
+      A loss scalar (with .backward / .backward_start / .backward_finish), the logits handle, the labels handle.
     """
     assert hidden.dtype == torch.float32 and hidden.dim() == 2
     hidden = hidden.contiguous()
@@ -95,28 +111,38 @@ def add_contrastive_loss(hidden, hidden_norm=True, temperature=1.0, strategy=Non
         z, inv = hidden, None
     n = z.shape[0] // 2
     R, rank = num_replicas(strategy), replica_id(strategy)
-    z_all = gather_hidden(z, strategy)                           # :58-61 (collective A)
+    pending = gather_hidden(z, strategy, async_op=True)          # :58-61 (collective A), asynchronous
+    if overlap is not None:
+        overlap()
+    z_all = pending()
     out, row_stats, ws = ops.ntxent_fwd(z, z_all, rank, temperature)
-    state = {'done': False}
+    state = {'done': False, 'dz_local': None, 'slot': None}
 
-    def backward(grad_scale=1.0):
+    def backward_start(grad_scale=1.0):
         dz_local, dz_all = ops.ntxent_bwd(z, z_all, rank, temperature, row_stats, grad_scale, out, ws)
         state['done'] = True
-        if R > 1:
-            dz_slot = scatter_hidden_grad(dz_all, strategy)      # transpose of the concat
-        else:
-            dz_slot = dz_all
+        state['dz_local'] = dz_local
+        state['slot'] = scatter_hidden_grad(dz_all, strategy, async_op=True)   # transpose of the concat, asynchronous
+
+    def backward_finish():
+        dz_local = state['dz_local']
+        dz_slot = state['slot']()
+        state['dz_local'] = state['slot'] = None
         ops.axpy_f32(1.0, dz_slot, dz_local)
         if hidden_norm:
             return ops.l2norm_bwd(z, inv, dz_local)
         return dz_local
+
+    def backward(grad_scale=1.0):
+        backward_start(grad_scale)
+        return backward_finish()
 
     def ensure_entropy():
         if not state['done']:
             ops.ntxent_bwd(z, z_all, rank, temperature, row_stats, 0.0, out, ws)
             state['done'] = True
 
-    loss = _Loss(out[0:1], backward)
+    loss = _Loss(out[0:1], backward, backward_start, backward_finish)
     logits_con = LazyLogits(z, z_all, temperature, out, ensure_entropy)
     labels_con = LazyLabels(n, n * R, rank, z.device)
     loss.normalized = z

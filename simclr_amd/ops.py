@@ -18,35 +18,38 @@ class KernelProfiler:
     stream every kernel here is enqueued on).  Used by bench.py for the roofline object."""
 
     def __init__(self):
-        self.records = []   # (family, flops, bytes, start_event, end_event)
+        self.records = []   # (family, flops, min bytes, as-implemented bytes, start_event, end_event)
 
-    def launch(self, family, flops, nbytes, fn):
+    def launch(self, family, flops, nbytes, impl_bytes, fn):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
         r = fn()
         b.record()
-        self.records.append((family, flops, nbytes, a, b))
+        self.records.append((family, flops, nbytes, impl_bytes, a, b))
         return r
 
     def summary(self):
         out = {}
-        for fam, fl, by, a, b in self.records:
-            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for fam, fl, by, ib, a, b in self.records:
+            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, impl_bytes=0.0))
             d['launches'] += 1
             d['ms'] += a.elapsed_time(b)
             d['flops'] += fl
             d['bytes'] += by
+            d['impl_bytes'] += ib
         return out
 
 
 PROFILER = None
 
 
-def _launch(family, flops, nbytes, fn):
+def _launch(family, flops, nbytes, fn, impl_bytes=None):
+    """nbytes: SURVEY 8(d)'s MINIMUM bytes of the op (every operand read once, the result written once);
+    impl_bytes: what this implementation moves by design (extra operands of fused epilogues), default = nbytes."""
     if PROFILER is None:
         return fn()
-    return PROFILER.launch(family, flops, nbytes, fn)
+    return PROFILER.launch(family, flops, nbytes, nbytes if impl_bytes is None else impl_bytes, fn)
 
 
 def dt(t):
@@ -96,8 +99,9 @@ def ntxent_fwd(z_local, z_all, rank, temperature, ws=None):
         ws = ntxent_workspace(n, N, D, z_local.device)
     out = torch.zeros(4, device=z_local.device, dtype=torch.float32)
     row_stats = torch.empty(2 * n, 2, device=z_local.device, dtype=torch.float32)
-    lib().ntxent_fwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(out), _p(row_stats),
-                     _p(ws), _s())
+    _launch('ntxent_fwd', 8.0 * n * N * D, 4.0 * (2 * n + 2 * N) * D,
+            lambda: lib().ntxent_fwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(out), _p(row_stats),
+                                     _p(ws), _s()))
     return out, row_stats, ws
 
 
@@ -106,8 +110,10 @@ def ntxent_bwd(z_local, z_all, rank, temperature, row_stats, grad_scale, out, ws
     N = z_all.shape[0] // 2
     dz_local = torch.empty_like(z_local)
     dz_all = torch.empty_like(z_all)
-    lib().ntxent_bwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(row_stats),
-                     float(grad_scale), _p(dz_local), _p(dz_all), _p(out), _p(ws), _s())
+    # bytes: the fused forward+backward I/O of SURVEY 8(d): read h_local + h_all, write dH_local + dH_all
+    _launch('ntxent_bwd', 16.0 * n * N * D, 2.0 * (2 * n + 2 * N) * D * 4,
+            lambda: lib().ntxent_bwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(row_stats),
+                                     float(grad_scale), _p(dz_local), _p(dz_all), _p(out), _p(ws), _s()))
     return dz_local, dz_all
 
 
@@ -184,9 +190,9 @@ def conv2d_dgrad_bn(dy, w_d, KH, KW, pad, IH, IW, bn, out=None, accumulate=False
     partial = new_stats(Cin, dy.device)
     K = KH * KW * Cout
     esz = dy.element_size()
-    _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin,
-            esz * (V * OH * OW * Cout + (2 + (bn['mode'] == 1)) * V * IH * IW * Cin + K * Cin),
-            lambda: lib().conv2d_dgrad_bn(_p(dy), _p(w_d), _p(out), int(accumulate), _p(bn['x']), _p(bn.get('mask')),
+    _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + V * IH * IW * Cin + K * Cin),
+            impl_bytes=esz * (V * OH * OW * Cout + (2 + (bn['mode'] == 1) + int(accumulate)) * V * IH * IW * Cin + K * Cin),
+            fn=lambda: lib().conv2d_dgrad_bn(_p(dy), _p(w_d), _p(out), int(accumulate), _p(bn['x']), _p(bn.get('mask')),
                                           _p(bn.get('scale')), _p(bn.get('shift')), _p(bn['mean']), _p(bn['rstd']),
                                           bn['mode'], _p(partial), NSLOT, V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
                                           pad, dt(dy), _s()))

@@ -176,7 +176,18 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         self.moving_variance = Variable(self._base + '/moving_variance:0', self._pmv[:C], False)
 
     def prepare(self, inputs, training):
-        """Statistics -> (mean, rstd, scale, shift); moving-average update when training."""
+        """Statistics -> (mean, rstd, scale, shift); moving-average update when training.  If `prepare_many` already
+        handled this input (statistics exchanged together with another layer's), its result is used."""
+        p = getattr(self, '_prep', None)
+        if p is not None and p[0] is inputs.t:
+            self._prep = None
+            return p[1], p[2]
+        self._prep = None
+        return prepare_many([(self, inputs)], training)[0]
+
+    def _prepare_with(self, inputs, training, sums):
+        """sums: the cross-replica [2,C] fp64 sums (SyncBatchNormalization, :50-60) or None (one replica /
+        global_bn off: the slot reduction is fused into the finalize kernel)."""
         x = inputs.t
         C = x.shape[-1]
         if self.moving_mean is None:
@@ -186,15 +197,12 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         if training:
             if inputs.stats is None:
                 raise NotImplementedError('BatchNormRelu input must come from a conv/dense epilogue')
-            R = num_replicas(RT.strategy)
-            count = rows
-            if FLAGS.global_bn and R > 1:            # SyncBatchNormalization, :50-60
-                sums = ops.bn_reduce_slots(inputs.stats)
-                RT.strategy.all_reduce_sum(sums)
-                count = rows * R
+            if sums is not None:
+                count = rows * num_replicas(RT.strategy)
                 mean, rstd, scale, shift = ops.bn_finalize(sums, count, g, b, self._pmm, self._pmv,
                                                            FLAGS.batch_norm_decay, BATCH_NORM_EPSILON)
-            else:                                    # single replica: slot reduction fused into finalize
+            else:
+                count = rows
                 mean, rstd, scale, shift = ops.bn_finalize(None, count, g, b, self._pmm, self._pmv,
                                                            FLAGS.batch_norm_decay, BATCH_NORM_EPSILON,
                                                            partial=inputs.stats)
@@ -235,11 +243,12 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         assert s.get('masked'), 'fusion_info without mask_src needs a BN+ReLU layer'
         return dict(x=s['x'], scale=s['scale'], shift=s['shift'], mean=s['mean'], rstd=s['rstd'], mode=2)
 
-    def backward_fused(self, dm, partial):
+    def backward_fused(self, dm, partial, coeffs=None):
         """Second half of the backward when the reduce was fused into the producing dgrad: dm is the
-        already-masked gradient, partial the per-channel (sum dm, sum dm*x^) slots."""
+        already-masked gradient, partial the per-channel (sum dm, sum dm*x^) slots.  coeffs: (c1, c2) if
+        `bwd_finalize_many` already exchanged / finalised the sums together with another layer's."""
         s = self.saved
-        c1, c2 = self._bwd_finalize(partial, s['count'])
+        c1, c2 = coeffs if coeffs is not None else self._bwd_finalize(partial, s['count'])
         dx, _ = ops.bn_bwd_apply(dm, s['x'], None, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2, 0)
         self.saved = None
         return dx
@@ -247,17 +256,24 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
     def _bwd_finalize(self, partial, count):
         """partial slots -> (dgamma, dbeta written) and the coefficients c1 = mean(dy), c2 = mean(dy*x^).
         dgamma/dbeta take the LOCAL sums (the gradient all-reduce sums them), c1/c2 the GLOBAL ones."""
+        return bwd_finalize_many([(self, partial)])[0]
+
+    def _bwd_finalize_with(self, partial, local, glob):
         dgamma = self.gamma.ensure_grad() if self.gamma is not None and self.gamma.trainable else None
         dbeta = self.beta.ensure_grad() if self.beta is not None and self.beta.trainable else None
-        R = num_replicas(RT.strategy)
-        if FLAGS.global_bn and R > 1:
-            local = ops.bn_reduce_slots(partial)
-            glob = RT.strategy.all_reduce_sum(local.clone())
+        count = self.saved['count']
+        if local is not None:
             return ops.bn_bwd_finalize(local, glob, count, dgamma, dbeta)
         return ops.bn_bwd_finalize(None, None, count, dgamma, dbeta, partial=partial)
 
-    def backward(self, dy, mask_src=None, mask_mode=None, want_masked=False):
-        """dy: gradient wrt this layer's (activated) output.  Returns (dx, dy_masked)."""
+    def bwd_reduce(self, dy, mask_src=None, mask_mode=0):
+        """First half of the un-fused backward: per-channel (sum dy_m, sum dy_m * x^) partial slots."""
+        s = self.saved
+        return ops.bn_bwd_reduce(dy, s['x'], mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], mask_mode)
+
+    def backward(self, dy, mask_src=None, mask_mode=None, want_masked=False, coeffs=None):
+        """dy: gradient wrt this layer's (activated) output.  Returns (dx, dy_masked).
+        coeffs: (c1, c2) when the reduce + statistic exchange was already done (bwd_reduce + bwd_finalize_many)."""
         s = self.saved
         if mask_mode is None:
             # plain BN+ReLU: the ReLU mask is recomputed from x*scale+shift (exactly (y > 0)),
@@ -265,12 +281,46 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
             mask_mode = 2 if s.get('masked') else 0
             mask_src = None
         x = s['x']
-        part = ops.bn_bwd_reduce(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], mask_mode)
-        c1, c2 = self._bwd_finalize(part, s['count'])
+        if coeffs is None:
+            part = ops.bn_bwd_reduce(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], mask_mode)
+            c1, c2 = self._bwd_finalize(part, s['count'])
+        else:
+            c1, c2 = coeffs
         dx, dmasked = ops.bn_bwd_apply(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2,
                                        mask_mode, want_masked=want_masked)
         self.saved = None
         return dx, dmasked
+
+
+def _sync_bn():
+    return FLAGS.global_bn and num_replicas(RT.strategy) > 1
+
+
+def prepare_many(items, training):
+    """items: [(BatchNormRelu, Act)] whose inputs do not depend on each other (a projection shortcut's BN and bn1 of
+    the same block).  Cross-replica statistics (tf2/resnet.py:50-60) of all of them travel in ONE all-reduce.
+    Returns [(scale, shift)] and leaves each result cached on its layer for the following __call__ / prepare."""
+    sums = [None] * len(items)
+    if training and _sync_bn():
+        sums = RT.strategy.all_reduce_sum_many([ops.bn_reduce_slots(a.stats) for _, a in items])
+    out = []
+    for (bn, a), sm in zip(items, sums):
+        scale, shift = bn._prepare_with(a, training, sm)
+        bn._prep = (a.t, scale, shift)
+        out.append((scale, shift))
+    if len(items) == 1:
+        items[0][0]._prep = None
+    return out
+
+
+def bwd_finalize_many(items):
+    """items: [(BatchNormRelu, partial slots)] of independent backward reductions (a residual tail's BN and the
+    projection shortcut's BN share the same upstream gradient).  One all-reduce for all of them.  Returns [(c1, c2)]."""
+    if _sync_bn():
+        local = [ops.bn_reduce_slots(p) for _, p in items]
+        glob = RT.strategy.all_reduce_sum_many([l.clone() for l in local])
+        return [bn._bwd_finalize_with(p, l, g) for (bn, p), l, g in zip(items, local, glob)]
+    return [bn._bwd_finalize_with(p, None, None) for bn, p in items]
 
 
 # --------------------------------------------------------------------------- convolution
@@ -465,20 +515,54 @@ class _Shortcut(Layer):
                                        data_format=data_format)
         self.bn = BatchNormRelu(relu=False, data_format=data_format)
 
-    def __call__(self, inputs, training):
+    def conv_part(self, inputs, training):
+        """(avg-pool +) 1x1 conv; the BN statistics are exchanged by the caller together with bn1's."""
         if self.resnet_d:
             self._hw = inputs.t.shape[1:3]
             inputs = Act(ops.avgpool2_fwd(inputs.t, self.strides), c=inputs.c)
-        raw = self.conv(inputs, training)
+        return self.conv(inputs, training)
+
+    def __call__(self, inputs, training):
+        raw = self.conv_part(inputs, training)
         scale, shift = self.bn.prepare(raw, training)
         return raw.t, (scale, shift)
 
-    def backward(self, d_sum):
-        d_raw, _ = self.bn.backward(d_sum, mask_mode=0)
+    def backward(self, d_sum, coeffs=None):
+        d_raw, _ = self.bn.backward(d_sum, mask_mode=0, coeffs=coeffs)
         d = self.conv.backward(d_raw)
         if self.resnet_d:
             d = ops.avgpool2_bwd(d, self._hw[0], self._hw[1], self.strides)
         return d
+
+
+def _block_entry(block, inputs, training):
+    """Shortcut conv and conv1 read the same block input: run both, then ONE statistics exchange for the two
+    BatchNorms (SyncBN collective C), then bn1's apply.  Returns (shortcut tensor, shortcut (scale, shift) | None, h1)."""
+    if block.shortcut is None:
+        return inputs.t, None, block.bn1(block.conv1(inputs, training), training)
+    raw_sc = block.shortcut.conv_part(inputs, training)
+    raw1 = block.conv1(inputs, training)
+    (sc_bn, _) = prepare_many([(block.shortcut.bn, raw_sc), (block.bn1, raw1)], training)
+    block.shortcut.bn._prep = None
+    return raw_sc.t, sc_bn, block.bn1(raw1, training)
+
+
+def _block_tail_backward(block, bn_tail, dout, dout_partial):
+    """Backward of relu(bn_tail(h) + shortcut): returns (dh, dx_shortcut_path).  When the tail's reduce arrived fused
+    (dout_partial) and the block has a projection shortcut, the two BatchNorm backward reductions -- same upstream
+    gradient -- share one statistics exchange."""
+    if dout_partial is not None:
+        dsum = dout
+        if block.shortcut is not None:
+            sc_part = block.shortcut.bn.bwd_reduce(dsum, mask_mode=0)
+            co_t, co_s = bwd_finalize_many([(bn_tail, dout_partial), (block.shortcut.bn, sc_part)])
+            dh = bn_tail.backward_fused(dout, dout_partial, coeffs=co_t)
+            return dh, block.shortcut.backward(dsum, coeffs=co_s)
+        dh = bn_tail.backward_fused(dout, dout_partial)
+    else:
+        dh, dsum = bn_tail.backward(dout, mask_src=block.out, mask_mode=1, want_masked=True)
+    dx = block.shortcut.backward(dsum) if block.shortcut is not None else dsum
+    return dh, dx
 
 
 class ResidualBlock(Layer):  # tf2/resnet.py:314-382
@@ -495,11 +579,7 @@ class ResidualBlock(Layer):  # tf2/resnet.py:314-382
             self.bn2 = BatchNormRelu(relu=False, init_zero=True, data_format=data_format)
 
     def __call__(self, inputs, training):
-        if self.shortcut is not None:
-            sc, sc_bn = self.shortcut(inputs, training)
-        else:
-            sc, sc_bn = inputs.t, None
-        h = self.bn1(self.conv1(inputs, training), training)
+        sc, sc_bn, h = _block_entry(self, inputs, training)
         h = self.conv2(h, training)
         out = self.bn2(h, training, relu=True, add=sc, add_bn=sc_bn, want_bits=training)     # relu(inputs + shortcut), :382
         self.out = out.t
@@ -512,12 +592,8 @@ class ResidualBlock(Layer):  # tf2/resnet.py:314-382
         """dout_partial given: dout is already ReLU-masked and the tail BN's reduce is done (fused into
         the next block's dgrad).  prev_tail: tail_info() of the block feeding this one -- its reduce is
         fused into this block's last dgrad.  Returns (dx, partial-or-None)."""
-        if dout_partial is not None:
-            dh, dsum = self.bn2.backward_fused(dout, dout_partial), dout
-        else:
-            dh, dsum = self.bn2.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
+        dh, dx = _block_tail_backward(self, self.bn2, dout, dout_partial)
         self.out = None
-        dx = self.shortcut.backward(dsum) if self.shortcut is not None else dsum
         dm1, part1 = self.conv2.backward(dh, fuse_bn=self.bn1.fusion_info())
         dh1 = self.bn1.backward_fused(dm1, part1)
         if prev_tail is not None and self.conv1.strides == 1:
@@ -548,11 +624,7 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
             self.bn3 = BatchNormRelu(relu=False, init_zero=True, data_format=data_format)
 
     def __call__(self, inputs, training):
-        if self.shortcut is not None:
-            sc, sc_bn = self.shortcut(inputs, training)
-        else:
-            sc, sc_bn = inputs.t, None
-        h = self.bn1(self.conv1(inputs, training), training)
+        sc, sc_bn, h = _block_entry(self, inputs, training)
         if self.sk is not None:
             h = self.sk(h, training)
         else:
@@ -567,12 +639,8 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
 
     def backward(self, dout, dout_partial=None, prev_tail=None):
         """See ResidualBlock.backward.  Returns (dx, partial-or-None)."""
-        if dout_partial is not None:
-            dh3, dsum = self.bn3.backward_fused(dout, dout_partial), dout
-        else:
-            dh3, dsum = self.bn3.backward(dout, mask_src=self.out, mask_mode=1, want_masked=True)
+        dh3, dx = _block_tail_backward(self, self.bn3, dout, dout_partial)
         self.out = None
-        dx = self.shortcut.backward(dsum) if self.shortcut is not None else dsum
         if self.sk is not None:
             dsk = self.conv3.backward(dh3)
             if self.sk.strides == 1:

@@ -70,8 +70,8 @@ class GradSync:
         if idx is None or idx >= len(self.ranges):
             return
         a, b = self.ranges[idx]
-        self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.strategy.group,
-                                          async_op=True))
+        self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM,
+                                          group=getattr(self.strategy, 'grad_group', self.strategy.group), async_op=True))
 
     def wait(self):
         for w in self.works:
@@ -90,14 +90,22 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
         projection_head_outputs, supervised_head_outputs = model(features, training=True)   # :577-578
         R = num_replicas(strategy)
         con_loss = sup_loss = None
+        sup_box = {}
+
+        def supervised_part():
+            if supervised_head_outputs is not None:
+                l = labels['labels'] if isinstance(labels, dict) else labels
+                # labels are reused for both views (tf2/run.py:599-600: l = concat([l, l], 0))
+                sup_box['loss'] = obj_lib.add_supervised_loss(labels=l, logits=supervised_head_outputs)   # :601
         if projection_head_outputs is not None:
             outputs = projection_head_outputs
+            # collective A (all-gather of the hidden block) is in flight while the supervised loss is computed
             con_loss, logits_con, labels_con = obj_lib.add_contrastive_loss(                # :582-586
-                outputs, hidden_norm=FLAGS.hidden_norm, temperature=FLAGS.temperature, strategy=strategy)
-        if supervised_head_outputs is not None:
-            l = labels['labels'] if isinstance(labels, dict) else labels
-            # labels are reused for both views (tf2/run.py:599-600: l = concat([l, l], 0))
-            sup_loss = obj_lib.add_supervised_loss(labels=l, logits=supervised_head_outputs)   # :601
+                outputs, hidden_norm=FLAGS.hidden_norm, temperature=FLAGS.temperature, strategy=strategy,
+                overlap=supervised_part)
+        else:
+            supervised_part()
+        sup_loss = sup_box.get('loss')
         weight_decay = model_lib.add_weight_decay(model, adjust_per_optimizer=True)         # :609-610
 
         # ---- backward of (loss / R): tf2/run.py:617-621 ----
@@ -106,9 +114,14 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
             state['sync'] = GradSync(model, strategy)
         sync = state['sync']
         model._wd_grad_scale = 1.0 / R
-        d_proj = con_loss.backward(1.0 / R) if con_loss is not None else None
+        # NT-Xent backward launches the reduce-scatter of the key-side gradient (transpose of collective A); the
+        # supervised head's backward (independent: stop_gradient, tf2/model.py:276-277) runs while it is in flight
+        if con_loss is not None:
+            con_loss.backward_start(1.0 / R)
         d_sup = sup_loss.backward() if sup_loss is not None else None
-        model.backward(d_proj, d_sup, on_stage=sync.on_stage)
+        model.backward_supervised(d_sup)
+        d_proj = con_loss.backward_finish() if con_loss is not None else None
+        model.backward(d_proj, None, on_stage=sync.on_stage)
         sync.wait()
         optimizer.apply_gradients([(v.grad, v) for v in model._flat_order])                # :622
         RT.weights_version += 1
@@ -283,20 +296,22 @@ def main(argv):
     manager = None
     summary_writer = metrics.JsonlSummaryWriter(FLAGS.model_dir) if (FLAGS.model_dir and rank0) else None   # :526
     log_every = FLAGS.checkpoint_steps or 10
-    t0 = time.time()
     step = 0
+    if FLAGS.model_dir:
+        # Build the variables with a forward-only pass in inference mode (no statistics or moving averages move), then
+        # restore BEFORE step 0 as tf2/run.py:520-521 does: the latest checkpoint of model_dir (weights, BN moving
+        # statistics, LARS slots, step) or, failing that, the weights of --checkpoint (slots stay zero, step 0).
+        model(torch.zeros(2, FLAGS.image_size, FLAGS.image_size, 3, device=RT.device), training=False)
+        manager, status = try_restore_from_checkpoint(model, optimizer, FLAGS.model_dir, FLAGS.checkpoint,
+                                                      FLAGS.keep_checkpoint_max, FLAGS.zero_init_logits_layer)
+        if status is not None and manager.latest_checkpoint:
+            step = int(optimizer.iterations)
+            logging.info('restored %s; continuing from step %d', manager.latest_checkpoint, step)
+    t0 = time.time()
     while step < train_steps:
         features, labels = next(data)
         step_fn(features, labels)
         step += 1
-        if manager is None and FLAGS.model_dir:
-            # variables (and LARS slots) exist after the first step: resume now if model_dir holds a checkpoint
-            # (tf2/run.py:520-521); the step just taken is overwritten by the restored state
-            manager, status = try_restore_from_checkpoint(model, optimizer, FLAGS.model_dir, FLAGS.checkpoint,
-                                                          FLAGS.keep_checkpoint_max, FLAGS.zero_init_logits_layer)
-            if status is not None:
-                step = int(optimizer.iterations) if manager.latest_checkpoint else step
-                logging.info('restored; continuing from step %d', step)
         if step % log_every == 0:
             torch.cuda.synchronize()
             dt = time.time() - t0
@@ -313,8 +328,9 @@ def main(argv):
             for v in step_fn.metrics.values():
                 v.reset_states()
         if manager is not None and (step % checkpoint_steps == 0 or step == train_steps):   # :640-648 (every steps_per_loop)
-            if rank0:
-                manager.save(step)
+            # every replica records the new checkpoint (same name everywhere), replica 0 alone writes it: otherwise
+            # the other replicas' `latest_checkpoint` would still name the resume point in train_then_eval
+            manager.save(step, write=rank0)
             if strategy is not None:
                 dist.barrier()
     if FLAGS.mode == 'train_then_eval' and manager is not None:                           # :657-660

@@ -543,8 +543,12 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
     keys = list(params.keys())
     emu = compute_dtype == 'bf16'
 
-    def entry(name, err, ref_err, floor, cal=CAL, **kw):
+    def entry(name, err, ref_err, floor, cal=CAL, cap=None, **kw):
+        # calibrated tolerance, but never vacuous: `cap` is a fixed upper bound on the gate (gates whose
+        # calibrated tol exceeded 1.0 said nothing); the realistic-batch fixed-threshold gates are in check_train_step_fixed
         tol = cal * ref_err + floor
+        if cap is not None:
+            tol = min(tol, cap)
         d = dict(name=name, err=float(err), tol=float(tol), scale=float(ref_err), ok=bool(err <= tol), nbad=0, numel=1)
         d.update(kw)
         return d
@@ -586,9 +590,10 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
         gm = torch.cat([{v.name: v for v in model._flat_order}[k].grad.double().reshape(-1).cpu() for k in keys])
         cos_m = float((gm * g64).sum() / gm.norm() / g64.norm())
         cos_r = float((g32 * g64).sum() / g32.norm() / g64.norm())
-        res.append(entry('step_grad_1-cos %s%s' % (tag, st), 1 - cos_m, 1 - cos_r, 2e-4 if not emu else 2e-2, cal=8.0))
+        res.append(entry('step_grad_1-cos %s%s' % (tag, st), 1 - cos_m, 1 - cos_r, 2e-4 if not emu else 2e-2, cal=8.0,
+                         cap=5e-3 if not emu else 0.2))
         res.append(entry('step_grad_relnorm %s%s' % (tag, st), float((gm - g64).norm() / g64.norm()),
-                         float((g32 - g64).norm() / g64.norm()), 2e-2 if not emu else 1e-1))
+                         float((g32 - g64).norm() / g64.norm()), 2e-2 if not emu else 1e-1, cap=0.1 if not emu else 0.7))
         # Per-tensor relative errors.  A handful of ReLU pre-activations per step lie within fp32
         # rounding noise of zero; which side they fall on differs between ANY two fp32 evaluations
         # (ours is not even run-to-run deterministic: statistic atomics), and one flipped element is a
@@ -610,8 +615,13 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
                          2e-5 if not emu else 5e-2, cal=8.0))
         res.append(entry('step_grad_tensor_rel_p90 %s%s' % (tag, st), float(em_t.quantile(0.9)), float(er_t.quantile(0.9)),
                          1e-4 if not emu else 1e-1, cal=6.0))
-        res.append(entry('step_grad_worst_tensor_rel %s%s' % (tag, st), worst_m, float(er_t.max()),
-                         0.3 if not emu else 1.0, cal=12.0, worst=wn))
+        # worst single tensor, measured against the GLOBAL gradient norm (an absolute per-tensor bound: one layer being
+        # off by 30 % of its own norm shows up here unless that layer's gradient is negligible for the update)
+        gn64 = float(g64.norm())
+        wt_m = max(float((byname[k].grad.double().cpu() - t64['grads'][k]).norm()) / gn64 for k in keys if t64['grads'][k] is not None)
+        wt_r = max(float((t32['grads'][k].double() - t64['grads'][k]).norm()) / gn64 for k in keys if t64['grads'][k] is not None)
+        res.append(entry('step_grad_worst_tensor_vs_global_norm %s%s' % (tag, st), wt_m, wt_r,
+                         1e-3 if not emu else 5e-2, cal=6.0, cap=5e-2 if not emu else 0.5, worst=wn, worst_rel=worst_m))
         pm_l = torch.tensor([rel(byname[k].value, np64[k]) for k in keys])
         pr_l = torch.tensor([rel(np32[k], np64[k]) for k in keys])
         res.append(entry('step_new_params_rel_median %s%s' % (tag, st), float(pm_l.median()), float(pr_l.median()),
@@ -744,4 +754,277 @@ def check_eval_and_checkpoint(depth=18, image_size=32, batch=8, num_classes=10, 
     _, s3 = model3(xe, training=False)
     torch.cuda.synchronize()
     res.append(_res('eval_after_restore_identical ' + tag, s3.dense(), s2.dense(), 1e-6, 1e-7))
+    return res
+
+
+# ------------------------------------------------------------------ conv at the sizes bench.py runs
+def _guarded(shape, dtype, fill=None):
+    """A tensor with sentinel-filled guard bands on either side (one allocation).  Returns (view, check)
+    where check() -> number of guard elements a kernel overwrote (out-of-bounds WRITES)."""
+    n = 1
+    for s in shape:
+        n *= s
+    band = 4096
+    buf = torch.empty(n + 2 * band, device=DEV, dtype=dtype)
+    sent = 1234.5 if dtype != torch.uint8 else 77
+    buf[:band] = sent
+    buf[band + n:] = sent
+    view = buf[band:band + n].view(*shape)
+    if fill is not None:
+        view.copy_(fill)
+
+    def check():
+        return int((buf[:band] != sent).sum()) + int((buf[band + n:] != sent).sum())
+    return view, check
+
+
+def _ref64_conv(x, w, dy, k, s, pad, OH, OW, vchunk):
+    """Plain-torch float64 reference on the device, chunked over views so the float64 temporaries stay small:
+    y = sum_taps shift(x) @ w[tap] (Conv2dFixedPadding, tf2/resnet.py:183-208), dx / dw = its exact adjoints.
+    Yields per chunk (v0, v1, y64, dx64) and accumulates dw64, sum(y), sum(y^2)."""
+    V, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    w64 = w.double()
+    dw = torch.zeros(k, k, Cin, Cout, device=x.device, dtype=torch.float64)
+    pe = (k - 1) - pad
+    for v0 in range(0, V, vchunk):
+        v1 = min(V, v0 + vchunk)
+        xp = F.pad(x[v0:v1].double(), (0, 0, pad, pe, pad, pe))
+        dyc = dy[v0:v1].double()
+        y = torch.zeros(v1 - v0, OH, OW, Cout, device=x.device, dtype=torch.float64)
+        dxp = torch.zeros_like(xp)
+        for ty in range(k):
+            for tx in range(k):
+                xs = xp[:, ty:ty + s * (OH - 1) + 1:s, tx:tx + s * (OW - 1) + 1:s, :]
+                y += xs @ w64[ty, tx]
+                dxp[:, ty:ty + s * (OH - 1) + 1:s, tx:tx + s * (OW - 1) + 1:s, :] += dyc @ w64[ty, tx].t()
+                dw[ty, tx] += xs.reshape(-1, Cin).t() @ dyc.reshape(-1, Cout)
+        dx = dxp[:, pad:pad + H, pad:pad + W, :]
+        yield v0, v1, y, dx, dw
+
+
+def check_conv_bench_path(V, H, Cin, Cout, k, stride, dtype, seed=0, nsample=4096, bn_case=None):
+    """Forward / dgrad / wgrad (and, for stride 1, the fused dgrad + BN-backward reduce) at BASELINE cfg2 layer
+    shapes with enough rows that every persistent workgroup walks several tiles -- the regime bench.py runs.
+    References: (a) plain-torch float64 on the device over the FULL tensors (incl. dW and the BN sums),
+    (b) float64 on the CPU over `nsample` random output rows, computed independently by gathering patches.
+    bn_case: None | (mask_mode, accumulate) for simclr_conv2d_dgrad_bn."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    pad = (k - 1) // 2
+    OH = (H + (k - 1) - k) // stride + 1
+    OW = OH
+    W = H
+
+    def rnd(shape, scale=1.0):
+        return (torch.randn(shape, device=DEV, generator=g) * scale).to(dtype)
+
+    x = rnd((V, H, W, Cin))
+    w = rnd((k, k, Cin, Cout), (k * k * Cin) ** -0.5)
+    dy = rnd((V, OH, OW, Cout))
+    w32 = w.float()
+    w_t = ops.prep_weights(w32, 0, dtype)
+    w_d = ops.prep_weights(w32, 1, dtype)
+    stats = ops.new_stats(Cout, DEV)
+    y, y_guard = _guarded((V, OH, OW, Cout), dtype)
+    dx, dx_guard = _guarded((V, H, W, Cin), dtype)
+    dw, dw_guard = _guarded((k * k * Cin, Cout), torch.float32)
+    ops.conv2d_fwd(x, w_t, k, k, stride, pad, OH, OW, stats=stats, out=y)
+    sums = ops.bn_reduce_slots(stats)
+    ops.conv2d_dgrad(dy, w_d, k, k, stride, pad, H, W, out=dx)
+    ops.conv2d_wgrad(x, dy, k, k, stride, pad, out=dw)
+    dm = part = None
+    if bn_case is not None:
+        mode, acc = bn_case
+        epc = 8 if dtype == torch.bfloat16 else 4
+        bn_x = rnd((V, H, W, Cin), 1.5) + 0.3
+        scale = torch.rand(Cin, device=DEV, generator=g) - 0.4
+        shift = 0.3 * torch.randn(Cin, device=DEV, generator=g)
+        mean = 0.2 * torch.randn(Cin, device=DEV, generator=g)
+        rstd = 0.5 + torch.rand(Cin, device=DEV, generator=g)
+        prev = rnd((V, H, W, Cin)) if acc else None
+        mask_t = rnd((V, H, W, Cin)) if mode in (1, 3) else None
+        mask_arg = mask_t
+        if mode == 3:
+            mb = (mask_t > 0).reshape(-1, Cin // epc, epc).to(torch.int32)
+            mask_arg = (mb << torch.arange(epc, dtype=torch.int32, device=DEV)).sum(-1).to(torch.uint8)
+        dm, dm_guard = _guarded((V, H, W, Cin), dtype, fill=prev)
+        bn = dict(x=bn_x, mask=mask_arg, scale=scale, shift=shift, mean=mean, rstd=rstd, mode=mode)
+        _, part = ops.conv2d_dgrad_bn(dy, w_d, k, k, pad, H, W, bn, out=dm, accumulate=acc)
+        bsum = ops.bn_reduce_slots(part)
+    torch.cuda.synchronize()
+
+    tag = 'V%d %dx%d %d->%d k%d s%d %s' % (V, H, W, Cin, Cout, k, stride, str(dtype).split('.')[-1])
+    t = _tol(dtype)
+    res = []
+    oob = y_guard() + dx_guard() + dw_guard() + (dm_guard() if dm is not None else 0)
+    res.append(dict(name='bigconv_guard_bands ' + tag, err=float(oob), tol=0.0, scale=0.0, ok=oob == 0, nbad=oob, numel=4))
+
+    # ---- (a) full tensors vs float64 torch on the device
+    vchunk = max(1, min(V, int(3e8 // (H * W * max(Cin, Cout) * max(1, k * k // 3)))))
+    e_y = e_dx = e_dm = 0.0
+    m_y = m_dx = m_dm = 0.0
+    s1 = torch.zeros(Cout, device=DEV, dtype=torch.float64)
+    s2 = torch.zeros_like(s1)
+    b1 = torch.zeros(Cin, device=DEV, dtype=torch.float64)
+    b2 = torch.zeros_like(b1)
+    l1 = torch.zeros_like(b1)
+    dw64 = None
+    for v0, v1, y64, dx64, dw64 in _ref64_conv(x, w, dy, k, stride, pad, OH, OW, vchunk):
+        e_y = max(e_y, float((y[v0:v1].double() - y64).abs().max())); m_y = max(m_y, float(y64.abs().max()))
+        e_dx = max(e_dx, float((dx[v0:v1].double() - dx64).abs().max())); m_dx = max(m_dx, float(dx64.abs().max()))
+        s1 += y64.sum((0, 1, 2)); s2 += (y64 * y64).sum((0, 1, 2))
+        if dm is not None:
+            da = dx64 + (prev[v0:v1].double() if acc else 0.0)
+            if mode in (1, 3):
+                mk = mask_t[v0:v1] > 0
+            else:   # the kernel's fmaf(x, scale, shift) > 0: the exact sign, which float64 arithmetic reproduces
+                mk = (bn_x[v0:v1].double() * scale.double() + shift.double()) > 0
+            dmr = torch.where(mk, da, torch.zeros((), device=DEV, dtype=torch.float64))
+            xh = (bn_x[v0:v1].double() - mean.double()) * rstd.double()
+            b1 += dmr.sum((0, 1, 2)); b2 += (dmr * xh).sum((0, 1, 2)); l1 += (dmr * xh).abs().sum((0, 1, 2)) + dmr.abs().sum((0, 1, 2))
+            e_dm = max(e_dm, float((dm[v0:v1].double() - dmr).abs().max())); m_dm = max(m_dm, float(dmr.abs().max()))
+        del y64, dx64
+
+    def ent(name, err, scale, rtol, atol=0.0):
+        tol = rtol * scale + atol
+        return dict(name=name + ' ' + tag, err=float(err), tol=float(tol), scale=float(scale), ok=bool(err <= tol), nbad=0, numel=1)
+
+    res.append(ent('bigconv_fwd_full', e_y, m_y, t))
+    res.append(ent('bigconv_dgrad_full', e_dx, m_dx, t))
+    sum_tol = 1e-5 if dtype == torch.float32 else 1e-4     # relative to the L1 mass of the summed terms
+    res.append(ent('bigconv_stats_sum', float((sums[0] - s1).abs().max()), float(s2.max()) ** 0.5 * (V * OH * OW) ** 0.5, sum_tol))
+    res.append(ent('bigconv_stats_sq', float((sums[1] - s2).abs().max()), float(s2.max()), sum_tol))
+    res.append(ent('bigconv_wgrad_full', float((dw.view(k, k, Cin, Cout).double() - dw64).abs().max()), float(dw64.abs().max()),
+                   2e-5 if dtype == torch.float32 else 1e-4))
+    if dm is not None:
+        btag = ' mode%d acc%d' % (mode, acc)
+        res.append(ent('bigconv_dgrad_bn_dm' + btag, e_dm, m_dm, t * (2 if acc else 1)))
+        res.append(ent('bigconv_dgrad_bn_sum' + btag, float((bsum[0] - b1).abs().max()), float(l1.max()), sum_tol))
+        res.append(ent('bigconv_dgrad_bn_sumxhat' + btag, float((bsum[1] - b2).abs().max()), float(l1.max()), sum_tol))
+
+    # ---- (b) sampled rows vs float64 on the CPU (independent gather formulation)
+    gs = torch.Generator().manual_seed(seed + 99)
+    wc = w.double().cpu()
+    # forward: output pixel (v, oy, ox) <- patch of x
+    mo = torch.randint(0, V * OH * OW, (nsample,), generator=gs)
+    vv, rem = mo // (OH * OW), mo % (OH * OW)
+    oy, ox = rem // OW, rem % OW
+    patch = torch.zeros(nsample, k, k, Cin, dtype=torch.float64)
+    xc = None
+    for ty in range(k):
+        for tx in range(k):
+            iy, ix = oy * stride - pad + ty, ox * stride - pad + tx
+            ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W)
+            idx = ((vv * H + iy.clamp(0, H - 1)) * W + ix.clamp(0, W - 1)).to(DEV)
+            rows = x.view(-1, Cin)[idx].double().cpu()
+            patch[:, ty, tx] = torch.where(ok[:, None], rows, torch.zeros((), dtype=torch.float64))
+    y_cpu = torch.einsum('nabc,abcd->nd', patch, wc)
+    y_got = y.view(-1, Cout)[mo.to(DEV)].double().cpu()
+    res.append(_res('bigconv_fwd_cpu_rows ' + tag, y_got, y_cpu, t))
+    # dgrad: input pixel (v, iy, ix) <- every (tap, output pixel) that read it
+    mi = torch.randint(0, V * H * W, (nsample,), generator=gs)
+    vv, rem = mi // (H * W), mi % (H * W)
+    iy, ix = rem // W, rem % W
+    dx_cpu = torch.zeros(nsample, Cin, dtype=torch.float64)
+    for ty in range(k):
+        for tx in range(k):
+            ny, nx = iy + pad - ty, ix + pad - tx
+            ok = (ny >= 0) & (nx >= 0) & (ny % stride == 0) & (nx % stride == 0)
+            qy, qx = ny // stride, nx // stride
+            ok = ok & (qy < OH) & (qx < OW)
+            idx = ((vv * OH + qy.clamp(0, OH - 1)) * OW + qx.clamp(0, OW - 1)).to(DEV)
+            rows = dy.view(-1, Cout)[idx].double().cpu()
+            rows = torch.where(ok[:, None], rows, torch.zeros((), dtype=torch.float64))
+            dx_cpu += rows @ wc[ty, tx].t()
+    dx_got = dx.view(-1, Cin)[mi.to(DEV)].double().cpu()
+    res.append(_res('bigconv_dgrad_cpu_rows ' + tag, dx_got, dx_cpu, t))
+    return res
+
+
+_STEP_ORACLE_CACHE = {}
+
+
+def check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f32', num_classes=1000, seed=0,
+                           weight_decay=1e-6, lr=0.1):
+    """One full pretraining step at a realistic batch (BatchNorm well conditioned) with the reference
+    initialisation, against the float64 oracle, gated by FIXED thresholds (no calibration):
+      f32 : BASELINE.json north_star -- loss <= 1e-3 rel, normalised embeddings <= 1e-5 abs; plus gradient
+            1-cos <= 1e-6, every gradient tensor within 1e-3 of the GLOBAL gradient norm, new weights <= 1e-5 rel.
+      bf16: loss <= 1e-2 rel, gradient 1-cos <= 1e-2, embeddings reported and bounded at 5e-2 abs.
+    The oracle step is computed once per configuration and shared by the f32 and bf16 cases."""
+    from collections import OrderedDict
+    from oracle.model_torch import Config, init_model, train_step
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    from simclr_amd.run import make_single_step
+
+    key = (depth, image_size, batch, num_classes, seed, weight_decay, lr)
+    if key not in _STEP_ORACLE_CACHE:
+        cfg = Config(resnet_depth=depth, image_size=image_size, num_classes=num_classes, weight_decay=weight_decay)
+        params, state = init_model(cfg, seed=seed, randomize_bn=False)
+        momenta = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+        g = torch.Generator().manual_seed(seed + 1)
+        images = torch.rand(batch, image_size, image_size, 6, generator=g)
+        labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes).float()
+        p64 = OrderedDict((k, v.double()) for k, v in params.items())
+        s64 = OrderedDict((k, v.double()) for k, v in state.items())
+        m64 = OrderedDict((k, v.double()) for k, v in momenta.items())
+        np64, ns64, nm64, t64 = train_step(cfg, p64, s64, m64, images.double(), labels.double(), lr)
+        _STEP_ORACLE_CACHE[key] = (params, state, images, labels, np64, ns64, t64)
+    params, state, images, labels, np64, ns64, t64 = _STEP_ORACLE_CACHE[key]
+
+    FLAGS.reset()
+    FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype=compute_dtype, use_blur=False,
+                 weight_decay=weight_decay, train_batch_size=batch)
+    RT.reset()
+    RT.device = torch.device(DEV)
+    model = model_lib.Model(num_classes)
+    with torch.no_grad():
+        model(torch.zeros(2, image_size, image_size, 6, device=DEV), training=True)
+    allv = dict(params); allv.update(state)
+    for v in model.variables:
+        v.value.copy_(allv[v.name].to(DEV))
+    RT.weights_version += 1
+    optimizer = model_lib.build_optimizer(lr)
+    step_fn = make_single_step(model, optimizer, None)
+    out = step_fn(images.to(DEV), {'labels': labels.to(DEV)})
+    torch.cuda.synchronize()
+    emu = compute_dtype == 'bf16'
+    tag = 'R%d %dpx b%d %s fixed' % (depth, image_size, batch, compute_dtype)
+    res = []
+
+    def gate(name, err, tol, **kw):
+        d = dict(name='%s %s' % (name, tag), err=float(err), tol=float(tol), scale=1.0, ok=bool(err <= tol), nbad=0, numel=1)
+        d.update(kw)
+        res.append(d)
+
+    def rel(a, b):
+        return float((a.double().cpu() - b.double()).abs().max()) / (float(b.double().abs().max()) + 1e-30)
+
+    gate('fixed_con_loss_rel', rel(out['con_loss'].value.reshape(-1)[0], t64['con_loss'].detach()), 1e-2 if emu else 1e-3,
+         value=float(out['con_loss'].value.reshape(-1)[0]), ref=float(t64['con_loss']))
+    gate('fixed_sup_loss_rel', rel(out['sup_loss'].value.reshape(-1)[0], t64['sup_loss'].detach()), 1e-2 if emu else 1e-3)
+    z_err = float((out['con_loss'].normalized.double().cpu() - t64['z'].detach()).abs().max())
+    gate('fixed_embeddings_abs', z_err, 5e-2 if emu else 1e-5)
+    keys = list(params.keys())
+    byname = {v.name: v for v in model._flat_order}
+    g64 = torch.cat([(t64['grads'][k] if t64['grads'][k] is not None else torch.zeros_like(np64[k])).double().reshape(-1) for k in keys])
+    gm = torch.cat([byname[k].grad.double().reshape(-1).cpu() for k in keys])
+    gate('fixed_grad_1-cos', 1.0 - float((gm * g64).sum() / gm.norm() / g64.norm()), 1e-2 if emu else 1e-6)
+    gate('fixed_grad_relnorm', float((gm - g64).norm() / g64.norm()), 1.5e-1 if emu else 2e-3)
+    gn = float(g64.norm())
+    worst, wn = 0.0, ''
+    for k in keys:
+        ref = t64['grads'][k]
+        if ref is None:
+            continue
+        e = float((byname[k].grad.double().cpu() - ref).norm()) / gn
+        if e > worst:
+            worst, wn = e, k
+    gate('fixed_grad_tensor_vs_global_norm', worst, 1e-1 if emu else 1e-3, worst=wn)
+    pw = max(rel(byname[k].value, np64[k]) for k in keys)
+    gate('fixed_new_params_worst_rel', pw, 2e-2 if emu else 1e-5)
+    bm = max(rel(v.value, ns64[v.name]) for v in model.variables if v.name in ns64)
+    gate('fixed_bn_moving_worst_rel', bm, 1e-2 if emu else 1e-5)
     return res

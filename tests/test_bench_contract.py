@@ -16,11 +16,12 @@ def _bench():
 def test_roofline_entry_memory_bound_family():
     b = _bench()
     # 100 launches, 160 FLOP/B: below the bf16 ridge (2500e12 / 8000e9 = 312.5) -> HBM is the binding roof
-    r = b.make_roofline('conv_igemm', flops=100 * 1.6e11, nbytes=100 * 1.0e9, total_ms=100 * 0.4, launches=100, steps=2,
-                        mfma_peak_tflops=2500.0, traffic=1_100_000_000, traffic_src='profiles/x.json')
+    r = b.make_roofline('conv_igemm', flops=100 * 1.6e11, min_bytes=100 * 1.0e9, impl_bytes=100 * 1.2e9, total_ms=100 * 0.4,
+                        launches=100, steps=2, mfma_peak_tflops=2500.0)
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
-    assert abs(r['achieved'] - 2500.0) < 1e-6 and abs(r['frac'] - 2500.0 / 8000.0) < 1e-4
-    assert r['traffic'] == 1_100_000_000 and r['launches_per_step'] == 50
+    assert abs(r['achieved'] - 2500.0) < 1e-6 and abs(r['frac'] - 2500.0 / 8000.0) < 1e-4      # from the MINIMUM bytes
+    assert abs(r['impl_gbps'] - 3000.0) < 1e-6 and r['impl_bytes_per_launch'] == 1_200_000_000
+    assert r['traffic'] is None and r['launches_per_step'] == 50
     assert abs(r['achieved_tflops'] - 400.0) < 1e-6 and abs(r['mfma_frac'] - 0.16) < 1e-4
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r
@@ -28,7 +29,18 @@ def test_roofline_entry_memory_bound_family():
 
 def test_roofline_entry_compute_bound_family():
     b = _bench()
-    r = b.make_roofline('conv_igemm', flops=10 * 4.0e11, nbytes=10 * 1.0e9, total_ms=10 * 0.5, launches=10, steps=1,
-                        mfma_peak_tflops=2500.0, traffic=None, traffic_src=None)
+    r = b.make_roofline('conv_igemm', flops=10 * 4.0e11, min_bytes=10 * 1.0e9, impl_bytes=10 * 1.0e9, total_ms=10 * 0.5,
+                        launches=10, steps=1, mfma_peak_tflops=2500.0)
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0
     assert abs(r['achieved'] - 800.0) < 1e-6 and abs(r['frac'] - 0.32) < 1e-4 and r['traffic'] is None
+
+
+def test_step_time_percentiles_and_self_launch_command():
+    b = _bench()
+    p = b.percentiles([float(i) for i in range(1, 102)])
+    assert p == dict(p10=11.0, median=51.0, p90=91.0, n=101)
+    # `python bench.py --gpus N` without a torchrun environment re-launches itself with one rank per GPU
+    import inspect
+    src = inspect.getsource(b.relaunch_multi_gpu)
+    for needle in ('torch.distributed.run', '--nproc-per-node', '--master-addr', '127.0.0.1'):
+        assert needle in src

@@ -24,12 +24,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='gloo'):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.cuda.set_device(0)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        devno = rank if backend == 'nccl' else 0          # RCCL needs one device per rank; gloo ranks share cuda:0
+        torch.cuda.set_device(devno)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', devno))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
         from collections import OrderedDict
         from oracle.model_torch import Config, init_model, train_step
         from simclr_amd import comm
@@ -48,7 +52,7 @@ def _worker(rank, world, port, q):
         FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='f32', use_blur=False,
                      weight_decay=wd, train_batch_size=world * b)
         RT.reset()
-        RT.device = torch.device('cuda', 0)
+        RT.device = torch.device('cuda', devno)
         strategy = comm.Strategy()
         RT.strategy = strategy
         model = model_lib.Model(num_classes)
@@ -69,8 +73,9 @@ def _worker(rank, world, port, q):
         m64 = OrderedDict((k, torch.zeros_like(v)) for k, v in p64.items())
         np64, ns64, nm64, t64 = train_step(cfg, p64, s64, m64, images.double(), labels.double(), lr)
         # per-replica contrastive loss differs per rank; its mean over ranks is the global loss
-        lt = torch.tensor([float(out['con_loss'].value.item())], dtype=torch.float64)
+        lt = torch.tensor([float(out['con_loss'].value.item())], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(lt)
+        lt = lt.cpu()
         res = {}
         res['loss_rel'] = abs(float(lt) / world - float(t64['con_loss'])) / float(t64['con_loss'])
         byname = {v.name: v for v in model._flat_order}
@@ -84,6 +89,8 @@ def _worker(rank, world, port, q):
         res['param_worst_rel'] = max(
             float((byname[k].value.double().cpu() - np64[k]).abs().max()) / (float(np64[k].abs().max()) + 1e-30)
             for k in np64)
+        res['stat_collectives'] = strategy.stat_collectives
+        res['hidden_collectives'] = strategy.hidden_collectives
         res['bn_moving_worst_rel'] = max(
             float((v.value.double().cpu() - ns64[v.name]).abs().max()) / (float(ns64[v.name].abs().max()) + 1e-30)
             for v in model.variables if v.name in ns64)
@@ -95,12 +102,11 @@ def _worker(rank, world, port, q):
         q.put((rank, 'FAIL', traceback.format_exc()))
 
 
-def test_two_replica_step_equals_global_batch_oracle():
-    world = 2
+def _run(world, backend):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -113,3 +119,19 @@ def test_two_replica_step_equals_global_batch_oracle():
         assert m['grad_worst_rel'] < 2e-3, m
         assert m['param_worst_rel'] < 1e-4, m
         assert m['bn_moving_worst_rel'] < 1e-4, m
+        # ResNet-18: 21 encoder BNs (stem, 8 x 2, 4 projection shortcuts) + 3 head BNs, forward and backward; the 4
+        # projection blocks batch (shortcut BN, bn1) forward and (tail BN, shortcut BN) backward into one exchange each
+        assert m['hidden_collectives'] == 2, m
+        assert m['stat_collectives'] <= 2 * 24 - 8, m
+
+
+def test_two_replica_step_equals_global_batch_oracle():
+    _run(2, 'gloo')
+
+
+def test_two_replica_step_over_rccl():
+    """The same identity with one rank per GPU over RCCL ('nccl' backend): all-gather / reduce-scatter of the hidden
+    block, SyncBN all-reduces on their own communicator, bucketed gradient all-reduce.  Needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (the build session reaches one); the driver runs the multi-GPU bench')
+    _run(2, 'nccl')

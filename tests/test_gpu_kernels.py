@@ -88,6 +88,45 @@ def test_conv_fwd_dgrad_wgrad(V, H, Cin, Cout, k, s, dtype):
     _assert(gc.check_conv(V, H, H, Cin, Cout, k, s, dtype))
 
 
+# BASELINE cfg2 (ResNet-50 1x, 224 px) layer classes at the row counts the benchmark runs: every persistent
+# igemm workgroup walks several tiles (count >= 2), wgrad takes the XCD-mapped / 256x256 paths.
+# (V, H, Cin, Cout, k, stride, bn_case=(mask_mode, accumulate) of the fused dgrad + BN-backward reduce)
+BENCH_PATH_CASES = [
+    (1024, 56, 64, 256, 1, 1, (2, 0)),     # conv3 of group 1 (expand 1x1): 25 088 M-tiles
+    (256, 56, 256, 64, 1, 1, (3, 1)),      # conv1 of group 1 (reduce 1x1) + residual accumulate + ReLU bits
+    (1024, 56, 64, 64, 3, 1, (2, 0)),      # 3x3 @56^2
+    (256, 56, 128, 128, 3, 2, None),       # 3x3 stride 2, 56 -> 28 (class-decomposed dgrad)
+    (256, 56, 256, 512, 1, 2, None),       # projection shortcut 1x1 stride 2
+    (256, 28, 128, 512, 1, 1, (1, 0)),     # group 2 expand
+    (1024, 14, 256, 256, 3, 1, (2, 0)),    # 3x3 @14^2 (256x256 wgrad tile)
+    (1024, 7, 512, 2048, 1, 1, (2, 0)),    # group 4 expand
+    (1024, 7, 512, 512, 3, 1, (1, 0)),     # 3x3 @7^2
+]
+
+
+@pytest.mark.parametrize('dtype', [BF, F32])
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s,bn_case', BENCH_PATH_CASES)
+def test_conv_bench_path_shapes(V, H, Cin, Cout, k, s, bn_case, dtype):
+    """the code path bench.py runs (tf2/resnet.py:183-208 at cfg2 sizes)."""
+    from tests import gpu_checks as gc
+    if dtype == F32 and V == 1024 and H == 56:
+        V = 512                      # fp32 tensors: keep the float64 reference chunks small
+    _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, dtype, bn_case=bn_case))
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('compute_dtype', ['f32', 'bf16'])
+def test_train_step_resnet50_224_batch32_fixed_thresholds(compute_dtype):
+    """ResNet-50 / 224 px / batch 32 step vs the float64 oracle with FIXED gates
+    (f32: north_star 1e-3 loss / 1e-5 embeddings; bf16: loss 1e-2, gradient 1-cos 1e-2)."""
+    from tests import gpu_checks as gc
+    res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype=compute_dtype)
+    for r in res:
+        print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
+    _assert(res)
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('V,H,Cin,Cout', [(3, 14, 64, 128), (3, 9, 128, 192), (2, 16, 64, 64), (5, 8, 128, 64)])
 def test_conv_wgrad_multitap_3x3(V, H, Cin, Cout):
     """The opt-in multi-tap 3x3 wgrad kernel (SIMCLR_WGRAD_3X3) forced on:
