@@ -46,6 +46,15 @@ class _Runtime:
         self.device = 'cuda'
         self.seed = 0
         self.weights_version = 0     # bumped by the optimizer step; compute copies refresh lazily
+        self._wgrad_stream = None
+
+    def wgrad_stream(self):
+        """Side stream for the weight-gradient kernels (SIMCLR_WGRAD_STREAM=1), else None."""
+        if self._wgrad_stream is None:
+            import os
+            on = os.environ.get('SIMCLR_WGRAD_STREAM', '0') not in ('', '0') and torch.cuda.is_available()
+            self._wgrad_stream = torch.cuda.Stream() if on else False
+        return self._wgrad_stream or None
 
     def unique(self, base):
         i = self.counters.get(base, 0)
@@ -406,17 +415,19 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         if 'packed' in sv:
             if train_w:
                 pk = sv['packed']
-                if self.cout_p == self.filters:
-                    ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, out=self.kernel.ensure_grad())
-                else:
-                    self._store_wgrad(ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s))
+                with _wgrad_side_stream(pk.xp, dy):      # same stream as every other wgrad: they share one workspace
+                    if self.cout_p == self.filters:
+                        ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, out=self.kernel.ensure_grad())
+                    else:
+                        self._store_wgrad(ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s))
             return None
         if train_w:
-            if not self.padded:
-                ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'], out=self.kernel.ensure_grad().view(-1, self.filters))
-            else:
-                tmp = ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'])
-                self._store_wgrad(tmp.view(k, k, self.cin_p, self.cout_p))
+            with _wgrad_side_stream(sv['x'], dy):
+                if not self.padded:
+                    ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'], out=self.kernel.ensure_grad().view(-1, self.filters))
+                else:
+                    tmp = ops.conv2d_wgrad(sv['x'], dy, k, k, s, sv['pad'])
+                    self._store_wgrad(tmp.view(k, k, self.cin_p, self.cout_p))
         if not need_dx:
             return None
         if fuse_bn is not None:
@@ -425,6 +436,42 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
                                        accumulate=accumulate)
         return ops.conv2d_dgrad(dy, self.w_d, k, k, s, sv['pad'], sv['H'], sv['W'], out=dx_out,
                                 accumulate=accumulate)
+
+
+class _wgrad_side_stream:
+    """Weight gradients have no consumer until the optimizer step, while the data gradient of the same layer is on the
+    critical path of the backward pass.  With SIMCLR_WGRAD_STREAM=1 every wgrad launch goes to a second HIP stream
+    (after an event that marks its operands ready), so it runs concurrently with the dgrad / BatchNorm-backward chain;
+    `join_wgrad_stream()` makes the launch stream wait for it before gradients are reduced / applied."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        ws = RT.wgrad_stream()
+        if ws is None:
+            return self
+        ev = torch.cuda.Event()
+        ev.record()
+        ws.wait_event(ev)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(ws)          # the caching allocator must not recycle them before the side stream is done
+        self.ctx = torch.cuda.stream(ws)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+
+def join_wgrad_stream():
+    ws = RT.wgrad_stream()
+    if ws is not None:
+        torch.cuda.current_stream().wait_stream(ws)
 
 
 class _PlainConv1x1(Conv2dFixedPadding):

@@ -21,7 +21,7 @@ from . import model as model_lib
 from . import objective as obj_lib
 from .comm import Strategy, num_replicas
 from .flags import FLAGS
-from .resnet import RT
+from .resnet import RT, join_wgrad_stream
 
 
 def build_metrics():
@@ -63,6 +63,7 @@ class GradSync:
         """Called by the backward pass after block group `stage` (4..1) is done; 0 = stem done."""
         if self.strategy is None or self.strategy.num_replicas_in_sync <= 1:
             return
+        join_wgrad_stream()          # this bucket's weight gradients may still be running on the side stream
         if stage == 0:
             idx = len(self.ranges) - 1 if len(self.ranges) > 4 else None
         else:
@@ -122,6 +123,7 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
         model.backward_supervised(d_sup)
         d_proj = con_loss.backward_finish() if con_loss is not None else None
         model.backward(d_proj, None, on_stage=sync.on_stage)
+        join_wgrad_stream()
         sync.wait()
         optimizer.apply_gradients([(v.grad, v) for v in model._flat_order])                # :622
         RT.weights_version += 1
