@@ -59,6 +59,8 @@ _DEFS = [
     ('use_blur', True, bool, 'Whether or not to use Gaussian blur for augmentation during pretraining.'),  # :236
     # build-specific (not in the reference)
     ('compute_dtype', 'bf16', str, "MI355X build: activation/compute dtype, 'bf16' (speed) or 'f32' (parity)."),
+    ('head_dtype', 'same', str, "MI355X build: dtype of the projection / supervised heads: 'same' (= compute_dtype) or 'f32' "
+                                "(the heads are 0.2 % of the FLOPs; fp32 there keeps the loss gradient exact)."),
 ]
 
 

@@ -112,18 +112,19 @@ class LinearLayer(Layer):  # tf2/model.py:119-154
             self.bias = Variable(self._path + '/bias:0', torch.zeros(n, device=RT.device))
         self.cin = cin
 
-    def _refresh(self):
-        if self._version == RT.weights_version and getattr(self, '_dtype', None) == RT.dtype:
+    def _refresh(self, dtype):
+        """Compute copies of the fp32 master weight in the dtype of the layer's input."""
+        if self._version == RT.weights_version and getattr(self, '_dtype', None) == dtype:
             return
         w4 = self.kernel.value.view(1, 1, self.cin, self.nout)
         if self.npad == self.nout:
-            self.w_t = ops.prep_weights(w4, 0, RT.dtype)
+            self.w_t = ops.prep_weights(w4, 0, dtype)
         else:   # class dimension padded to a multiple of 16 with zero rows
-            self.w_t = torch.zeros(self.npad, self.cin, device=RT.device, dtype=RT.dtype)
-            ops.prep_weights(w4, 0, RT.dtype, out=self.w_t[:self.nout])
-        self.w_d = ops.prep_weights(w4, 1, RT.dtype) if self.npad == self.nout else None
+            self.w_t = torch.zeros(self.npad, self.cin, device=RT.device, dtype=dtype)
+            ops.prep_weights(w4, 0, dtype, out=self.w_t[:self.nout])
+        self.w_d = ops.prep_weights(w4, 1, dtype) if self.npad == self.nout else None
         self._version = RT.weights_version
-        self._dtype = RT.dtype
+        self._dtype = dtype
 
     def __call__(self, inputs, training, relu=False):
         """inputs: [V, C] tensor.  Returns [V, n] tensor (dense [+BN [+relu]])."""
@@ -131,7 +132,7 @@ class LinearLayer(Layer):  # tf2/model.py:119-154
         V, cin = inputs.shape
         if self.kernel is None:
             self.build(cin)
-        self._refresh()
+        self._refresh(inputs.dtype)
         x4 = inputs.view(V, 1, 1, cin)
         stats = ops.new_stats(self.npad, RT.device) if (self.use_bn and training) else None
         y = ops.conv2d_fwd(x4, self.w_t, 1, 1, 1, 0, 1, 1, stats=stats).view(V, self.npad)
@@ -185,6 +186,9 @@ class ProjectionHead(Layer):  # tf2/model.py:157-213
     def __call__(self, inputs, training):
         if FLAGS.proj_head_mode == 'none':
             return inputs, inputs  # directly use the output hiddens as hiddens
+        self._in_dtype = inputs.dtype
+        if FLAGS.head_dtype == 'f32' and inputs.dtype != torch.float32:
+            inputs = ops.cast(inputs, torch.float32)          # heads in fp32 on top of a bf16 encoder
         hiddens_list = [inputs]
         if FLAGS.proj_head_mode == 'linear':
             # The reference returns None here (list.append, tf2/model.py:198-199); we return the
@@ -200,6 +204,8 @@ class ProjectionHead(Layer):  # tf2/model.py:157-213
     def backward(self, d):
         for layer in reversed(self.linear_layers):
             d = layer.backward(d)
+        if self.linear_layers and d.dtype != self._in_dtype:
+            d = ops.cast(d, self._in_dtype)
         return d
 
 
@@ -263,6 +269,7 @@ class Model(Layer):
         hiddens = self.resnet_model(packed, training=training)                     # :262
         proj, sup_in = self._projection_head(hiddens, training)                    # :265-266
         self._proj_is_encoder = proj is hiddens
+        self._proj_dtype = proj.dtype
         proj32 = ops.cast(proj, torch.float32) if proj.dtype != torch.float32 else proj
         sup_out = None
         if FLAGS.train_mode == 'pretrain' and FLAGS.lineareval_while_pretraining:
@@ -280,7 +287,7 @@ class Model(Layer):
     def backward(self, d_proj, d_sup=None, on_stage=None):
         """d_proj: float32 [k*b, proj_out_dim]; d_sup: gradient wrt the supervised logits."""
         self.backward_supervised(d_sup)
-        d = ops.cast(d_proj, RT.dtype) if RT.dtype != torch.float32 else d_proj
+        d = ops.cast(d_proj, self._proj_dtype) if self._proj_dtype != torch.float32 else d_proj
         d = self._projection_head.backward(d)
         self.resnet_model.backward(d, on_stage=on_stage)
 

@@ -115,12 +115,12 @@ def test_conv_bench_path_shapes(V, H, Cin, Cout, k, s, bn_case, dtype):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('compute_dtype', ['f32', 'bf16'])
-def test_train_step_resnet50_224_batch32_fixed_thresholds(compute_dtype):
+@pytest.mark.parametrize('compute_dtype,head_dtype', [('f32', 'same'), ('bf16', 'same'), ('bf16', 'f32')])
+def test_train_step_resnet50_224_batch32_fixed_thresholds(compute_dtype, head_dtype):
     """ResNet-50 / 224 px / batch 32 step vs the float64 oracle with FIXED gates
     (f32: north_star 1e-3 loss / 1e-5 embeddings; bf16: loss 1e-2, gradient 1-cos 1e-2)."""
     from tests import gpu_checks as gc
-    res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype=compute_dtype)
+    res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype=compute_dtype, head_dtype=head_dtype)
     for r in res:
         print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
     _assert(res)
@@ -268,3 +268,62 @@ def test_eval_mode_checkpoint_resume_and_perform_evaluation():
     """eval forward vs oracle, checkpoint -> restore -> identical continuation, eval loop outputs."""
     from tests import gpu_checks as gc
     _assert(gc.check_eval_and_checkpoint())
+
+
+def test_hand_derived_lars_cases_on_device():
+    """The fused multi-tensor LARS kernels vs the paper-and-pencil cases of tests/golden/HAND_DERIVED.md
+    (tf2/lars_optimizer.py:83-137) -- expected values NOT produced by the oracle."""
+    import json
+    from simclr_amd.lars_optimizer import LARSOptimizer, Variable
+    h = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'hand_derived.json')))['lars']
+    groups = {}
+    for c in h['cases']:
+        groups.setdefault((c['classic'], c['nesterov'], c.get('weight_decay', h['weight_decay'])), []).append(c)
+    for (classic, nest, wd), cases in groups.items():
+        vs = []
+        for c in cases:
+            v = Variable(c['name'], torch.tensor(c['w'], device='cuda'))
+            v.grad = torch.tensor(c['g'], device='cuda')
+            vs.append(v)
+        opt = LARSOptimizer(h['lr'], momentum=h['momentum'], weight_decay=wd, use_nesterov=nest, classic_momentum=classic,
+                            eeta=h['eeta'], exclude_from_weight_decay=h['exclude_from_weight_decay'])
+        opt._build(vs)
+        for v, c in zip(vs, cases):
+            opt.get_slot(v, 'Momentum').copy_(torch.tensor(c['v'], device='cuda'))
+        opt.apply_gradients([(v.grad, v) for v in vs])
+        torch.cuda.synchronize()
+        for v, c in zip(vs, cases):
+            assert np.allclose(v.value.cpu().numpy(), c['w_new'], rtol=2e-6, atol=1e-7), (c, v.value)
+            assert np.allclose(opt.get_slot(v, 'Momentum').cpu().numpy(), c['v_new'], rtol=2e-6, atol=1e-7), c
+
+
+def test_hand_derived_batch_norm_on_device():
+    """BatchNorm kernels (statistics finalize with the BIASED variance + moving averages, apply + ReLU, backward)
+    vs the hand-derived case of tests/golden/HAND_DERIVED.md (tf2/resnet.py:31-78)."""
+    from simclr_amd import ops
+    from tests.test_oracle import bn_hand_expected
+    b, y_ref, bwd = bn_hand_expected()
+    C, Cp = 2, 4                                           # kernels move 4 fp32 channels per lane: pad with zeros
+    x = torch.zeros(4, Cp, device='cuda'); x[:, :C] = torch.tensor(b['x'], device='cuda')
+    gamma = torch.zeros(Cp, device='cuda'); gamma[:C] = torch.tensor(b['gamma'], device='cuda')
+    beta = torch.zeros(Cp, device='cuda'); beta[:C] = torch.tensor(b['beta'], device='cuda')
+    mm, mv = torch.zeros(Cp, device='cuda'), torch.ones(Cp, device='cuda')
+    part = ops.new_stats(Cp, 'cuda')
+    part[0, 0] = x.sum(0); part[0, 1] = (x * x).sum(0)
+    mean, rstd, scale, shift = ops.bn_finalize(None, 4, gamma, beta, mm, mv, b['decay'], b['eps'], partial=part)
+    y = ops.bn_apply(x, scale, shift, True)
+    torch.cuda.synchronize()
+    assert np.allclose(mean.cpu().numpy()[:C], b['mean'], atol=1e-6)
+    assert np.allclose(mm.cpu().numpy()[:C], b['moving_mean'], atol=1e-6)
+    assert np.allclose(mv.cpu().numpy()[:C], b['moving_variance'], atol=1e-6)
+    assert np.abs(y.cpu().numpy()[:, :C] - y_ref).max() < 2e-6
+    dy = torch.zeros(4, Cp, device='cuda'); dy[:, :C] = torch.tensor(bwd['dy'], device='cuda', dtype=torch.float32)
+    p = ops.bn_bwd_reduce(dy, x, None, scale, shift, mean, rstd, 0)
+    dgamma, dbeta = torch.zeros(Cp, device='cuda'), torch.zeros(Cp, device='cuda')
+    c1, c2 = ops.bn_bwd_finalize(None, None, 4, dgamma, dbeta, partial=p)
+    dx, _ = ops.bn_bwd_apply(dy, x, None, scale, shift, mean, rstd, c1, c2, 0)
+    torch.cuda.synchronize()
+    assert np.abs(dgamma.cpu().numpy()[:C] - bwd['dgamma']).max() < 1e-5
+    assert np.abs(dbeta.cpu().numpy()[:C] - bwd['dbeta']).max() < 1e-5
+    # dx is O(eps) here: absolute tolerance at fp32 cancellation level of its O(1) terms
+    assert np.abs(dx.cpu().numpy()[:, :C] - bwd['dx']).max() < 2e-6

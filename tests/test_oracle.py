@@ -207,3 +207,76 @@ def test_blur_oracle_is_separable_gaussian_and_selector_semantics():
     assert np.abs(y - ref).max() < 1e-12
     out = oblur.batch_random_blur([x * 1.5], 50, [1.0], [np.array([0.0, 1.0])])[0]
     assert np.array_equal(out[0], np.clip(x[0] * 1.5, 0, 1)) and not np.array_equal(out[1], np.clip(x[1] * 1.5, 0, 1))
+
+
+# ---- hand-derived known answers (tests/golden/HAND_DERIVED.md; NOT oracle output) ----------------
+def _hand():
+    import json
+    return json.load(open(os.path.join(GOLD, 'hand_derived.json')))
+
+
+def test_hand_derived_lars_cases():
+    """tf2/lars_optimizer.py:83-137 worked by hand: weight decay, trust ratio, classic / Nesterov / 'popular' momentum,
+    the excluded-name filters and both zero-norm branches."""
+    h = _hand()['lars']
+    for c in h['cases']:
+        nw, nv = olars.lars_apply(c['name'], np.array(c['w']), np.array(c['g']), np.array(c['v']), h['lr'],
+                                  momentum=h['momentum'], use_nesterov=c['nesterov'],
+                                  weight_decay=c.get('weight_decay', h['weight_decay']),
+                                  exclude_from_weight_decay=h['exclude_from_weight_decay'],
+                                  classic_momentum=c['classic'], eeta=h['eeta'])
+        assert np.allclose(nw, c['w_new'], rtol=0, atol=1e-12), (c, nw)
+        assert np.allclose(nv, c['v_new'], rtol=0, atol=1e-12), (c, nv)
+
+
+def bn_hand_expected():
+    """Evaluates the closed-form expressions of tests/golden/hand_derived.json (float64)."""
+    from math import sqrt  # noqa: F401  (used by eval below)
+    b = _hand()['batch_norm']
+    env = {'sqrt': sqrt}
+    env.update({k: eval(v, {'sqrt': sqrt}) for k, v in b['r_expr'].items()})
+    y = np.array([[eval(e, dict(env)) for e in row] for row in b['y_relu_expr']], dtype=np.float64)
+    x = np.array(b['x'])
+    var = np.array(b['biased_var'])
+    xh = (x - np.array(b['mean'])) / np.sqrt(var + b['eps'])
+    bwd = dict(dy=xh, dbeta=np.zeros(2), dgamma=4 * var / (var + b['eps']),
+               dx=np.array(b['gamma']) / np.sqrt(var + b['eps']) * xh * b['eps'] / (var + b['eps']))
+    return b, y, bwd
+
+
+def test_hand_derived_batch_norm():
+    """tf2/resnet.py:31-78: biased variance, moving-average update, BN+ReLU output, and the BN backward."""
+    from oracle.model_torch import Builder
+    b, y_ref, bwd = bn_hand_expected()
+    x = torch.tensor(b['x'], dtype=torch.float64).t().reshape(1, 2, 4, 1).permute(2, 1, 0, 3).contiguous()   # [N=4, C=2, 1, 1]
+    bl = Builder(Config(), dtype=torch.float64)
+    bl.batch_norm_relu(x, relu=True)                       # creates gamma=1, beta=0; overwrite, then run
+    names = list(bl.params.keys())
+    bl.params[names[0]] = torch.tensor(b['gamma'], dtype=torch.float64)
+    bl.params[names[1]] = torch.tensor(b['beta'], dtype=torch.float64)
+    bl.init = False
+    bl.namer = type(bl.namer)()
+    y = bl.batch_norm_relu(x, relu=True)[:, :, 0, 0].numpy()
+    assert np.abs(y - y_ref).max() < 1e-12
+    st = {k.rsplit('/', 1)[1]: v.numpy() for k, v in bl.new_state.items()}
+    assert np.allclose(st['moving_mean:0'], b['moving_mean'], atol=1e-15)
+    assert np.allclose(st['moving_variance:0'], b['moving_variance'], atol=1e-15)
+    # backward of the BN alone for dy = x^
+    xr = x.clone().requires_grad_(True)
+    g = bl.params[names[0]].clone().requires_grad_(True)
+    be = bl.params[names[1]].clone().requires_grad_(True)
+    bl.params[names[0]], bl.params[names[1]] = g, be
+    bl.namer = type(bl.namer)()
+    out = bl.batch_norm_relu(xr, relu=False)
+    out.backward(torch.tensor(bwd['dy']).reshape(4, 2, 1, 1))
+    assert np.abs(xr.grad[:, :, 0, 0].numpy() - bwd['dx']).max() < 1e-12
+    assert np.abs(g.grad.numpy() - bwd['dgamma']).max() < 1e-12 and np.abs(be.grad.numpy() - bwd['dbeta']).max() < 1e-12
+
+
+def test_oracle_matches_tensorflow_reference():
+    """Runs /root/reference/tf2 itself against the oracle when TensorFlow is importable (it is not in this image)."""
+    from oracle import check_against_tf as chk
+    if not chk.available():
+        pytest.skip('tensorflow / absl / reference checkout not available here: oracle stays unpinned (DESIGN.md section 5)')
+    ok, res = chk.run_all()
+    assert ok, res
