@@ -62,7 +62,8 @@ int simclr_ntxent_logits_ab(const float* z_local, const float* z_all, int n, int
 /* ---- LARS: tf2/lars_optimizer.py:83-137 (_resource_apply_dense), all tensors in 2 launches ---- */
 /* table: device int64[5*T] = {w ptrs | g ptrs | v ptrs | numel | flags(bit0 use_weight_decay :139-148,
  * bit1 do_layer_adaptation :150-157)}; chunks: device int64[2*num_chunks] = (tensor id, element
- * offset), one per simclr_lars_chunk_elems() elements; norms: device double[2*T] scratch.
+ * offset), one per simclr_lars_chunk_elems() elements, a tensor's chunks consecutive and in offset order; norms: device
+ * double[2*num_chunks] scratch (per-chunk partial norms, summed in a fixed order: the update is run-to-run deterministic).
  * lr_dev (nullable) overrides lr with a device-resident value (graph replay). */
 int simclr_lars_chunk_elems(void);
 int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long long* chunks,
@@ -78,6 +79,15 @@ int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin,
 /* modes 0 (dst_t) and 1 (dst_d) of the same weight in one launch. */
 int simclr_prep_weights_pair(const float* w_hwio, void* dst_t, void* dst_d, int KH, int KW, int Cin, int Cout,
                              int CinP, int CoutP, int dtype, simclr_stream_t stream);
+/* Partial-statistics slots.  Every `stats` / `partial` argument below is float [nslot][2][C], zeroed by the caller.
+ * With nslot >= the number returned here each producing workgroup stores into its OWN slot (no float atomics) and the
+ * slot reduction of simclr_bn_finalize / simclr_bn_bwd_finalize / simclr_bn_reduce_slots adds the slots in a fixed
+ * order: BatchNorm statistics are then bit-identical from run to run, like the reference's SyncBatchNormalization
+ * (tf2/resnet.py:54-60).  With fewer slots the producers fall back to float atomics into slot (workgroup % nslot). */
+int simclr_conv2d_stats_slots(long long M, int C);      /* simclr_conv2d_fwd, simclr_conv2d_dgrad_bn: M output rows x C channels */
+int simclr_stem_stats_slots(long long M);               /* simclr_stem_conv_fwd: M = V*OH*OW */
+int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype);
+
 /* y[V,OH,OW,Cout] = conv(x[V,IH,IW,Cin], w), explicit symmetric padding `pad` (resnet.py:167-180).
  * stats (nullable) float[nslot][2][Cout], zeroed by caller: per-channel partial (sum, sum sq) of y
  * for BatchNorm (resnet.py:50-78).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0. */

@@ -17,35 +17,67 @@
 
 namespace {
 
+// Fixed-order reduction of the partial-statistics slots: a 256-thread workgroup owns 32 channels; thread
+// (sl = tid / 32, cl = tid % 32) adds slots sl, sl+8, sl+16, ... of channel c0+cl in ascending order (coalesced
+// 128-byte rows, several loads in flight), then the eight lane sums are added in the order sl = 0..7.  The order
+// never depends on timing, so the result is bit-identical from run to run whatever wrote the slots.
+// Returns the two sums of channel c0 + (tid % 32) in the threads with tid < 32 (others: partial values).
+constexpr int kSlotCh = 32;
+__device__ __forceinline__ void slot_sums(const float* __restrict__ partial, int nslot, int C, int c0,
+                                          double* sh /* [2][8][32] */, double& s1, double& s2) {
+  const int sl = threadIdx.x >> 5, cl = threadIdx.x & 31, c = c0 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    int s = sl;
+    for (; s + 24 < nslot; s += 32) {            // four independent loads per statistic in flight
+      const float* q = partial + (long long)s * 2 * C + c;
+      const float a0 = q[0], a1 = q[16ll * C], a2 = q[32ll * C], a3 = q[48ll * C];
+      const float b0 = q[C], b1 = q[16ll * C + C], b2 = q[32ll * C + C], b3 = q[48ll * C + C];
+      a += (double)a0; a += (double)a1; a += (double)a2; a += (double)a3;
+      b += (double)b0; b += (double)b1; b += (double)b2; b += (double)b3;
+    }
+    for (; s < nslot; s += 8) {
+      a += (double)partial[(long long)s * 2 * C + c];
+      b += (double)partial[(long long)s * 2 * C + C + c];
+    }
+  }
+  sh[sl * 32 + cl] = a;
+  sh[256 + sl * 32 + cl] = b;
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+  if (threadIdx.x < 32) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1 += sh[j * 32 + cl]; s2 += sh[256 + j * 32 + cl]; }
+  }
+}
+
 // sums[2][C] (double) = sum over slots of partial[slot][2][C] (float)
-__global__ void bn_reduce_slots(const float* __restrict__ partial, int nslot, int C,
-                                double* __restrict__ sums) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
-  double a = 0.0;
-  for (int s = 0; s < nslot; ++s) a += (double)partial[(long long)s * 2 * C + i];
-  sums[i] = a;
+__global__ __launch_bounds__(256) void bn_reduce_slots(const float* __restrict__ partial, int nslot, int C,
+                                                       double* __restrict__ sums) {
+  __shared__ double sh[512];
+  const int c0 = blockIdx.x * kSlotCh;
+  double s1, s2;
+  slot_sums(partial, nslot, C, c0, sh, s1, s2);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x < 32 && c < C) { sums[c] = s1; sums[C + c] = s2; }
 }
 
 // From global sums -> mean/rstd/scale/shift, moving-stat update.  If `partial` is given (single
 // replica: no all-reduce between) the slot reduction is done here instead of a separate launch.
-__global__ void bn_finalize(const double* __restrict__ sums, const float* __restrict__ partial, int nslot,
-                            double count, int C,
+__global__ __launch_bounds__(256) void bn_finalize(const double* __restrict__ sums, const float* __restrict__ partial,
+                            int nslot, double count, int C,
                             const float* __restrict__ gamma, const float* __restrict__ beta,
                             float* __restrict__ moving_mean, float* __restrict__ moving_var,
                             float decay, float eps, float* __restrict__ mean_out,
                             float* __restrict__ rstd_out, float* __restrict__ scale,
                             float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1, s2;
-  if (partial) {
-    s1 = 0.0; s2 = 0.0;
-    for (int s = 0; s < nslot; ++s) {
-      s1 += (double)partial[(long long)s * 2 * C + c];
-      s2 += (double)partial[(long long)s * 2 * C + C + c];
-    }
-  } else { s1 = sums[c]; s2 = sums[C + c]; }
+  __shared__ double sh[512];
+  const int c0 = blockIdx.x * kSlotCh;
+  double s1 = 0.0, s2 = 0.0;
+  if (partial) slot_sums(partial, nslot, C, c0, sh, s1, s2);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x >= 32 || c >= C) return;
+  if (!partial) { s1 = sums[c]; s2 = sums[C + c]; }
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;  // biased variance (Keras non-fused BN)
   if (var < 0.0) var = 0.0;
@@ -153,7 +185,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(
   const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = min(rows, r0 + rows_per_block);
-  float* slot = partial + (long long)(blockIdx.x % nslot) * 2 * C;
+  // nslot >= gridDim.x (simclr_bn_bwd_reduce_slots): every workgroup stores into its own slot, no float atomics
+  const bool own_slot = nslot >= (int)gridDim.x;
+  float* slot = partial + (long long)(own_slot ? blockIdx.x : blockIdx.x % nslot) * 2 * C;
   for (int cc0 = 0; cc0 < cpr; cc0 += cw) {
     const int cc = cc0 + tcol;
     float s1[EPC], s2[EPC];
@@ -209,30 +243,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(
           a += red[((q * cw + tcol) * EPC + e) * 2];
           b += red[((q * cw + tcol) * EPC + e) * 2 + 1];
         }
-        atomicAdd(slot + cc * EPC + e, a);
-        atomicAdd(slot + C + cc * EPC + e, b);
+        if (own_slot) { slot[cc * EPC + e] = a; slot[C + cc * EPC + e] = b; }     // deterministic: one writer per entry
+        else { atomicAdd(slot + cc * EPC + e, a); atomicAdd(slot + C + cc * EPC + e, b); }
       }
     }
   }
 }
 
 // local sums -> dgamma/dbeta (+=), global sums/count -> c1 = mean(dy), c2 = mean(dy*x^)
-__global__ void bn_bwd_finalize(const double* __restrict__ local_sums,
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const double* __restrict__ local_sums,
                                 const double* __restrict__ global_sums, const float* __restrict__ partial,
                                 int nslot, double count, int C,
                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                 float* __restrict__ c1, float* __restrict__ c2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double l1, l2, g1, g2;
-  if (partial) {           // single replica: local == global, reduce the slots here
-    l1 = 0.0; l2 = 0.0;
-    for (int s = 0; s < nslot; ++s) {
-      l1 += (double)partial[(long long)s * 2 * C + c];
-      l2 += (double)partial[(long long)s * 2 * C + C + c];
-    }
-    g1 = l1; g2 = l2;
-  } else { l1 = local_sums[c]; l2 = local_sums[C + c]; g1 = global_sums[c]; g2 = global_sums[C + c]; }
+  __shared__ double sh[512];
+  const int c0 = blockIdx.x * kSlotCh;
+  double l1 = 0.0, l2 = 0.0, g1, g2;
+  if (partial) slot_sums(partial, nslot, C, c0, sh, l1, l2);     // single replica: local == global
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x >= 32 || c >= C) return;
+  if (partial) { g1 = l1; g2 = l2; }
+  else { l1 = local_sums[c]; l2 = local_sums[C + c]; g1 = global_sums[c]; g2 = global_sums[C + c]; }
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)l1;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)l2;
   c1[c] = (float)(g1 / count);
@@ -297,12 +328,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
 
 }  // namespace
 
+static int bwd_reduce_grid(long long rows, int C, int epc, int* rows_per_block) {
+  const int cpr = C / epc;
+  const int rl = max(1, 256 / min(cpr, 256));
+  // ~2048 workgroups, fewer for wide layers so that the [slots][2][C] partial buffer stays around 2 M floats
+  const long long want_blocks = max(256ll, min(2048ll, (1ll << 20) / max(C, 1)));
+  *rows_per_block = (int)max((long long)rl * 4, (rows + want_blocks - 1) / want_blocks);
+  return ceil_div(rows, *rows_per_block);
+}
+
 extern "C" {
+
+// slots that make simclr_bn_bwd_reduce deterministic (one per workgroup)
+int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype) {
+  int rpb;
+  return bwd_reduce_grid(rows, C, dtype == SIMCLR_DT_BF16 ? 8 : 4, &rpb);
+}
 
 // partial [nslot][2][C] fp32 -> sums [2][C] fp64 (the buffer the host all-reduces)
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, hipStream_t stream) {
   SIMCLR_CHECK_ARG(nslot > 0 && C > 0, "bn_reduce_slots: bad shape");
-  hipLaunchKernelGGL(bn_reduce_slots, dim3(ceil_div(2 * C, 256)), dim3(256), 0, stream, partial, nslot, C, sums);
+  hipLaunchKernelGGL(bn_reduce_slots, dim3(ceil_div(C, kSlotCh)), dim3(256), 0, stream, partial, nslot, C, sums);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -316,7 +362,7 @@ int simclr_bn_finalize(const double* sums, const float* partial, int nslot, doub
                        hipStream_t stream) {
   SIMCLR_CHECK_ARG(C > 0 && count > 0, "bn_finalize: bad shape");
   SIMCLR_CHECK_ARG((sums != nullptr) != (partial != nullptr), "bn_finalize: give sums OR partial slots");
-  hipLaunchKernelGGL(bn_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, partial, nslot, count, C,
+  hipLaunchKernelGGL(bn_finalize, dim3(ceil_div(C, kSlotCh)), dim3(256), 0, stream, sums, partial, nslot, count, C,
                      gamma, beta, moving_mean, moving_var, decay, eps, mean, rstd, scale, shift);
   SIMCLR_CHECK_LAUNCH();
   return 0;
@@ -356,18 +402,16 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
   return 0;
 }
 
-// partial [nslot][2][C] must be zeroed by the caller.
+// partial [nslot][2][C] must be zeroed by the caller.  nslot >= simclr_bn_bwd_reduce_slots(rows, C, dtype): one slot
+// per workgroup, plain stores, run-to-run deterministic; fewer: float atomics into slot (workgroup % nslot).
 int simclr_bn_bwd_reduce(const void* dy, const void* x, const void* mask_src, const float* scale,
                          const float* shift, const float* mean, const float* rstd, long long rows, int C,
                          int mask_mode, float* partial, int nslot, int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_reduce: C=%d must be a multiple of %d", C, epc);
   SIMCLR_CHECK_ARG(mask_mode != 1 || mask_src, "bn_bwd_reduce: mask_mode 1 needs mask_src");
-  const int cpr = C / epc;
-  const int rl = max(1, 256 / min(cpr, 256));
-  long long want_blocks = 2048;
-  int rows_per_block = (int)max((long long)rl * 4, (rows + want_blocks - 1) / want_blocks);
-  const int grid = ceil_div(rows, rows_per_block);
+  int rows_per_block;
+  const int grid = bwd_reduce_grid(rows, C, epc, &rows_per_block);
   if (dtype == SIMCLR_DT_BF16)
     hipLaunchKernelGGL((bn_bwd_reduce<uint16_t>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)dy,
                        (const uint16_t*)x, (const uint16_t*)mask_src, scale, shift, mean, rstd, rows, C,
@@ -385,7 +429,7 @@ int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, 
                            float* c1, float* c2, hipStream_t stream) {
   SIMCLR_CHECK_ARG((local_sums != nullptr && global_sums != nullptr) != (partial != nullptr),
                    "bn_bwd_finalize: give (local, global) sums OR partial slots");
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(C, 256)), dim3(256), 0, stream, local_sums, global_sums,
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(C, kSlotCh)), dim3(256), 0, stream, local_sums, global_sums,
                      partial, nslot, count, C, dgamma, dbeta, accumulate, c1, c2);
   SIMCLR_CHECK_LAUNCH();
   return 0;

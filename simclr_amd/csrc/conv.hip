@@ -803,12 +803,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       red[((tid / CPR) * BN + e_cc * 8 + e) * 2 + 1] = e_q[e];
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < p.N && count > 0) {
+    // nslot >= mslots (what simclr_conv2d_stats_slots returns): every workgroup owns slot `mslot` of its channels and
+    // stores its sums there -- no float atomics, so the statistics are bit-identical from run to run (idle
+    // workgroups store zeros).  Fewer slots: atomics into slot mslot % nslot (order-dependent rounding).
+    const bool own_slot = p.nslot >= mslots;
+    if (tid < BN && n0 + tid < p.N && (count > 0 || own_slot)) {
       float s1 = 0.f, s2 = 0.f;
       for (int w = 0; w < RPP; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
-      float* st = p.stats + (long long)(mslot % p.nslot) * 2 * p.N;
-      atomicAdd(st + n0 + tid, s1);
-      atomicAdd(st + p.N + n0 + tid, s2);
+      float* st = p.stats + (long long)(own_slot ? mslot : mslot % p.nslot) * 2 * p.N;
+      if (own_slot) { st[n0 + tid] = s1; st[p.N + n0 + tid] = s2; }
+      else { atomicAdd(st + n0 + tid, s1); atomicAdd(st + p.N + n0 + tid, s2); }
     }
     return;
   }
@@ -831,13 +835,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       }
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < p.N && count > 0) {
+    const bool own_slot = p.nslot >= mslots;       // see the BNEPI flush above
+    if (tid < BN && n0 + tid < p.N && (count > 0 || own_slot)) {
       float s = 0.f, ss = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; ss += red[(w * BN + tid) * 2 + 1]; }
-      float* st = p.stats + (long long)(mslot % p.nslot) * 2 * p.N;
-      atomicAdd(st + n0 + tid, s);
-      atomicAdd(st + p.N + n0 + tid, ss);
+      float* st = p.stats + (long long)(own_slot ? mslot : mslot % p.nslot) * 2 * p.N;
+      if (own_slot) { st[n0 + tid] = s; st[p.N + n0 + tid] = ss; }
+      else { atomicAdd(st + n0 + tid, s); atomicAdd(st + p.N + n0 + tid, ss); }
     }
   }
 }
@@ -1594,6 +1599,10 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
   T* __restrict__ Y = (T*)p.y;
   const int row_elems = p.KWP * 4;             // elements per kernel row
   const int ksteps = p.KP / KSTEP;
+  // nslot >= gridDim.x: the workgroup keeps its channel sums in registers over all its tiles (ascending order) and
+  // stores them once into its own slot -> deterministic statistics; otherwise per-tile atomics into slot mt % nslot
+  const bool own_slot = STATS && p.nslot >= (int)gridDim.x;
+  float own_s = 0.f, own_ss = 0.f;
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
     const int mw = mt * 128 + wave * 32;
     long long base[2];
@@ -1668,12 +1677,20 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { s += red[(w * BN + tid) * 2]; ss += red[(w * BN + tid) * 2 + 1]; }
-        float* st = p.stats + (long long)(mt % p.nslot) * 2 * p.N;
-        atomicAdd(st + n0 + tid, s);
-        atomicAdd(st + p.N + n0 + tid, ss);
+        if (own_slot) { own_s += s; own_ss += ss; }
+        else {
+          float* st = p.stats + (long long)(mt % p.nslot) * 2 * p.N;
+          atomicAdd(st + n0 + tid, s);
+          atomicAdd(st + p.N + n0 + tid, ss);
+        }
       }
       __syncthreads();
     }
+  }
+  if (own_slot && tid < BN && n0 + tid < p.N) {
+    float* st = p.stats + (long long)blockIdx.x * 2 * p.N;
+    st[n0 + tid] = own_s;
+    st[p.N + n0 + tid] = own_ss;
   }
 }
 
@@ -1748,6 +1765,21 @@ static const void* zero_page() {
   return zp;
 }
 
+// Persistent-grid geometry of conv_igemm_persistent for an [M, N] output: tile width, N-tiles, grid size.
+// 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one workgroup per tile.
+static void igemm_persistent_grid(long long M, int N, int* bn, int* n_tiles, int* grid) {
+  const int BN = (N <= 64) ? 64 : 128;
+  const int m_tiles = (int)((M + 127) / 128);
+  const int nt = ceil_div(N, BN);
+  const int unit = 8 * nt;
+  const int resident = (BN == 64 ? 3 : 2) * 256;      // workgroups that fit: LDS 48 KB / 64 KB each
+  int pg = (resident / unit) * unit;
+  if (pg < unit) pg = unit;
+  const int need = ceil_div(m_tiles, 8) * unit;       // enough workgroups to give every M-tile a slot
+  if (pg > need) pg = need;
+  *bn = BN; *n_tiles = nt; *grid = pg;
+}
+
 template <typename T, int MODE>
 void launch_igemm_one(ConvP p, hipStream_t stream) {
   const int BN = (p.N <= 64) ? 64 : 128;
@@ -1769,12 +1801,8 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     // alternatives that were slower on every ResNet-50 layer (profiles/r01_notes.md): 256x128 with 8
     // waves (one workgroup per CU), and 3-stage rings with counted vmcnt for either tile.
     // persistent grid: 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one per tile
-    const int unit = 8 * p.n_tiles;
-    const int resident = (BN == 64 ? 3 : 2) * 256;      // workgroups that fit: LDS 48 KB / 64 KB each
-    int pg = (resident / unit) * unit;
-    if (pg < unit) pg = unit;
-    const int need = ceil_div(p.m_tiles, 8) * unit;     // enough workgroups to give every M-tile a slot
-    if (pg > need) pg = need;
+    int bn_, nt_, pg;
+    igemm_persistent_grid(p.M, p.N, &bn_, &nt_, &pg);
     const size_t plds = 2 * (128 + BN) * 128 + 4 * BN * sizeof(float) + 128 * sizeof(long long);
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
@@ -1847,9 +1875,21 @@ int launch_igemm(const ConvP& p0, hipStream_t stream) {
 
 extern "C" {
 
+// Number of partial-statistics slots that makes the statistics of simclr_conv2d_fwd / simclr_conv2d_dgrad_bn
+// deterministic for an output of M rows x C channels (one slot per persistent workgroup of an N-tile).
+int simclr_conv2d_stats_slots(long long M, int C) {
+  int bn, nt, pg;
+  igemm_persistent_grid(M, C, &bn, &nt, &pg);
+  return pg / nt;
+}
+// same for simclr_stem_conv_fwd (M = V*OH*OW output pixels)
+int simclr_stem_stats_slots(long long M) { return (int)min((M + 127) / 128, 2048ll); }
+
 // Forward conv / dense.  x [V,IH,IW,Cin] (T), w_t [Cout][KH*KW*Cin] (T), y [V,OH,OW,Cout] (T).
 // stats (nullable): float [nslot][2][Cout], must be zeroed by the caller; receives
-// per-channel partial (sum, sum of squares) of the fp32 results (BatchNorm statistics).
+// per-channel partial (sum, sum of squares) of the fp32 results (BatchNorm statistics).  With
+// nslot >= simclr_conv2d_stats_slots(V*OH*OW, Cout) every workgroup stores into its own slot (no float
+// atomics): the statistics are bit-identical from run to run, like the reference's (tf2/resnet.py:54-60).
 int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V,
                       int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
                       int pad, int dtype, hipStream_t stream) {

@@ -30,13 +30,14 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
   }
 }
 
-// norms[2t] += sum w^2 ; norms[2t+1] += sum u^2 with u = g + wd*w (classic) or
-// u = momentum*v + g (+ nesterov) (popular momentum, lars_optimizer.py:117-126)
+// Per-chunk partial squared norms: part[2c] = sum w^2, part[2c+1] = sum u^2 over chunk c, with u = g + wd*w (classic)
+// or u = momentum*v + g (+ nesterov) (popular momentum, lars_optimizer.py:117-126).  Plain stores, no atomics: the
+// update kernel adds a tensor's partials in chunk order, so the trust ratio is bit-identical from run to run.
 __global__ __launch_bounds__(256) void lars_norms(const long long* __restrict__ table, int T,
                                                   const long long* __restrict__ chunks,
                                                   float weight_decay, float momentum,
                                                   int classic, int nesterov,
-                                                  double* __restrict__ norms) {
+                                                  double* __restrict__ part) {
   __shared__ double sh[8];
   const int t = (int)chunks[2 * blockIdx.x];
   const long long off = chunks[2 * blockIdx.x + 1];
@@ -58,8 +59,8 @@ __global__ __launch_bounds__(256) void lars_norms(const long long* __restrict__ 
   }
   block_sum2(sw, su, sh);
   if (threadIdx.x == 0) {
-    atomicAdd(&norms[2 * t], sw);
-    atomicAdd(&norms[2 * t + 1], su);
+    part[2 * blockIdx.x] = sw;
+    part[2 * blockIdx.x + 1] = su;
   }
 }
 
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void lars_update(const long long* __restrict__
                                                    const float* __restrict__ lr_ptr, float lr_val,
                                                    float weight_decay, float momentum, float eeta,
                                                    int classic, int nesterov,
-                                                   const double* __restrict__ norms) {
+                                                   const double* __restrict__ part) {
+  __shared__ double red[2 * 256];
   const int t = (int)chunks[2 * blockIdx.x];
   const long long off = chunks[2 * blockIdx.x + 1];
   const int flags = (int)table[4 * T + t];
@@ -80,8 +82,21 @@ __global__ __launch_bounds__(256) void lars_update(const long long* __restrict__
   const float lr = lr_ptr ? *lr_ptr : lr_val;
   float trust = 1.0f;
   if (flags & 2) {  // lars_optimizer.py:101-107 / :124-130
-    const float wn = (float)sqrt(norms[2 * t]);
-    const float un = (float)sqrt(norms[2 * t + 1]);
+    // this tensor's chunks are consecutive in the chunk list: the first one is (off / kChunk) entries back.
+    // Fixed summation order: thread i adds partials i, i+256, ... ; then a fixed binary tree over the 256 threads.
+    const long long first = (long long)blockIdx.x - off / kChunk;
+    const long long nch = (numel + kChunk - 1) / kChunk;
+    double a = 0.0, b = 0.0;
+    for (long long c = threadIdx.x; c < nch; c += 256) { a += part[2 * (first + c)]; b += part[2 * (first + c) + 1]; }
+    red[threadIdx.x] = a;
+    red[256 + threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) { red[threadIdx.x] += red[threadIdx.x + s]; red[256 + threadIdx.x] += red[256 + threadIdx.x + s]; }
+      __syncthreads();
+    }
+    const float wn = (float)sqrt(red[0]);
+    const float un = (float)sqrt(red[256]);
     if (wn > 0.f && un > 0.f) trust = eeta * wn / un;
   }
   const float slr = lr * trust;  // :108 / :131
@@ -109,16 +124,15 @@ extern "C" {
 
 int simclr_lars_chunk_elems(void) { return kChunk; }
 
-// norms: device double[2*T] scratch (zeroed here).  lr_dev may be NULL (then lr is used);
-// a device-resident lr lets a captured hipGraph replay with a new learning rate.
+// norms: device double[2*num_chunks] scratch (per-chunk partial squared norms; every used entry is rewritten by the
+// call).  lr_dev may be NULL (then lr is used); a device-resident lr lets a captured hipGraph replay with a new
+// learning rate.
 int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long long* chunks,
                              int num_chunks, const float* lr_dev, float lr, float momentum,
                              float weight_decay, float eeta, int classic_momentum, int use_nesterov,
                              double* norms, hipStream_t stream) {
   SIMCLR_CHECK_ARG(num_tensors > 0 && num_chunks > 0, "lars: empty tensor list");
   SIMCLR_CHECK_ARG(table && chunks && norms, "lars: null table/chunks/norms");
-  hipError_t e = hipMemsetAsync(norms, 0, sizeof(double) * 2 * num_tensors, stream);
-  SIMCLR_CHECK_ARG(e == hipSuccess, "lars: memset failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(lars_norms, dim3(num_chunks), dim3(256), 0, stream, table, num_tensors, chunks,
                      weight_decay, momentum, classic_momentum, use_nesterov, norms);
   SIMCLR_CHECK_LAUNCH();

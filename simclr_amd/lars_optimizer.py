@@ -128,7 +128,7 @@ class LARSOptimizer:
         dev = variables[0].value.device
         self._table = table.to(dev)
         self._chunks = torch.tensor(chunks, dtype=torch.int64).view(-1).to(dev)
-        self._norms = torch.zeros(2 * T, dtype=torch.float64, device=dev)
+        self._norms = torch.zeros(2 * len(chunks), dtype=torch.float64, device=dev)   # per-chunk partial norms
         self._num = (T, len(chunks))
         self._key = tuple((v.value.data_ptr(), g.data_ptr()) for v, g in zip(variables, grads))
 

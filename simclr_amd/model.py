@@ -134,7 +134,7 @@ class LinearLayer(Layer):  # tf2/model.py:119-154
             self.build(cin)
         self._refresh(inputs.dtype)
         x4 = inputs.view(V, 1, 1, cin)
-        stats = ops.new_stats(self.npad, RT.device) if (self.use_bn and training) else None
+        stats = ops.conv_stats(V, self.npad, RT.device) if (self.use_bn and training) else None
         y = ops.conv2d_fwd(x4, self.w_t, 1, 1, 1, 0, 1, 1, stats=stats).view(V, self.npad)
         self.saved = dict(x=x4)
         if self.use_bn:

@@ -10,7 +10,7 @@ import torch
 
 from ._lib import DT_BF16, DT_F32, lib
 
-NSLOT = 32  # partial-statistics slots (spreads atomic contention; summed by bn_reduce_slots)
+NSLOT = 32  # default slot count of hand-filled statistics buffers (tests); producers ask the library (conv_stats_slots ...)
 
 
 class KernelProfiler:
@@ -160,7 +160,7 @@ def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None):
     M, K = V * OH * OW, KH * KW * Cin
     esz = x.element_size()
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, esz * (V * IH * IW * Cin + M * Cout + K * Cout),
-            lambda: lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), NSLOT if stats is not None else 0, V,
+            lambda: lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0] if stats is not None else 0, V,
                                      IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
     return out
 
@@ -187,14 +187,14 @@ def conv2d_dgrad_bn(dy, w_d, KH, KW, pad, IH, IW, bn, out=None, accumulate=False
     if out is None:
         assert not accumulate
         out = torch.empty(V, IH, IW, Cin, device=dy.device, dtype=dy.dtype)
-    partial = new_stats(Cin, dy.device)
+    partial = conv_stats(V * IH * IW, Cin, dy.device)
     K = KH * KW * Cout
     esz = dy.element_size()
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + V * IH * IW * Cin + K * Cin),
             impl_bytes=esz * (V * OH * OW * Cout + (2 + (bn['mode'] == 1) + int(accumulate)) * V * IH * IW * Cin + K * Cin),
             fn=lambda: lib().conv2d_dgrad_bn(_p(dy), _p(w_d), _p(out), int(accumulate), _p(bn['x']), _p(bn.get('mask')),
                                           _p(bn.get('scale')), _p(bn.get('shift')), _p(bn['mean']), _p(bn['rstd']),
-                                          bn['mode'], _p(partial), NSLOT, V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
+                                          bn['mode'], _p(partial), partial.shape[0], V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
                                           pad, dt(dy), _s()))
     return out, partial
 
@@ -259,7 +259,7 @@ def stem_conv_fwd(xp, w_s, geo, stride, stats=None):
     y = torch.empty(V, geo['OH'], geo['OW'], Cout, device=xp.device, dtype=xp.dtype)
     M = V * geo['OH'] * geo['OW']
     _launch('stem_conv_fwd', 2.0 * M * 147 * Cout, xp.element_size() * (xp.numel() + M * Cout),
-            lambda: lib().stem_conv_fwd(_p(xp), _p(w_s), _p(y), _p(stats), NSLOT if stats is not None else 0, V,
+            lambda: lib().stem_conv_fwd(_p(xp), _p(w_s), _p(y), _p(stats), stats.shape[0] if stats is not None else 0, V,
                                         geo['HP'], geo['WP'], geo['OH'], geo['OW'], Cout, geo['KHP'], geo['KWP'],
                                         stride, dt(xp), _s()))
     return y
@@ -286,20 +286,30 @@ class _StatsArena:
     def __init__(self):
         self.buf = None
         self.ptr = 0
+        self.high = 0
+        self.missed = 0
+        self.want = 0
 
-    def begin_step(self, device, nfloats=8 << 20):
-        if self.buf is None or self.buf.device != torch.device(device):
-            self.buf = torch.zeros(nfloats, device=device, dtype=torch.float32)
+    def begin_step(self, device, nfloats=32 << 20):
+        want = max(nfloats, getattr(self, 'want', 0))
+        if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < want:
+            self.buf = torch.zeros(want, device=device, dtype=torch.float32)
         else:
-            self.buf.zero_()
+            self.buf[:max(self.high, 1)].zero_()       # only what the previous step handed out
         self.ptr = 0
+        self.high = 0
+        self.missed = 0
 
     def take(self, n, device):
         n_al = (n + 63) // 64 * 64
         if self.buf is None or self.buf.device != torch.device(device) or self.ptr + n_al > self.buf.numel():
+            if self.buf is not None and self.ptr < (1 << 60):
+                self.missed += n_al                        # arena too small: grow it for the next step
+                self.want = self.buf.numel() + 2 * self.missed
             return None
         out = self.buf[self.ptr:self.ptr + n]
         self.ptr += n_al
+        self.high = max(self.high, self.ptr)
         return out
 
 
@@ -316,11 +326,22 @@ def end_step():
     _ARENA.ptr = 1 << 62
 
 
-def new_stats(C, device):
-    t = _ARENA.take(NSLOT * 2 * C, device)
+def new_stats(C, device, slots=NSLOT):
+    """Zeroed partial-statistics buffer [slots, 2, C] (from the per-step arena when inside a step)."""
+    t = _ARENA.take(slots * 2 * C, device)
     if t is None:
-        return torch.zeros(NSLOT, 2, C, device=device, dtype=torch.float32)
-    return t.view(NSLOT, 2, C)
+        return torch.zeros(slots, 2, C, device=device, dtype=torch.float32)
+    return t.view(slots, 2, C)
+
+
+def conv_stats(M, C, device):
+    """Statistics buffer for conv2d_fwd / conv2d_dgrad_bn over an [M, C] output with one slot per producing workgroup
+    (simclr_conv2d_stats_slots): plain stores instead of float atomics -> run-to-run deterministic BatchNorm."""
+    return new_stats(C, device, lib().conv2d_stats_slots(M, C))
+
+
+def stem_stats(M, C, device):
+    return new_stats(C, device, lib().stem_stats_slots(M))
 
 
 def bn_reduce_slots(partial):
@@ -358,9 +379,9 @@ def bn_apply(x, scale, shift, relu, res=None, rscale=None, rshift=None, out=None
 def bn_bwd_reduce(dy, x, mask_src, scale, shift, mean, rstd, mask_mode):
     C = x.shape[-1]
     rows = x.numel() // C
-    partial = new_stats(C, x.device)
+    partial = new_stats(C, x.device, lib().bn_bwd_reduce_slots(rows, C, dt(x)))
     lib().bn_bwd_reduce(_p(dy), _p(x), _p(mask_src), _p(scale), _p(shift), _p(mean), _p(rstd), rows, C,
-                        mask_mode, _p(partial), NSLOT, dt(x), _s())
+                        mask_mode, _p(partial), partial.shape[0], dt(x), _s())
     return partial
 
 

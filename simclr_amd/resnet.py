@@ -383,7 +383,8 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             if self.kernel is None:
                 self.build(3)
             self._refresh(inputs.geo)
-            stats = ops.new_stats(self.cout_p, RT.device) if (want_stats and training) else None
+            stats = (ops.stem_stats(inputs.V * inputs.geo['OH'] * inputs.geo['OW'], self.cout_p, RT.device)
+                     if (want_stats and training) else None)
             y = ops.stem_conv_fwd(inputs.xp, self.w_s, inputs.geo, s, stats=stats)
             self.saved = dict(packed=inputs)
             return Act(y, stats, c=self.filters)
@@ -395,7 +396,7 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         pad = (k - 1) // 2                                  # FixedPadding / SAME at stride 1
         OH = (H + (k - 1) - k) // s + 1
         OW = (W + (k - 1) - k) // s + 1
-        stats = ops.new_stats(self.cout_p, RT.device) if (want_stats and training) else None
+        stats = ops.conv_stats(V * OH * OW, self.cout_p, RT.device) if (want_stats and training) else None
         y = ops.conv2d_fwd(x, self.w_t, k, k, s, pad, OH, OW, stats=stats)
         self.saved = dict(x=x, H=H, W=W, pad=pad)
         return Act(y, stats, c=self.filters)

@@ -327,3 +327,11 @@ def test_hand_derived_batch_norm_on_device():
     assert np.abs(dbeta.cpu().numpy()[:C] - bwd['dbeta']).max() < 1e-5
     # dx is O(eps) here: absolute tolerance at fp32 cancellation level of its O(1) terms
     assert np.abs(dx.cpu().numpy()[:, :C] - bwd['dx']).max() < 2e-6
+
+
+@pytest.mark.parametrize('depth,size,batch,dtype', [(18, 32, 16, 'bf16'), (50, 64, 8, 'f32'), (50, 64, 8, 'bf16')])
+def test_training_step_is_bitwise_deterministic(depth, size, batch, dtype):
+    """fixed-order statistic reductions -- two runs of the same steps give identical bits."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_step_determinism(depth=depth, image_size=size, batch=batch, compute_dtype=dtype,
+                                      num_classes=10 if size <= 32 else 1000))

@@ -90,7 +90,7 @@ def main():
         y = torch.empty(V, H, H, Cout, device=dev, dtype=dt)
         dx = torch.randn(V, H, H, Cin, device=dev).to(dt)
         dw = torch.empty(k * k * Cin, Cout, device=dev)
-        stats = ops.new_stats(Cout, dev)
+        stats = ops.conv_stats(V * H * H, Cout, dev)
         sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
         mean = torch.randn(Cin, device=dev) * 0.1; rstd = torch.rand(Cin, device=dev) + 0.5
         bn2 = dict(x=x, mask=None, scale=sc, shift=sh, mean=mean, rstd=rstd, mode=2)

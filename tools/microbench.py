@@ -71,7 +71,7 @@ def main():
             y = torch.empty(V, OH, OH, Cout, device=dev, dtype=dt)
             dx = torch.empty(V, H, H, Cin, device=dev, dtype=dt)
             dw = torch.empty(k * k * Cin, Cout, device=dev)
-            stats = ops.new_stats(Cout, dev)
+            stats = ops.conv_stats(V * OH * OH, Cout, dev)
             t_f = timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=stats, out=y), args.iters)
             t_n = timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=None, out=y), args.iters)
             t_d = timeit(lambda: ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H, out=dx), args.iters)
