@@ -72,7 +72,11 @@ def cpu_baseline():
     from oracle import ntxent as ont
     from oracle.model_torch import Config, init_model, train_step
     torch.manual_seed(0)
-    cores = torch.get_num_threads()
+    # 16 threads: on the 128-core GPU host the small CIFAR-sized convolutions run SLOWER with all cores (14.6 images/s
+    # at 128 threads vs the 8-core build container's 20.4) -- thread oversubscription, not a property of the algorithm
+    prev = torch.get_num_threads()
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
 
     def model_step(depth, size, b, classes, budget, max_steps):
         cfg = Config(resnet_depth=depth, image_size=size, num_classes=classes)
@@ -109,6 +113,7 @@ def cpu_baseline():
             olars.lars_apply(name, w, g, m, 0.3, momentum=0.9, weight_decay=1e-6,
                              exclude_from_weight_decay=['batch_normalization', 'bias', 'head_supervised'])
     k, dt = _timed_steps(lars_all, 2.0, 20)
+    torch.set_num_threads(prev)
     out['lars_per_tensor'] = dict(us=round(dt / k * 1e6, 1), elems=nel, gbps=round(28.0 * nel * k / dt / 1e9, 2),
                                   sample='%d x oracle/lars.py lars_apply over %d tensors (numpy float64), %.1f s' % (k, len(ts), dt))
     return out
