@@ -193,6 +193,16 @@ int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out
 int simclr_axpy_f32(float a, const float* x, float* y, long long n, simclr_stream_t stream);
 int simclr_l2_loss_f32(const float* x, long long n, float* out, simclr_stream_t stream); /* tf.nn.l2_loss, model.py:49-60 */
 
+/* ---- two-view training augmentation on the device: tf2/data_util.py:443-475 (preprocess_for_train: random-resized-crop
+ * with bicubic resize :246-320/:362-377, random flip :463, colour jitter in random order :54-173/:380-389, random grayscale
+ * :48-52, clip :473-474) for every image and both views of tf2/data.py:52-62.  The random draws come from the caller as
+ * params [b][views][16] = {crop_y, crop_x, crop_h, crop_w, flip, jitter_on, perm[4], brightness, contrast, saturation,
+ * hue_delta, gray_on, 0}; src [b,Hs,Ws,3] float32 in [0,1] (src_dtype 0) or uint8 (src_dtype 2); out [b,H,W,3*views]
+ * float32 in [0,1], the layout Model.__call__ (tf2/model.py:241-259) consumes. ---- */
+size_t simclr_augment_workspace_bytes(int b, int views, int H, int W);
+int simclr_augment_views(const void* src, int src_dtype, const float* params, void* workspace, float* out, int b,
+                         int views, int Hs, int Ws, int H, int W, simclr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -530,3 +530,23 @@ def axpy_f32(a, x, y):
 
 def l2_loss_f32(x, out):
     lib().l2_loss_f32(_p(x), x.numel(), _p(out), _s())
+
+
+# ---------------------------------------------------------------- two-view augmentation
+def augment_views(src, params, H, W, out=None):
+    """src [b, Hs, Ws, 3] float32 in [0,1] or uint8; params [b, views, 16] float32 (simclr_amd.data_util.PARAM_FIELDS).
+    Returns [b, H, W, 3*views] float32 in [0,1]."""
+    b, Hs, Ws, C = src.shape
+    assert C == 3 and params.dtype == torch.float32 and params.shape[0] == b and params.shape[2] == 16
+    views = params.shape[1]
+    if src.dtype == torch.uint8:
+        code = 2
+    elif src.dtype == torch.float32:
+        code = DT_F32
+    else:
+        raise TypeError('augment_views: source images must be uint8 or float32, got %s' % src.dtype)
+    if out is None:
+        out = torch.empty(b, H, W, 3 * views, device=src.device, dtype=torch.float32)
+    ws = _workspace(lib().augment_workspace_bytes(b, views, H, W), src.device, key='augment')
+    lib().augment_views(_p(src), code, _p(params), _p(ws), _p(out), b, views, Hs, Ws, H, W, _s())
+    return out
