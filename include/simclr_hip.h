@@ -159,6 +159,8 @@ int simclr_maxpool_bwd(const void* dy, const unsigned char* arg, void* dx, int V
                        simclr_stream_t stream);
 int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int dtype,
                               simclr_stream_t stream);
+int simclr_global_avgpool_fwd_f32(const void* x, float* y32, int V, int HW, int C, int dtype,
+                                  simclr_stream_t stream);   /* same mean, float32 output (input of fp32 heads) */
 int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, int V, int HW, int C,
                               int dtype, simclr_stream_t stream);
 

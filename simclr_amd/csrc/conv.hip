@@ -876,7 +876,9 @@ template <typename T> __device__ __forceinline__ int px_key(int px) {
   return sizeof(T) == 2 ? ((px & 3) | (((px >> 3) & 1) << 2)) : (px & 7);
 }
 
-template <typename T, int BKW, int BNW>
+// MT (multi-tap k-tile): the BKW rows of the tile span SEVERAL taps of IC < BKW channels each (the stem: 7 kernel rows x 32
+// packed elements = 224 rows in one 256-row tile), so the gradient tensor is read once instead of once per tap.
+template <typename T, int BKW, int BNW, bool MT = false>
 __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BR = 8 * EPC;                 // pixels per reduction chunk (64 bf16 / 32 f32)
@@ -958,7 +960,21 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
       const int px = id / A_CPR, cc = id % A_CPR;
       const int m = mbase + px;
       ra[j] = zero16();
-      if (m < p.M) {
+      if (MT) {
+        const int kidx = kk0 + cc * EPC;                 // this chunk's own tap / channel offset
+        if (m < p.M && kidx < p.K) {
+          const int tapc = kidx / p.IC, cic = kidx - tapc * p.IC;
+          const int tyc = tapc / p.KW, txc = tapc - tyc * p.KW;
+          int v = vbase, rem = rbase + px;
+          if (rem >= ohow) { rem -= ohow; ++v; }
+          if (rem >= ohow) { rem -= ohow; ++v; }
+          if (rem >= ohow) { v = m / ohow; rem = m - v * ohow; }
+          const int oy = (int)(((float)rem + 0.5f) * inv_ow), ox = rem - oy * p.OW;
+          const int iy = oy * p.stride - p.pad + tyc, ix = ox * p.stride - p.pad + txc;
+          if ((unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+            ra[j] = ld16(X + (((long long)v * p.IH + iy) * p.IW + ix) * p.pixpitch + cic);
+        }
+      } else if (m < p.M) {
         if (flat) {
           ra[j] = ld16(X + (long long)m * p.pixpitch + ci0 + cc * EPC);
         } else {
@@ -1976,24 +1992,25 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
 size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int Cout, int KH, int KW,
                                            int dtype);
 
-static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int* chunks_per_split) {
-  const int tiles = (K / bkw) * ceil_div(N, bnw);
+static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int* chunks_per_split, int cap = 256,
+                        int want = 0) {
+  const int tiles = ceil_div(K, bkw) * ceil_div(N, bnw);
   const int nchunks = ceil_div(M, br);
   // ~1024-2048 workgroups in total; a multiple of 8 pixel ranges so that the XCD-aware mapping (one
   // pixel range per XCD at a time) keeps all 8 XCDs equally loaded
   static const int target_env = getenv("SIMCLR_WGRAD_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD_BLOCKS")) : 1536;
   // 256 x 256 tiles run one 8-wave workgroup per CU: two rounds of 256 instead of three rounds of 512
-  const int target = bkw == 256 ? 512 : target_env;
+  const int target = want > 0 ? want : (bkw == 256 ? 512 : target_env);
   int splits = max(1, min(nchunks, target / max(1, tiles)));
   if (nchunks >= 8) splits = min(nchunks / 8 * 8, max(8, (splits + 7) / 8 * 8));
-  splits = min(splits, 256);
+  splits = min(splits, cap);
   *chunks_per_split = ceil_div(nchunks, splits);
   int eff = ceil_div(nchunks, *chunks_per_split);
   // keep the effective split count a multiple of 8 when possible
   while (nchunks >= 8 && eff % 8 != 0 && *chunks_per_split > 1) {
     --*chunks_per_split;
     eff = ceil_div(nchunks, *chunks_per_split);
-    if (eff > 256) { ++*chunks_per_split; eff = ceil_div(nchunks, *chunks_per_split); break; }
+    if (eff > cap) { ++*chunks_per_split; eff = ceil_div(nchunks, *chunks_per_split); break; }
   }
   return eff;
 }
@@ -2040,6 +2057,8 @@ size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int C
   splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, 32, &cps));
   if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0)      // experimental multi-tap kernel: 64x64 tiles of all taps
     splits = max(splits, wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 64, &cps));
+  if (Cin == 32 && KH * KW * Cin <= 256 && Cout <= 64)            // stem: one 256-row k-tile, up to 1024 pixel ranges
+    splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, 256, 64, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps, 1024, 1024));
   return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
 }
 
@@ -2079,6 +2098,10 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   int bkw, bnw;
   wgrad_tile(Cin, Cout, dtype, p.M, KH * KW, &bkw, &bnw);
   if ((pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0 && bkw == 256) { bkw = 128; bnw = 128; }
+  // stem (packed input, 32 elements per kernel row): all kernel rows in ONE 256-row k-tile, so dY is read once
+  static const bool stem_mt_on = !getenv("SIMCLR_STEM_WGRAD_MT") || atoi(getenv("SIMCLR_STEM_WGRAD_MT")) != 0;
+  const bool stem_mt = stem_mt_on && bkw == 32 && Cin == 32 && p.K <= 256 && Cout <= 64;
+  if (stem_mt) { bkw = 256; bnw = 64; }
   // kernel variant: 1 = LDS-DMA ring, 64-pixel chunks x 2 stages; 2 = 32-pixel chunks x 3 stages for the
   // 128x128 tile (3 workgroups/CU), 3 stages elsewhere; 3 = 32-pixel chunks x 4 stages; 0 = register-staged
   // kernel (kept for A/B runs: SIMCLR_WGRAD_CFG).
@@ -2090,15 +2113,16 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   int cfg = cfg_env >= 0 ? cfg_env : 1;
   if (dtype != SIMCLR_DT_BF16 && cfg > 1) cfg = 1;
   // the stem's packed input (pixel pitch 4 elements) gives 8-byte-aligned sources: keep the register-staged kernel
-  if (bkw == 32 || (pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0) cfg = 0;
+  if (bkw == 32 || stem_mt || (pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0) cfg = 0;
   const bool big = bkw == 128 && bnw == 128;
-  const bool big256 = bkw == 256;
+  const bool big256 = bkw == 256 && !stem_mt;
   if (big256 && cfg == 0) cfg = 1;
   const int brm = ((cfg >= 2 && big) || big256) ? 1 : 2;
   const int stages = big256 ? 4 : (cfg <= 1 ? 2 : (big ? (cfg == 2 ? 3 : 4) : 3));
   const int br = (dtype == SIMCLR_DT_BF16 ? 32 : 16) * brm;
-  p.splits = wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split);
-  p.k_tiles = p.K / bkw;
+  p.splits = stem_mt ? wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split, 1024, 1024)
+                     : wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split);
+  p.k_tiles = ceil_div(p.K, bkw);
   p.n_tiles = ceil_div(p.N, bnw);
   // XCD-aware mapping: with the LDS-DMA kernel a win (or neutral) on every ResNet-50 layer; the register-staged
   // kernel (cfg 0: stem) keeps the old size rule
@@ -2116,6 +2140,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
 #define LD(TT, A, B, M_, S_) hipLaunchKernelGGL((conv_wgrad_dma<TT, A, B, M_, S_>), dim3(grid), dim3(256), lds, stream, p)
   if (big256) {
     hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 256, 1, 4, 2, 4>), dim3(grid), dim3(512), lds, stream, p);
+  } else if (stem_mt) {
+    if (dtype == SIMCLR_DT_BF16) hipLaunchKernelGGL((conv_wgrad<uint16_t, 256, 64, true>), dim3(grid), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad<float, 256, 64, true>), dim3(grid), dim3(256), lds, stream, p);
   } else if (cfg == 0) {
     if (dtype == SIMCLR_DT_BF16) {
       if (bkw == 128 && bnw == 128) LW(uint16_t, 128, 128);

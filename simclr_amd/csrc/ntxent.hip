@@ -143,43 +143,64 @@ __global__ __launch_bounds__(256) void ntxent_fwd_partial(
 }
 
 // ------------------------------------------------------------------------------
-// Finalize: merge splits, per-row lse (base 2), loss and contrast accuracy.
-// row_stats[row] = {lse_full2, lse_ab2};  out[0]=loss, out[1]=contrast_acc
-// Single workgroup (2n <= a few thousand rows); deterministic reduction order.
+// Finalize, part 1: merge the key splits of every query row -- 16 lanes per row (lane j merges splits j, j+16, ...;
+// a fixed xor-shuffle tree joins them), 16 rows per 256-thread workgroup.  Writes row_stats[row] = {lse_full2, lse_ab2}
+// and rowterm[row] = {loss term, arg-max hit}.  Part 2 (ntxent_reduce_out) adds the row terms in a fixed order:
+// out[0] = loss, out[1] = contrast_acc.  (The former single-workgroup finalize serialised 2n * nsplit dependent loads.)
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ntxent_finalize(const float* __restrict__ part, int nsplit,
-                                                       int rows_pad, int n, int N, int rank,
-                                                       float* __restrict__ row_stats,
-                                                       float* __restrict__ out) {
+__global__ __launch_bounds__(256) void ntxent_finalize_rows(const float* __restrict__ part, int nsplit,
+                                                            int rows_pad, int n, int N, int rank,
+                                                            float* __restrict__ row_stats,
+                                                            float* __restrict__ rowterm) {
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int j = threadIdx.x & 15;
+  float m0 = -INFINITY, l0 = 0.f, m1 = -INFINITY, l1 = 0.f, pos = -INFINITY, av = -INFINITY;
+  int ai = 0x7fffffff;
+  if (q < 2 * n) {
+    for (int s = j; s < nsplit; s += 16) {
+      const float4 a = *(const float4*)(part + ((size_t)s * rows_pad + q) * kPartStride);
+      const float4 b = *(const float4*)(part + ((size_t)s * rows_pad + q) * kPartStride + 4);
+      ml_merge(m0, l0, a.x, a.y);
+      ml_merge(m1, l1, a.z, a.w);
+      pos = fmaxf(pos, b.x);
+      arg_merge(av, ai, b.y, __float_as_int(b.z));
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    float om0 = __shfl_xor(m0, o, 64), ol0 = __shfl_xor(l0, o, 64);
+    float om1 = __shfl_xor(m1, o, 64), ol1 = __shfl_xor(l1, o, 64);
+    float op = __shfl_xor(pos, o, 64), oav = __shfl_xor(av, o, 64);
+    int oai = __shfl_xor(ai, o, 64);
+    ml_merge(m0, l0, om0, ol0);
+    ml_merge(m1, l1, om1, ol1);
+    pos = fmaxf(pos, op);
+    arg_merge(av, ai, oav, oai);
+  }
+  if (j == 0 && q < 2 * n) {
+    const float lse_ab2 = m1 + log2f(l1);
+    float mf = m0, lf = l0;
+    ml_merge(mf, lf, m1, l1);
+    const float lse2 = mf + log2f(lf);
+    row_stats[2 * q] = lse2;
+    row_stats[2 * q + 1] = lse_ab2;
+    int mask_col, pos_col;
+    row_cols(q, n, N, rank, mask_col, pos_col);
+    rowterm[2 * q] = (lse2 - pos) * kLn2;
+    rowterm[2 * q + 1] = (q < n && ai == pos_col) ? 1.f : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ntxent_reduce_out(const float* __restrict__ rowterm, int n, float* __restrict__ out) {
   __shared__ double sh_loss[256];
   __shared__ double sh_hit[256];
   double loss = 0.0, hit = 0.0;
-  for (int q = threadIdx.x; q < 2 * n; q += 256) {
-    float m0 = -INFINITY, l0 = 0.f, m1 = -INFINITY, l1 = 0.f, pos = -INFINITY, av = -INFINITY;
-    int ai = 0x7fffffff;
-    for (int s = 0; s < nsplit; ++s) {
-      const float* p = part + ((size_t)s * rows_pad + q) * kPartStride;
-      ml_merge(m0, l0, p[0], p[1]);
-      ml_merge(m1, l1, p[2], p[3]);
-      pos = fmaxf(pos, p[4]);
-      arg_merge(av, ai, p[5], __float_as_int(p[6]));
-    }
-    float lse_ab2 = m1 + log2f(l1);
-    float mf = m0, lf = l0;
-    ml_merge(mf, lf, m1, l1);
-    float lse2 = mf + log2f(lf);
-    row_stats[2 * q] = lse2;
-    row_stats[2 * q + 1] = lse_ab2;
-    loss += (double)((lse2 - pos) * kLn2);
-    int mask_col, pos_col;
-    row_cols(q, n, N, rank, mask_col, pos_col);
-    if (q < n && ai == pos_col) hit += 1.0;
-  }
+  for (int q = threadIdx.x; q < 2 * n; q += 256) { loss += (double)rowterm[2 * q]; hit += (double)rowterm[2 * q + 1]; }
   sh_loss[threadIdx.x] = loss;
   sh_hit[threadIdx.x] = hit;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
+    if ((int)threadIdx.x < s) {
       sh_loss[threadIdx.x] += sh_loss[threadIdx.x + s];
       sh_hit[threadIdx.x] += sh_hit[threadIdx.x + s];
     }
@@ -201,11 +222,10 @@ __global__ __launch_bounds__(256) void ntxent_finalize(const float* __restrict__
 // contrast-entropy term of tf2/metrics.py:33-35 (a rows, ab block only).
 // ------------------------------------------------------------------------------
 template <int D, bool FIXED_IS_QUERY>
-__global__ __launch_bounds__(256) void ntxent_bwd_sweep(
-    const float* __restrict__ fixed_mat, int fixed_rows, const float* __restrict__ stream_mat,
+__device__ __forceinline__ void ntxent_bwd_sweep_body(
+    float* lds, const float* __restrict__ fixed_mat, int fixed_rows, const float* __restrict__ stream_mat,
     int stream_rows, int n, int N, int rank, float scale2, const float* __restrict__ row_stats,
     int tiles_per_split, float* __restrict__ gpart, int rows_pad, float* __restrict__ epart) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* stats_s = lds + kTile * D;  // [64][2] row stats of the streamed queries (key-fixed mode)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fl = lane & 15;
@@ -304,38 +324,58 @@ __global__ __launch_bounds__(256) void ntxent_bwd_sweep(
   }
 }
 
-// out[row][:] = scale * sum_split gpart[split][row][:]   (+ optional add[row][:])
-__global__ void ntxent_combine(const float* __restrict__ gpart, int nsplit, int rows_pad, int rows,
-                               int D, float scale, const float* __restrict__ add,
-                               float* __restrict__ out) {
-  const int total = rows * (D / 4);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int r = i / (D / 4), c = i % (D / 4);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nsplit; ++s) {
-      float4 v = *(const float4*)(gpart + ((size_t)s * rows_pad + r) * D + c * 4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
-    if (add) {
-      float4 v = *(const float4*)(add + (size_t)r * D + c * 4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *(float4*)(out + (size_t)r * D + c * 4) = acc;
+// Both sweeps in ONE launch: blockIdx.z = 0 query-fixed (gradient wrt the local rows + the entropy term),
+// blockIdx.z = 1 key-fixed (gradient wrt the gathered rows).  They are independent, so they share the chip.
+template <int D>
+__global__ __launch_bounds__(256) void ntxent_bwd_sweeps(
+    const float* __restrict__ z_local, const float* __restrict__ z_all, int n, int N, int rank, float scale2,
+    const float* __restrict__ row_stats, int tiles_k, int tiles_q, float* __restrict__ gq, int rows_pad_q,
+    float* __restrict__ gk, int rows_pad_k, float* __restrict__ epart, int gxq, int gyq, int gxk, int gyk) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (blockIdx.z == 0) {
+    if ((int)blockIdx.x >= gxq || (int)blockIdx.y >= gyq) return;
+    ntxent_bwd_sweep_body<D, true>(lds, z_local, 2 * n, z_all, 2 * N, n, N, rank, scale2, row_stats, tiles_k, gq,
+                                   rows_pad_q, epart);
+  } else {
+    if ((int)blockIdx.x >= gxk || (int)blockIdx.y >= gyk) return;
+    ntxent_bwd_sweep_body<D, false>(lds, z_all, 2 * N, z_local, 2 * n, n, N, rank, scale2, row_stats, tiles_q, gk,
+                                    rows_pad_k, (float*)nullptr);
   }
 }
 
-// entropy = (1/n) sum over a-rows and splits of epart ; single workgroup
-__global__ __launch_bounds__(256) void ntxent_entropy(const float* __restrict__ epart, int nsplit,
-                                                      int rows_pad, int n, float* __restrict__ out) {
+// One launch for the three tail reductions of the backward: dz_local = scale * sum_split gq, dz_all = scale * sum_split gk
+// (fixed split order), and -- last workgroup -- out[2] = contrast entropy = (1/n) sum over a-rows and splits of epart.
+__global__ __launch_bounds__(256) void ntxent_combine_all(const float* __restrict__ gq, int ksplit, int rows_pad_q, int rows_q,
+                                                          const float* __restrict__ gk, int qsplit, int rows_pad_k, int rows_k,
+                                                          int D, float scale, float* __restrict__ dz_local,
+                                                          float* __restrict__ dz_all, const float* __restrict__ epart,
+                                                          int n, float* __restrict__ out, int blocks_q, int blocks_k) {
   __shared__ double sh[256];
+  const int b = blockIdx.x;
+  if (b < blocks_q + blocks_k) {
+    const bool isq = b < blocks_q;
+    const float* gp = isq ? gq : gk;
+    const int nsplit = isq ? ksplit : qsplit, rows_pad = isq ? rows_pad_q : rows_pad_k, rows = isq ? rows_q : rows_k;
+    float* dst = isq ? dz_local : dz_all;
+    const int i = (isq ? b : b - blocks_q) * 256 + threadIdx.x;
+    if (i >= rows * (D / 4)) return;
+    const int r = i / (D / 4), c = i % (D / 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+      const float4 v = *(const float4*)(gp + ((size_t)s * rows_pad + r) * D + c * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+    *(float4*)(dst + (size_t)r * D + c * 4) = acc;
+    return;
+  }
   double e = 0.0;
   for (int q = threadIdx.x; q < n; q += 256)
-    for (int s = 0; s < nsplit; ++s) e += (double)epart[(size_t)s * rows_pad + q];
+    for (int s = 0; s < ksplit; ++s) e += (double)epart[(size_t)s * rows_pad_q + q];
   sh[threadIdx.x] = e;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
     __syncthreads();
   }
   if (threadIdx.x == 0) out[2] = (float)(sh[0] / n);
@@ -404,7 +444,8 @@ size_t ws_floats(int n, int N, int D) {
   size_t gq = (size_t)p.ksplit * p.rows_pad_q * D;
   size_t gk = (size_t)p.qsplit * p.rows_pad_k * D;
   size_t ep = (size_t)p.ksplit * p.rows_pad_q;
-  return part + gq + gk + ep;
+  size_t rowterm = (size_t)2 * p.rows_pad_q;
+  return part + gq + gk + ep + rowterm;
 }
 
 }  // namespace
@@ -446,8 +487,11 @@ int simclr_ntxent_fwd(const float* z_local, const float* z_all, int n, int N, in
   if (D == 64) LAUNCH_FWD(64); else if (D == 128) LAUNCH_FWD(128); else LAUNCH_FWD(256);
 #undef LAUNCH_FWD
   SIMCLR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ntxent_finalize, dim3(1), dim3(256), 0, stream, part, p.ksplit, p.rows_pad_q,
-                     n, N, rank, row_stats, out);
+  float* rowterm = part + (size_t)p.ksplit * p.rows_pad_q * kPartStride + (size_t)p.ksplit * p.rows_pad_q * D +
+                   (size_t)p.qsplit * p.rows_pad_k * D + (size_t)p.ksplit * p.rows_pad_q;
+  hipLaunchKernelGGL(ntxent_finalize_rows, dim3(ceil_div(2 * n, 16)), dim3(256), 0, stream, part, p.ksplit, p.rows_pad_q,
+                     n, N, rank, row_stats, rowterm);
+  hipLaunchKernelGGL(ntxent_reduce_out, dim3(1), dim3(256), 0, stream, rowterm, n, out);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -469,24 +513,18 @@ int simclr_ntxent_bwd(const float* z_local, const float* z_all, int n, int N, in
   const float scale2 = kLog2e / temperature;
   const size_t lds = (size_t)(kTile * D + 2 * kTile) * sizeof(float);
   dim3 gridq(p.rows_pad_q / kTile, p.ksplit), gridk(p.rows_pad_k / kTile, p.qsplit);
-#define LAUNCH_BWD(DD)                                                                             \
-  do {                                                                                             \
-    hipLaunchKernelGGL((ntxent_bwd_sweep<DD, true>), gridq, dim3(256), lds, stream, z_local, 2 * n, \
-                       z_all, 2 * N, n, N, rank, scale2, row_stats, p.tiles_k, gq, p.rows_pad_q,   \
-                       ep);                                                                        \
-    hipLaunchKernelGGL((ntxent_bwd_sweep<DD, false>), gridk, dim3(256), lds, stream, z_all, 2 * N, \
-                       z_local, 2 * n, n, N, rank, scale2, row_stats, p.tiles_q, gk, p.rows_pad_k, \
-                       (float*)nullptr);                                                           \
-  } while (0)
+  dim3 gridb(max(gridq.x, gridk.x), max(gridq.y, gridk.y), 2);
+#define LAUNCH_BWD(DD)                                                                                       \
+  hipLaunchKernelGGL((ntxent_bwd_sweeps<DD>), gridb, dim3(256), lds, stream, z_local, z_all, n, N, rank, scale2, \
+                     row_stats, p.tiles_k, p.tiles_q, gq, p.rows_pad_q, gk, p.rows_pad_k, ep, (int)gridq.x,    \
+                     (int)gridq.y, (int)gridk.x, (int)gridk.y)
   if (D == 64) LAUNCH_BWD(64); else if (D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(256);
 #undef LAUNCH_BWD
   SIMCLR_CHECK_LAUNCH();
   const float scale = grad_scale / (temperature * (float)n);
-  hipLaunchKernelGGL(ntxent_combine, dim3(ceil_div(2 * n * (D / 4), 256)), dim3(256), 0, stream, gq,
-                     p.ksplit, p.rows_pad_q, 2 * n, D, scale, (const float*)nullptr, dz_local);
-  hipLaunchKernelGGL(ntxent_combine, dim3(ceil_div(2 * N * (D / 4), 256)), dim3(256), 0, stream, gk,
-                     p.qsplit, p.rows_pad_k, 2 * N, D, scale, (const float*)nullptr, dz_all);
-  hipLaunchKernelGGL(ntxent_entropy, dim3(1), dim3(256), 0, stream, ep, p.ksplit, p.rows_pad_q, n, out);
+  const int blocks_q = ceil_div(2 * n * (D / 4), 256), blocks_k = ceil_div(2 * N * (D / 4), 256);
+  hipLaunchKernelGGL(ntxent_combine_all, dim3(blocks_q + blocks_k + 1), dim3(256), 0, stream, gq, p.ksplit, p.rows_pad_q,
+                     2 * n, gk, p.qsplit, p.rows_pad_k, 2 * N, D, scale, dz_local, dz_all, ep, n, out, blocks_q, blocks_k);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -133,8 +133,10 @@ __global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict_
 }
 
 // y[v][c] = mean over HW of x[v][hw][c]
+// y32 (nullable): also / instead write the fp32 means (the heads may run in fp32 on top of a bf16 encoder: rounding the
+// mean of HW bf16 values back to bf16 would throw away the sqrt(HW) averaging gain right before the head's BatchNorm)
 template <typename T>
-__global__ void global_avgpool_fwd(const T* __restrict__ x, T* __restrict__ y, int V, int HW, int C) {
+__global__ void global_avgpool_fwd(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ y32, int V, int HW, int C) {
   constexpr int EPC = Elem<T>::EPC;
   const int cpr = C / EPC;
   const long long total = (long long)V * cpr;
@@ -154,7 +156,12 @@ __global__ void global_avgpool_fwd(const T* __restrict__ x, T* __restrict__ y, i
     const float inv = 1.f / (float)HW;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] *= inv;
-    *(u32x4*)(y + (long long)v * C + cc * EPC) = f32_to_chunk<T>(acc);
+    if (y) *(u32x4*)(y + (long long)v * C + cc * EPC) = f32_to_chunk<T>(acc);
+    if (y32) {
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4)
+        *(float4*)(y32 + (long long)v * C + cc * EPC + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+    }
   }
 }
 // dx[v][hw][c] = (dy[v][c] [+ dy2[v][c]]) / HW, optionally masked by mask_src > 0
@@ -551,17 +558,25 @@ int simclr_maxpool_bwd(const void* dy, const unsigned char* arg, void* dx, int V
   return 0;
 }
 
-int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int dtype, hipStream_t stream) {
+static int avgpool_fwd_impl(const void* x, void* y, float* y32, int V, int HW, int C, int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "global_avgpool_fwd: C %% %d != 0", epc);
+  SIMCLR_CHECK_ARG(y || y32, "global_avgpool_fwd: no output");
   const long long total = (long long)V * (C / epc);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((global_avgpool_fwd<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream,
-                                (const uint16_t*)x, (uint16_t*)y, V, HW, C),
+                                (const uint16_t*)x, (uint16_t*)y, y32, V, HW, C),
              hipLaunchKernelGGL((global_avgpool_fwd<float>), dim3(grid_for(total)), dim3(256), 0, stream,
-                                (const float*)x, (float*)y, V, HW, C));
+                                (const float*)x, (float*)y, y32, V, HW, C));
   SIMCLR_CHECK_LAUNCH();
   return 0;
+}
+int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int dtype, hipStream_t stream) {
+  return avgpool_fwd_impl(x, y, nullptr, V, HW, C, dtype, stream);
+}
+// the same mean, written as float32 whatever the activation dtype (input of fp32 heads)
+int simclr_global_avgpool_fwd_f32(const void* x, float* y32, int V, int HW, int C, int dtype, hipStream_t stream) {
+  return avgpool_fwd_impl(x, nullptr, y32, V, HW, C, dtype, stream);
 }
 
 // dx = dy/HW broadcast; mask_src (nullable, same shape as dx): zero where mask_src <= 0

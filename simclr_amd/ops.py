@@ -433,10 +433,16 @@ def maxpool_bwd(dy, arg, H, W, ksz=3, stride=2):
     return dx
 
 
-def global_avgpool_fwd(x):
+def global_avgpool_fwd(x, out_dtype=None):
+    """reduce_mean over H, W (tf2/resnet.py:693-696).  out_dtype=torch.float32: fp32 means from bf16 activations."""
     V, H, W, C = x.shape
-    y = torch.empty(V, C, device=x.device, dtype=x.dtype)
-    lib().global_avgpool_fwd(_p(x), _p(y), V, H * W, C, dt(x), _s())
+    if out_dtype is None or out_dtype == x.dtype:
+        y = torch.empty(V, C, device=x.device, dtype=x.dtype)
+        lib().global_avgpool_fwd(_p(x), _p(y), V, H * W, C, dt(x), _s())
+        return y
+    assert out_dtype == torch.float32
+    y = torch.empty(V, C, device=x.device, dtype=torch.float32)
+    lib().global_avgpool_fwd_f32(_p(x), _p(y), V, H * W, C, dt(x), _s())
     return y
 
 

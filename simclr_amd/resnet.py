@@ -805,7 +805,8 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
             x = g(x, training)
             self.endpoints['block_group%d' % (i + 1)] = x.t
         self._final = x.t
-        out = ops.global_avgpool_fwd(x.t)                                        # reduce_mean [1,2], :693-696
+        # reduce_mean [1,2], :693-696.  With fp32 heads (--head_dtype=f32) the means leave the encoder in fp32.
+        out = ops.global_avgpool_fwd(x.t, torch.float32 if FLAGS.head_dtype == 'f32' else None)
         self.endpoints['final_avg_pool'] = out
         return out
 
@@ -813,6 +814,8 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
         """dh: [V, C] gradient wrt the pooled features.  on_stage(i) is called when block group
         i (4..1) has finished its backward, and on_stage(0) after the stem (gradient bucketing)."""
         _, H, W, _ = self._final.shape
+        if dh.dtype != self._final.dtype:
+            dh = ops.cast(dh, self._final.dtype)
         d = ops.global_avgpool_bwd(dh, H, W)
         self._final = None
         partial = None

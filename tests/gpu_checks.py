@@ -563,8 +563,7 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
             for v in model._flat_order:
                 optimizer.get_slot(v, 'Momentum').copy_(momenta[v.name].to(DEV))
         RT.weights_version += 1
-        images = (torch.rand(batch, image_size, image_size, 6, generator=g) if inputs == 'iid'
-                  else structured_images(batch, image_size, 2, g))
+        images = torch.rand(batch, image_size, image_size, 6, generator=g)
         labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes).float()
         p64 = OrderedDict((k, v.double()) for k, v in params.items())
         s64 = OrderedDict((k, v.double()) for k, v in state.items())

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import gpu_checks as gc
 
 out = {}
-for inputs in ('structured', 'iid'):
+kinds = sys.argv[1:] or ['structured', 'iid']
+for inputs in kinds:
     for head in ('same', 'f32'):
         res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='bf16', head_dtype=head, inputs=inputs)
         out['%s head=%s' % (inputs, head)] = {r['name'].split(' R50')[0]: r['err'] for r in res}
