@@ -195,6 +195,27 @@ int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out
 int simclr_axpy_f32(float a, const float* x, float* y, long long n, simclr_stream_t stream);
 int simclr_l2_loss_f32(const float* x, long long n, float* out, simclr_stream_t stream); /* tf.nn.l2_loss, model.py:49-60 */
 
+/* ---- BatchNorm backward FOLDED into the convolution that produced the BN's input (1x1 expand convs, K <= N): what
+ * tape.gradient (tf2/run.py:621) yields for conv -> BatchNormalization (tf2/resnet.py:460-467, the block's last conv + BN)
+ * without ever forming the gradient wrt the conv output.  With c = h W, dh = a*dm + b*c + d per channel:
+ *   dW = (h^T dm)*a + ((h^T h) W)*b + colsum(h) (x) d ;   d(h) = dm (a*W)^T + h (W diag(b) W^T) + W d.
+ * simclr_bn_fold_coeffs -> a, b, d;  simclr_bn_fold_pre -> W*b (fp32), the first N columns of the extended dgrad weights and
+ * the bias W d;  [GEMMs h^T dm, h^T h via simclr_conv2d_wgrad; (h^T h) W and (W*b) W^T via simclr_conv2d_fwd];
+ * simclr_bn_fold_post -> dW and the last K columns of the extended weights;  simclr_conv2d_dgrad_bn_ext -> d(h) with the fused
+ * BN-backward reduce of the producer BN, reading dm and h (K-extended reduction) instead of a materialised dh. ---- */
+int simclr_bn_fold_coeffs(const float* scale, const float* mean, const float* rstd, const float* c1, const float* c2,
+                          float* a, float* b, float* d, int C, simclr_stream_t stream);
+int simclr_bn_fold_pre(const void* w, const float* a, const float* b, const float* d, float* wb, void* wext, float* e,
+                       int K, int N, int dtype, simclr_stream_t stream);
+int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* a, const float* b, const float* d,
+                        const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype,
+                        simclr_stream_t stream);
+int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext, const float* bias, void* dx,
+                               int accumulate, const void* bn_x, const void* bn_mask, const float* bn_scale,
+                               const float* bn_shift, const float* bn_mean, const float* bn_rstd, int mask_mode,
+                               float* stats, int nslot, int V, int H, int W, int Cin, int Cout, int dtype,
+                               simclr_stream_t stream);
+
 /* ---- two-view training augmentation on the device: tf2/data_util.py:443-475 (preprocess_for_train: random-resized-crop
  * with bicubic resize :246-320/:362-377, random flip :463, colour jitter in random order :54-173/:380-389, random grayscale
  * :48-52, clip :473-474) for every image and both views of tf2/data.py:52-62.  The random draws come from the caller as

@@ -326,6 +326,69 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
   }
 }
 
+// ---- BatchNorm backward folded into the convolution that produced the BN's input (1x1 "expand" convs: K <= N) -------
+// For c = h W (h [M,K], W [K,N]) followed by BN, the gradient wrt c is dh = a*dm + b*c + d per channel j
+// (a = scale, b = -scale*k2*rstd, d = scale*(k2*mean*rstd - k1); k1 = mean(dm), k2 = mean(dm*x^)).  By linearity
+//   dW = h^T dh = (h^T dm)*a + ((h^T h) W)*b + colsum(h) (x) d          (columns j scaled)
+//   dh_in = dh W^T = dm (a*W)^T + h (W diag(b) W^T) + W d
+// so neither dh nor the streaming pass that would compute it is needed: h^T dm, h^T h are weight-gradient GEMMs, the rest
+// is O(K*N) work.  Kernels below do the O(K*N) parts; the GEMMs run on the conv kernels.
+__global__ void bn_fold_coeffs(const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
+                               const float* __restrict__ c1, const float* __restrict__ c2, float* __restrict__ a,
+                               float* __restrict__ b, float* __restrict__ d, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = scale[c];
+  a[c] = sc;
+  b[c] = -sc * c2[c] * rstd[c];
+  d[c] = sc * (c2[c] * mean[c] * rstd[c] - c1[c]);
+}
+
+// one workgroup per input channel i (row of W [K][N]):  wb[i][j] = W[i][j]*b[j] (fp32),  wext[i][j] = T(W[i][j]*a[j]) for
+// j < N (row pitch N + K),  e[i] = sum_j W[i][j]*d[j]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fold_pre(const T* __restrict__ w, const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ d, float* __restrict__ wb, T* __restrict__ wext,
+                                                   float* __restrict__ e, int K, int N) {
+  __shared__ double sh[256];
+  const int i = blockIdx.x;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float wv = Elem<T>::ld(w + (long long)i * N + j);
+    wb[(long long)i * N + j] = wv * b[j];
+    Elem<T>::st(wext + (long long)i * (N + K) + j, wv * a[j]);
+    acc += (double)wv * (double)d[j];
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) e[i] = (float)sh[0];
+}
+
+// dw[i][j] = a[j]*t1[i][j] + b[j]*gw[i][j] + d[j]*cs[i]  (+= if accumulate);  wext[i][N + k] = T(q[k][i])
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fold_post(const float* __restrict__ t1, const float* __restrict__ gw,
+                                                    const double* __restrict__ cs, const float* __restrict__ a,
+                                                    const float* __restrict__ b, const float* __restrict__ d,
+                                                    const float* __restrict__ q, float* __restrict__ dw, T* __restrict__ wext,
+                                                    int K, int N, int accumulate) {
+  const long long total = (long long)K * N;
+  for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total + (long long)K * K; t += gridDim.x * 256ll) {
+    if (t < total) {
+      const int i = (int)(t / N), j = (int)(t % N);
+      const float v = fmaf(a[j], t1[t], fmaf(b[j], gw[t], d[j] * (float)cs[i]));
+      dw[t] = accumulate ? dw[t] + v : v;
+    } else {
+      const long long u = t - total;
+      const int i = (int)(u / K), k = (int)(u % K);
+      Elem<T>::st(wext + (long long)i * (N + K) + N + k, q[(long long)k * K + i]);
+    }
+  }
+}
+
 }  // namespace
 
 static int bwd_reduce_grid(long long rows, int C, int epc, int* rows_per_block) {
@@ -459,6 +522,45 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
   }
 #undef LBX
 #undef LBW
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// BN-backward coefficients of the folded form (see bn_fold_*): a, b, d [C] from scale, mean, rstd and c1 = mean(dm), c2 = mean(dm*x^)
+int simclr_bn_fold_coeffs(const float* scale, const float* mean, const float* rstd, const float* c1, const float* c2,
+                          float* a, float* b, float* d, int C, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(C > 0, "bn_fold_coeffs: bad C");
+  hipLaunchKernelGGL(bn_fold_coeffs, dim3(ceil_div(C, 256)), dim3(256), 0, stream, scale, mean, rstd, c1, c2, a, b, d, C);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// w [K][N] (T: the compute copy the forward used): wb [K][N] fp32 = w*b, wext [K][N+K] (T) columns < N = w*a, e [K] = w d
+int simclr_bn_fold_pre(const void* w, const float* a, const float* b, const float* d, float* wb, void* wext, float* e,
+                       int K, int N, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "bn_fold_pre: bad dtype %d", dtype);
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((bn_fold_pre<uint16_t>), dim3(K), dim3(256), 0, stream, (const uint16_t*)w, a, b, d, wb, (uint16_t*)wext, e, K, N);
+  else
+    hipLaunchKernelGGL((bn_fold_pre<float>), dim3(K), dim3(256), 0, stream, (const float*)w, a, b, d, wb, (float*)wext, e, K, N);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// dw [K][N] fp32 = a*t1 + b*gw + cs (x) d  (t1 = h^T dm, gw = (h^T h) w, cs [K] fp64 = colsum h);  wext columns N.. = q^T (q [K][K] = wb w^T)
+int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* a, const float* b, const float* d,
+                        const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "bn_fold_post: bad dtype %d", dtype);
+  const long long total = (long long)K * N + (long long)K * K;
+  const int grid = (int)min((total + 255) / 256, 1ll << 20);
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((bn_fold_post<uint16_t>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, a, b, d, q, dw, (uint16_t*)wext, K, N, accumulate);
+  else
+    hipLaunchKernelGGL((bn_fold_post<float>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, a, b, d, q, dw, (float*)wext, K, N, accumulate);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

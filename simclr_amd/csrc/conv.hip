@@ -52,6 +52,13 @@ struct ConvP {
   const void* bn_mask;
   const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
   int bn_mode;     // 0 off, 1 mask tensor, 2 recompute
+  // K-extension (EXT instantiations, 1x1 stride-1 dgrad only): after the IC channels of x the reduction continues over
+  // ic2 channels of a SECOND tensor x2 at the same pixel (weights rows hold [K | ic2] values), and `bias[n]` is added to
+  // every output row.  This is how a BatchNorm backward is folded into the consuming convolution by linearity:
+  // d(conv input) = dm (a*W)^T + h (W diag(b) W^T) + W d, with dh = a*dm + b*(h W) + d never materialised.
+  const void* x2;
+  const float* bias;
+  int ic2, pixpitch2;
   const void* zero;  // 16 zero bytes in device memory (source of padding chunks for direct-to-LDS loads):
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 // N-tiles) sit on the same XCD and advance in lockstep, so the gathered A tile is served by
 // that XCD's L2.
 // ------------------------------------------------------------------------------------
-template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI>
+template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void conv_igemm_persistent(const ConvP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
@@ -415,8 +422,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   constexpr int STG = (BM + BN) * 8;              // u32x4 per stage
   u32x4* As = (u32x4*)smem;                       // stage s: As + s*STG
   u32x4* Bs = As + BM * 8;                        // stage s: Bs + s*STG
-  float* bnp = (float*)(As + STAGES * STG);       // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile
-  long long* rowoff = (long long*)(bnp + 4 * BN); // [BM] output offsets of the tile rows (LDS epilogue)
+  float* bnp = (float*)(As + STAGES * STG);       // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile (+ [BN] bias if EXT)
+  long long* rowoff = (long long*)(bnp + (4 + (EXT ? 1 : 0)) * BN); // [BM] output offsets of the tile rows (LDS epilogue)
   constexpr bool LDS_EPI = sizeof(T) == 2;        // bf16: coalesced row-wise epilogue through LDS
   constexpr int NTH = NW * 64;
   constexpr int CPR = BN / 8;                     // 16-byte chunks (8 channels) per C row
@@ -442,7 +449,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   const int n0 = nt * BN;
   const int count = (mslot < p.m_tiles) ? (p.m_tiles - mslot + mslots - 1) / mslots : 0;
   const int kpt = p.IC / BK;
-  const int KT = p.ntaps * kpt;
+  const int kpt2 = EXT ? p.ic2 / BK : 0;          // k-tiles of the second source (appended after the regular taps)
+  const int KT = p.ntaps * kpt + kpt2;
+  const int kmain = p.KH * p.KW * p.IC;           // weight-row offset of the extension block
+  const T* __restrict__ X2 = (const T*)p.x2;
 
   const int kc = (lane & 7) ^ (lane >> 3);
   // 1x1 stride-1 (and the Dense layers): output row m reads input pixel m -- no decode at all
@@ -453,6 +463,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   // precomputed on the host, so a tap change costs two adds, two unsigned compares and one 64-bit
   // add per row, and a k-tile inside a tap costs nothing but `+ ci0`.
   int a_ry[AJ], a_rx[AJ];
+  int a_m[AJ];                  // EXT: pixel index of the row (flat convolutions: input pixel == output row)
   const T* a_rb[AJ];
   bool a_ok[AJ];
   const T* a_tp[AJ];
@@ -476,6 +487,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         pix = ((long long)v * p.IH + ry) * p.IW + rx;
       }
       a_ry[j] = ry; a_rx[j] = rx;
+      if (EXT) a_m[j] = mm;
       a_rb[j] = X + pix * p.pixpitch + kc * EPC;
       a_tp[j] = a_rb[j];                   // flat: final; otherwise overwritten by set_tap
       a_tok[j] = a_ok[j];
@@ -504,12 +516,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   auto issue_tile = [&](int ti, int ci, int buf) __attribute__((always_inline)) {
     if (DIAG(2)) return;
     const int ci0 = ci * BK;
-    const int k0 = (int)((p.tap_w >> (4 * ti)) & 15) * p.IC + ci0;
+    const bool ext = EXT && ti == p.ntaps;         // wave-uniform
+    const int k0 = ext ? kmain + ci0 : (int)((p.tap_w >> (4 * ti)) & 15) * p.IC + ci0;
     unsigned char* a_dst = (unsigned char*)(As + buf * STG) + wave * AJ * 1024;
     unsigned char* b_dst = (unsigned char*)(Bs + buf * STG) + wave * BJ * 1024;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const void* src = a_tok[j] ? (const void*)(a_tp[j] + ci0) : p.zero;
+      const void* src;
+      if (ext) src = a_ok[j] ? (const void*)(X2 + (long long)a_m[j] * p.pixpitch2 + kc * EPC + ci0) : p.zero;
+      else src = a_tok[j] ? (const void*)(a_tp[j] + ci0) : p.zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
     }
 #pragma unroll
@@ -527,6 +542,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       bnp[BN + i] = (ok && p.bn_mode == 2) ? p.bn_shift[n] : 0.f;
       bnp[2 * BN + i] = ok ? p.bn_mean[n] : 0.f;
       bnp[3 * BN + i] = ok ? p.bn_rstd[n] : 0.f;
+      if (EXT) bnp[4 * BN + i] = (ok && p.bias) ? p.bias[n] : 0.f;
     }
     // visibility: the first barrier of the k-loop (or the explicit one before the flush) orders these writes
   }
@@ -552,13 +568,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
     issue_tile(iti, ici, ibuf);
     ibuf = (ibuf + 1 == STAGES) ? 0 : ibuf + 1;
     ++issued;
-    if (++ici == kpt) {
+    if (++ici == ((EXT && iti == p.ntaps) ? kpt2 : kpt)) {
       ici = 0;
-      if (++iti == p.ntaps) {
+      if (++iti == p.ntaps + ((EXT && kpt2 > 0) ? 1 : 0)) {
         iti = 0;
         if (++it < count) setup_rows(mslot + it * mslots);
       }
-      if (it < count) set_tap(iti);
+      if (it < count && iti < p.ntaps) set_tap(iti);
     }
   };
   if (count > 0) {
@@ -686,6 +702,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         uint16_t* dst = (uint16_t*)Y + eoff[i];
         float v[8];
         chunk_to_f32<uint16_t>(cv, v);
+        if (EXT) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bnp[4 * BN + e_cc * 8 + e];
+        }
         if (p.accumulate) {
           float o[8];
           chunk_to_f32<uint16_t>(e_ov[i], o);
@@ -712,7 +732,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
           }
         }
         if (DIAG(16)) continue;
-        if (p.accumulate || BNEPI) *(u32x4*)dst = f32_to_chunk<uint16_t>(v);
+        if (p.accumulate || BNEPI || EXT) *(u32x4*)dst = f32_to_chunk<uint16_t>(v);
         else *(u32x4*)dst = cv;
       }
     } else {
@@ -739,6 +759,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         if (off >= 0 && n < p.N) {
           T* dst = Y + off + n;
           float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+          if (EXT) {
+            const float4 bi = *(const float4*)(bnp + 4 * BN + wn * 64 + ni * 16 + g * 4);
+            v[0] += bi.x; v[1] += bi.y; v[2] += bi.z; v[3] += bi.w;
+          }
           if (p.accumulate) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += Elem<T>::ld(dst + r);
@@ -1819,10 +1843,13 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     // persistent grid: 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one per tile
     int bn_, nt_, pg;
     igemm_persistent_grid(p.M, p.N, &bn_, &nt_, &pg);
-    const size_t plds = 2 * (128 + BN) * 128 + 4 * BN * sizeof(float) + 128 * sizeof(long long);
+    const size_t plds = 2 * (128 + BN) * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long);
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
-    if (p.bn_mode) {           // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
+    if (p.bn_mode && p.x2) {   // K-extended dgrad (folded BatchNorm backward of the consumer's output) + fused BN reduce
+      if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 64, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
+      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
+    } else if (p.bn_mode) {    // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
       if (BN == 64) LP(64, true, true); else LP(128, true, true);
     } else if (BN == 64) { if (st) LP(64, true, false); else LP(64, false, false); }
     else { if (st) LP(128, true, false); else LP(128, false, false); }
@@ -1981,6 +2008,41 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cout;
   p.M = V * IH * IW; p.K = KH * KW * Cout;
+  p.bn_x = bn_x; p.bn_mask = bn_mask; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+  p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.bn_mode = mask_mode;
+  if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
+  else launch_igemm<float, MODE_DGRAD>(p, stream);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// 1x1 stride-1 data gradient whose upstream gradient passes through a BatchNorm backward that is FOLDED into this
+// convolution by linearity (the BN of this conv's own output, e.g. the residual tail BN3 after the expand conv3):
+//   dh = a*dm + b*c + d  per output channel (BN backward: a = scale, b = -scale*k2*rstd, d = scale*(k2*mean*rstd - k1)),
+//   c = h W  (this conv's forward)  =>  d(h) = dm (a*W)^T + h (W diag(b) W^T) + W d.
+// dm [M, Cout] (masked gradient wrt the BN output), h [M, Cin] (this conv's forward input), w_ext [Cin][Cout + Cin] =
+// [a*W | Q^T] rows (T), bias [Cin] fp32 = W d.  The rest as simclr_conv2d_dgrad_bn (fused reduce of the PRODUCER BN of h).
+int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext, const float* bias, void* dx,
+                               int accumulate, const void* bn_x, const void* bn_mask, const float* bn_scale,
+                               const float* bn_shift, const float* bn_mean, const float* bn_rstd, int mask_mode,
+                               float* stats, int nslot, int V, int H, int W, int Cin, int Cout, int dtype,
+                               hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_bn_ext: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0 && Cin % (8 * epc) == 0, "conv2d_dgrad_bn_ext: Cin=%d / Cout=%d must be multiples of %d", Cin, Cout, 8 * epc);
+  SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "conv2d_dgrad_bn_ext: M overflows int32");
+  SIMCLR_CHECK_ARG(mask_mode >= 1 && mask_mode <= 3, "conv2d_dgrad_bn_ext: mask_mode must be 1, 2 or 3");
+  SIMCLR_CHECK_ARG(dm && h && w_ext && bn_x && bn_mean && bn_rstd && stats && nslot > 0, "conv2d_dgrad_bn_ext: null argument");
+  SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn_ext: mask_mode 1 / 3 need bn_mask");
+  SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn_ext: mask_mode 2 needs scale/shift");
+  ConvP p = {};
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
+  p.x = dm; p.w = w_ext; p.y = dx; p.stats = stats; p.nslot = nslot; p.accumulate = accumulate;
+  p.V = V; p.IH = H; p.IW = W; p.IC = Cout; p.OH = H; p.OW = W; p.N = Cin;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pixpitch = Cout;
+  p.M = V * H * W; p.K = Cout + Cin;
+  p.x2 = h; p.ic2 = Cin; p.pixpitch2 = Cin; p.bias = bias;
   p.bn_x = bn_x; p.bn_mask = bn_mask; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
   p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.bn_mode = mask_mode;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);

@@ -556,3 +556,50 @@ def augment_views(src, params, H, W, out=None):
     ws = _workspace(lib().augment_workspace_bytes(b, views, H, W), src.device, key='augment')
     lib().augment_views(_p(src), code, _p(params), _p(ws), _p(out), b, views, Hs, Ws, H, W, _s())
     return out
+
+
+# ---------------------------------------------------------------- BatchNorm backward folded into the producing 1x1 conv
+def bn_fold_coeffs(scale, mean, rstd, c1, c2):
+    C = scale.shape[0]
+    a, b, d = (torch.empty(C, device=scale.device, dtype=torch.float32) for _ in range(3))
+    lib().bn_fold_coeffs(_p(scale), _p(mean), _p(rstd), _p(c1), _p(c2), _p(a), _p(b), _p(d), C, _s())
+    return a, b, d
+
+
+def bn_fold_pre(w_d, a, b, d):
+    """w_d [K][N] (compute copy, = the conv's dgrad layout).  Returns (wb [K,N] f32 = w*b, wext [K, N+K] (first N columns
+    = w*a, the rest filled by bn_fold_post), e [K] f32 = w d)."""
+    K, N = w_d.shape
+    wb = torch.empty(K, N, device=w_d.device, dtype=torch.float32)
+    wext = torch.empty(K, N + K, device=w_d.device, dtype=w_d.dtype)
+    e = torch.empty(K, device=w_d.device, dtype=torch.float32)
+    lib().bn_fold_pre(_p(w_d), _p(a), _p(b), _p(d), _p(wb), _p(wext), _p(e), K, N, dt(w_d), _s())
+    return wb, wext, e
+
+
+def bn_fold_post(t1, gw, cs, a, b, d, q, dw, wext, accumulate=False):
+    K, N = t1.shape
+    assert cs.dtype == torch.float64 and tuple(q.shape) == (K, K) and tuple(dw.shape) == (K, N)
+    lib().bn_fold_post(_p(t1), _p(gw), _p(cs), _p(a), _p(b), _p(d), _p(q), _p(dw), _p(wext), K, N, int(accumulate),
+                       dt(wext), _s())
+    return dw
+
+
+def conv2d_dgrad_bn_ext(dm, h, wext, bias, bn, out=None, accumulate=False):
+    """1x1 stride-1 dgrad reading (dm [V,H,W,N], h [V,H,W,K]) with the K-extended weights of bn_fold_pre/post and the bias
+    W d, plus the fused BN-backward reduce of the producer BN of h (`bn` as in conv2d_dgrad_bn).  Returns (dm_in, partial)."""
+    V, H, W, N = dm.shape
+    K = h.shape[3]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(V, H, W, K, device=dm.device, dtype=dm.dtype)
+    partial = conv_stats(V * H * W, K, dm.device)
+    esz = dm.element_size()
+    M = V * H * W
+    _launch('conv_igemm_dgrad', 2.0 * M * N * K, esz * (M * N + M * K + N * K),
+            impl_bytes=esz * (M * N + (3 + (bn['mode'] == 1) + int(accumulate)) * M * K + (N + K) * K),
+            fn=lambda: lib().conv2d_dgrad_bn_ext(_p(dm), _p(h), _p(wext), _p(bias), _p(out), int(accumulate), _p(bn['x']),
+                                                 _p(bn.get('mask')), _p(bn.get('scale')), _p(bn.get('shift')), _p(bn['mean']),
+                                                 _p(bn['rstd']), bn['mode'], _p(partial), partial.shape[0], V, H, W, K, N,
+                                                 dt(dm), _s()))
+    return out, partial

@@ -47,6 +47,16 @@ class _Runtime:
         self.seed = 0
         self.weights_version = 0     # bumped by the optimizer step; compute copies refresh lazily
         self._wgrad_stream = None
+        self._consts = {}
+
+    def const(self, C, value):
+        """Cached constant fp32 vector on the device (means 0 / rstd 1 for plain column sums)."""
+        key = (C, float(value), str(self.device))
+        t = self._consts.get(key)
+        if t is None:
+            t = torch.full((C,), float(value), device=self.device, dtype=torch.float32)
+            self._consts[key] = t
+        return t
 
     def wgrad_stream(self):
         """Side stream for the weight-gradient kernels (SIMCLR_WGRAD_STREAM=1), else None."""
@@ -406,6 +416,44 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         g = self.kernel.ensure_grad()
         g.copy_(tmp4[:, :, :g.shape[2], :self.filters])
 
+    def _f32_copies(self):
+        """fp32 views of the compute copies (the values the forward multiplied with), cached per weight version."""
+        if getattr(self, '_v32', -1) != self._version:
+            self.w_d32 = self.w_d if self.w_d.dtype == torch.float32 else ops.cast(self.w_d, torch.float32)
+            self.w_t32 = self.w_t if self.w_t.dtype == torch.float32 else ops.cast(self.w_t, torch.float32)
+            self._v32 = self._version
+        return self.w_d32, self.w_t32
+
+    def backward_folded(self, dm, bn_out, coeffs, fuse_bn):
+        """1x1 stride-1 conv whose output c = h W goes through `bn_out` (BatchNorm, no ReLU before the add): the BN backward
+        dh = a*dm + b*c + d is folded into this layer's gradients by linearity (csrc/bn.hip bn_fold_*), so neither the
+        streaming BN-backward pass nor dh exists.  dm: masked gradient wrt bn_out's output; coeffs = (c1, c2) of bn_out.
+        Returns (dm_in, partial) like backward(..., fuse_bn=...)."""
+        assert self.kernel_size == 1 and self.strides == 1 and not self.padded
+        sv = self.saved
+        self.saved = None
+        h = sv['x']
+        V, H, W, K = h.shape
+        N = self.cout_p
+        st = bn_out.saved
+        a, b, d = ops.bn_fold_coeffs(st['scale'], st['mean'], st['rstd'], coeffs[0], coeffs[1])
+        wb, wext, e = ops.bn_fold_pre(self.w_d, a, b, d)
+        w_d32, w_t32 = self._f32_copies()
+        q = ops.conv2d_fwd(wb.view(K, 1, 1, N), w_d32, 1, 1, 1, 0, 1, 1).view(K, K)           # (W*b) W^T
+        if self.kernel.trainable:
+            with _wgrad_side_stream(h, dm):
+                t1 = ops.conv2d_wgrad(h, dm, 1, 1, 1, 0)                                        # h^T dm   [K, N]
+                g = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)                                          # h^T h    [K, K]
+                cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, RT.const(K, 0.0), RT.const(K, 1.0), 0))
+                gw = ops.conv2d_fwd(g.view(K, 1, 1, K), w_t32, 1, 1, 1, 0, 1, 1).view(K, N)    # (h^T h) W
+                ops.bn_fold_post(t1, gw, cs, a, b, d, q, self.kernel.ensure_grad().view(K, N), wext)
+        else:
+            z = torch.zeros(K, N, device=h.device)
+            ops.bn_fold_post(z, z, torch.zeros(2, K, device=h.device, dtype=torch.float64), a, b, d, q,
+                             torch.empty(K, N, device=h.device), wext)
+        join_wgrad_stream()                       # wext's last K columns come from bn_fold_post
+        return ops.conv2d_dgrad_bn_ext(dm, h, wext, e, fuse_bn)
+
     def backward(self, dy, need_dx=True, dx_out=None, accumulate=False, fuse_bn=None):
         """Returns dx, or (dm, partial) when `fuse_bn` (BatchNormRelu.fusion_info of the layer that
         produced this conv's input) asks for the fused BN-backward reduce (stride-1 convs only)."""
@@ -437,6 +485,11 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
                                        accumulate=accumulate)
         return ops.conv2d_dgrad(dy, self.w_d, k, k, s, sv['pad'], sv['H'], sv['W'], out=dx_out,
                                 accumulate=accumulate)
+
+
+def _bn_fold_enabled():
+    import os
+    return os.environ.get('SIMCLR_BN_FOLD', '1') not in ('', '0')
 
 
 class _wgrad_side_stream:
@@ -595,6 +648,17 @@ def _block_entry(block, inputs, training):
     return raw_sc.t, sc_bn, block.bn1(raw1, training)
 
 
+def _block_tail_coeffs(block, bn_tail, dout, dout_partial):
+    """Like _block_tail_backward for the folded form: statistics exchange + finalize of the tail BN (and of the projection
+    shortcut's BN, which still runs its own backward), but NO apply pass for the tail.  Returns ((c1, c2), dx_shortcut_path)."""
+    dsum = dout
+    if block.shortcut is not None:
+        sc_part = block.shortcut.bn.bwd_reduce(dsum, mask_mode=0)
+        co_t, co_s = bwd_finalize_many([(bn_tail, dout_partial), (block.shortcut.bn, sc_part)])
+        return co_t, block.shortcut.backward(dsum, coeffs=co_s)
+    return bwd_finalize_many([(bn_tail, dout_partial)])[0], dsum
+
+
 def _block_tail_backward(block, bn_tail, dout, dout_partial):
     """Backward of relu(bn_tail(h) + shortcut): returns (dh, dx_shortcut_path).  When the tail's reduce arrived fused
     (dout_partial) and the block has a projection shortcut, the two BatchNorm backward reductions -- same upstream
@@ -687,6 +751,23 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
 
     def backward(self, dout, dout_partial=None, prev_tail=None):
         """See ResidualBlock.backward.  Returns (dx, partial-or-None)."""
+        fold = (dout_partial is not None and self.sk is None and not self.conv3.padded and _bn_fold_enabled())
+        if fold:
+            # tail BN3 backward folded into conv3's wgrad / dgrad (no bn_bwd_apply pass, no dh3 tensor)
+            co3, dx = _block_tail_coeffs(self, self.bn3, dout, dout_partial)
+            self.out = None
+            dm2, part2 = self.conv3.backward_folded(dout, self.bn3, co3, fuse_bn=self.bn2.fusion_info())
+            self.bn3.saved = None
+            dh2 = self.bn2.backward_fused(dm2, part2)
+            if self.conv2.strides == 1:
+                dm1, part1 = self.conv2.backward(dh2, fuse_bn=self.bn1.fusion_info())
+                dh1 = self.bn1.backward_fused(dm1, part1)
+            else:
+                dh1, _ = self.bn1.backward(self.conv2.backward(dh2))
+            if prev_tail is not None:
+                return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
+            self.conv1.backward(dh1, dx_out=dx, accumulate=True)
+            return dx, None
         dh3, dx = _block_tail_backward(self, self.bn3, dout, dout_partial)
         self.out = None
         if self.sk is not None:

@@ -373,3 +373,12 @@ def test_two_view_augmentation_feeds_the_training_step():
     out = step(x, {'labels': labels})
     assert torch.isfinite(out['total_loss']).all()
     FLAGS.reset(); RT.reset()
+
+
+@pytest.mark.parametrize('dtype', [F32, BF])
+@pytest.mark.parametrize('V,H,K,N', [(3, 9, 64, 256), (2, 14, 128, 512), (64, 28, 128, 512), (1024, 7, 512, 2048)])
+def test_batchnorm_backward_folded_into_expand_conv(V, H, K, N, dtype):
+    """Tail BatchNorm backward folded into the block's last 1x1 conv by linearity (tf2/resnet.py:460-467 under
+    tape.gradient): no bn_bwd_apply pass, K-extended dgrad reading (dm, h).  Includes a multi-tile persistent case."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_bn_fold(V, H, K, N, dtype))
