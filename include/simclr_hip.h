@@ -199,17 +199,23 @@ int simclr_l2_loss_f32(const float* x, long long n, float* out, simclr_stream_t 
  * tape.gradient (tf2/run.py:621) yields for conv -> BatchNormalization (tf2/resnet.py:460-467, the block's last conv + BN)
  * without ever forming the gradient wrt the conv output.  With c = h W, dh = a*dm + b*c + d per channel:
  *   dW = (h^T dm)*a + ((h^T h) W)*b + colsum(h) (x) d ;   d(h) = dm (a*W)^T + h (W diag(b) W^T) + W d.
- * simclr_bn_fold_coeffs -> a, b, d;  simclr_bn_fold_pre -> W*b (fp32), the first N columns of the extended dgrad weights and
- * the bias W d;  [GEMMs h^T dm, h^T h via simclr_conv2d_wgrad; (h^T h) W and (W*b) W^T via simclr_conv2d_fwd];
+ * simclr_bn_fold_pre -> a, b, d, W*b (fp32), the first N columns of the extended dgrad weights and the bias W d
+ * (simclr_bn_fold_coeffs: a, b, d alone);  [GEMMs h^T dm, h^T h via simclr_conv2d_wgrad; (h^T h) W and (W*b) W^T via simclr_conv2d_fwd];
  * simclr_bn_fold_post -> dW and the last K columns of the extended weights;  simclr_conv2d_dgrad_bn_ext -> d(h) with the fused
  * BN-backward reduce of the producer BN, reading dm and h (K-extended reduction) instead of a materialised dh. ---- */
 int simclr_bn_fold_coeffs(const float* scale, const float* mean, const float* rstd, const float* c1, const float* c2,
                           float* a, float* b, float* d, int C, simclr_stream_t stream);
-int simclr_bn_fold_pre(const void* w, const float* a, const float* b, const float* d, float* wb, void* wext, float* e,
-                       int K, int N, int dtype, simclr_stream_t stream);
-int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* a, const float* b, const float* d,
-                        const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype,
+int simclr_bn_fold_pre(const void* w, const float* scale, const float* mean, const float* rstd, const float* c1,
+                       const float* c2, float* a, float* b, float* d, float* wb, void* wext, float* e, int K, int N,
+                       int dtype, simclr_stream_t stream);
+int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* cs32, const float* a, const float* b,
+                        const float* d, const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype,
                         simclr_stream_t stream);
+/* h^T h [K*K] followed by colsum(h) [K] for h [M][K] (T), K in {64, 128, 256(bf16)}: the activation is streamed once */
+size_t simclr_conv2d_gram_workspace_bytes(long long M, int K, int dtype);
+int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, int K, int dtype, simclr_stream_t stream);
+/* C [M][N] = A [M][K] B[N][K]^T, fp32 on the matrix cores (the small K x K / K x N products of the folded form) */
+int simclr_small_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, simclr_stream_t stream);
 int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext, const float* bias, void* dx,
                                int accumulate, const void* bn_x, const void* bn_mask, const float* bn_scale,
                                const float* bn_shift, const float* bn_mean, const float* bn_rstd, int mask_mode,

@@ -346,18 +346,25 @@ __global__ void bn_fold_coeffs(const float* __restrict__ scale, const float* __r
 
 // one workgroup per input channel i (row of W [K][N]):  wb[i][j] = W[i][j]*b[j] (fp32),  wext[i][j] = T(W[i][j]*a[j]) for
 // j < N (row pitch N + K),  e[i] = sum_j W[i][j]*d[j]
+// (the coefficient vectors a, b, d are computed here from the BN quantities and written out by workgroup 0)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_fold_pre(const T* __restrict__ w, const float* __restrict__ a, const float* __restrict__ b,
-                                                   const float* __restrict__ d, float* __restrict__ wb, T* __restrict__ wext,
+__global__ __launch_bounds__(256) void bn_fold_pre(const T* __restrict__ w, const float* __restrict__ scale,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   const float* __restrict__ c1, const float* __restrict__ c2,
+                                                   float* __restrict__ a, float* __restrict__ b, float* __restrict__ d,
+                                                   float* __restrict__ wb, T* __restrict__ wext,
                                                    float* __restrict__ e, int K, int N) {
   __shared__ double sh[256];
   const int i = blockIdx.x;
   double acc = 0.0;
   for (int j = threadIdx.x; j < N; j += 256) {
+    const float sc = scale[j];
+    const float aj = sc, bj = -sc * c2[j] * rstd[j], dj = sc * (c2[j] * mean[j] * rstd[j] - c1[j]);
+    if (i == 0) { a[j] = aj; b[j] = bj; d[j] = dj; }
     const float wv = Elem<T>::ld(w + (long long)i * N + j);
-    wb[(long long)i * N + j] = wv * b[j];
-    Elem<T>::st(wext + (long long)i * (N + K) + j, wv * a[j]);
-    acc += (double)wv * (double)d[j];
+    wb[(long long)i * N + j] = wv * bj;
+    Elem<T>::st(wext + (long long)i * (N + K) + j, wv * aj);
+    acc += (double)wv * (double)dj;
   }
   sh[threadIdx.x] = acc;
   __syncthreads();
@@ -371,7 +378,8 @@ __global__ __launch_bounds__(256) void bn_fold_pre(const T* __restrict__ w, cons
 // dw[i][j] = a[j]*t1[i][j] + b[j]*gw[i][j] + d[j]*cs[i]  (+= if accumulate);  wext[i][N + k] = T(q[k][i])
 template <typename T>
 __global__ __launch_bounds__(256) void bn_fold_post(const float* __restrict__ t1, const float* __restrict__ gw,
-                                                    const double* __restrict__ cs, const float* __restrict__ a,
+                                                    const double* __restrict__ cs, const float* __restrict__ cs32,
+                                                    const float* __restrict__ a,
                                                     const float* __restrict__ b, const float* __restrict__ d,
                                                     const float* __restrict__ q, float* __restrict__ dw, T* __restrict__ wext,
                                                     int K, int N, int accumulate) {
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void bn_fold_post(const float* __restrict__ t1
   for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total + (long long)K * K; t += gridDim.x * 256ll) {
     if (t < total) {
       const int i = (int)(t / N), j = (int)(t % N);
-      const float v = fmaf(a[j], t1[t], fmaf(b[j], gw[t], d[j] * (float)cs[i]));
+      const float v = fmaf(a[j], t1[t], fmaf(b[j], gw[t], d[j] * (cs ? (float)cs[i] : cs32[i])));
       dw[t] = accumulate ? dw[t] + v : v;
     } else {
       const long long u = t - total;
@@ -539,28 +547,35 @@ int simclr_bn_fold_coeffs(const float* scale, const float* mean, const float* rs
   return 0;
 }
 
-// w [K][N] (T: the compute copy the forward used): wb [K][N] fp32 = w*b, wext [K][N+K] (T) columns < N = w*a, e [K] = w d
-int simclr_bn_fold_pre(const void* w, const float* a, const float* b, const float* d, float* wb, void* wext, float* e,
-                       int K, int N, int dtype, hipStream_t stream) {
+// w [K][N] (T: the compute copy the forward used) and the BN-backward quantities (scale, mean, rstd of the BN; c1 = mean(dm),
+// c2 = mean(dm*x^) from simclr_bn_bwd_finalize): outputs a, b, d [N], wb [K][N] fp32 = w*b, wext [K][N+K] (T) columns < N = w*a,
+// e [K] = w d
+int simclr_bn_fold_pre(const void* w, const float* scale, const float* mean, const float* rstd, const float* c1,
+                       const float* c2, float* a, float* b, float* d, float* wb, void* wext, float* e, int K, int N,
+                       int dtype, hipStream_t stream) {
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "bn_fold_pre: bad dtype %d", dtype);
   if (dtype == SIMCLR_DT_BF16)
-    hipLaunchKernelGGL((bn_fold_pre<uint16_t>), dim3(K), dim3(256), 0, stream, (const uint16_t*)w, a, b, d, wb, (uint16_t*)wext, e, K, N);
+    hipLaunchKernelGGL((bn_fold_pre<uint16_t>), dim3(K), dim3(256), 0, stream, (const uint16_t*)w, scale, mean, rstd, c1, c2,
+                       a, b, d, wb, (uint16_t*)wext, e, K, N);
   else
-    hipLaunchKernelGGL((bn_fold_pre<float>), dim3(K), dim3(256), 0, stream, (const float*)w, a, b, d, wb, (float*)wext, e, K, N);
+    hipLaunchKernelGGL((bn_fold_pre<float>), dim3(K), dim3(256), 0, stream, (const float*)w, scale, mean, rstd, c1, c2, a, b,
+                       d, wb, (float*)wext, e, K, N);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
 
-// dw [K][N] fp32 = a*t1 + b*gw + cs (x) d  (t1 = h^T dm, gw = (h^T h) w, cs [K] fp64 = colsum h);  wext columns N.. = q^T (q [K][K] = wb w^T)
-int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* a, const float* b, const float* d,
-                        const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype, hipStream_t stream) {
+// dw [K][N] fp32 = a*t1 + b*gw + cs (x) d  (t1 = h^T dm, gw = (h^T h) w, cs [K] = colsum h as fp64 `cs` or fp32 `cs32`);  wext columns N.. = q^T (q [K][K] = wb w^T)
+int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* cs32, const float* a, const float* b,
+                        const float* d, const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype,
+                        hipStream_t stream) {
+  SIMCLR_CHECK_ARG((cs != nullptr) != (cs32 != nullptr), "bn_fold_post: give the column sums as fp64 OR fp32");
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "bn_fold_post: bad dtype %d", dtype);
   const long long total = (long long)K * N + (long long)K * K;
   const int grid = (int)min((total + 255) / 256, 1ll << 20);
   if (dtype == SIMCLR_DT_BF16)
-    hipLaunchKernelGGL((bn_fold_post<uint16_t>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, a, b, d, q, dw, (uint16_t*)wext, K, N, accumulate);
+    hipLaunchKernelGGL((bn_fold_post<uint16_t>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, cs32, a, b, d, q, dw, (uint16_t*)wext, K, N, accumulate);
   else
-    hipLaunchKernelGGL((bn_fold_post<float>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, a, b, d, q, dw, (float*)wext, K, N, accumulate);
+    hipLaunchKernelGGL((bn_fold_post<float>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, cs32, a, b, d, q, dw, (float*)wext, K, N, accumulate);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -1139,7 +1139,10 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
 // ------------------------------------------------------------------------------------
 //   WK x WNN waves: 2 x 2 (128 x 128 and smaller tiles, 2-3 workgroups per CU) or 2 x 4 (256 x 256 tile, one
 //   8-wave workgroup per CU: half the L2->LDS bytes per FLOP for the layers whose reduction is short).
-template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2>
+// GRAM: the "gradient" operand IS the activation tile (dy == x, BNW == BKW, one tile spans all channels): h^T h with a single
+// DMA stream, plus the column sums of h from one extra MFMA per k-fragment against an all-ones fragment (slab layout
+// [K*K | K]).  Used by the folded BatchNorm backward (csrc/bn.hip bn_fold_*).
+template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false>
 __global__ __launch_bounds__(WK * WNN * 64,
                              WK * WNN == 8 ? 1 : ((STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
 void conv_wgrad_dma(const WgradP p) {
@@ -1193,6 +1196,11 @@ void conv_wgrad_dma(const WgradP p) {
   for (int i = 0; i < KI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 acs[KI];          // GRAM: column sums (every n row of the fragment holds the same value)
+#pragma unroll
+  for (int i = 0; i < KI; ++i) acs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int LPC = GRAM ? AJ : AJ + BJ;       // LDS-DMA instructions per wave per chunk
 
   const int nchunks = (p.M + BR - 1) / BR;
   const int c_begin = split * p.chunks_per_split;
@@ -1280,12 +1288,14 @@ void conv_wgrad_dma(const WgradP p) {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(a_dst + j * 1024), 16, 0, 0);
       }
     }
+    if (!GRAM) {
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      const void* src = (b_m[j] < p.M && b_cok[j]) ? (const void*)b_ptr[j] : p.zero;
-      b_ptr[j] += b_step;
-      b_m[j] += BR;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
+      for (int j = 0; j < BJ; ++j) {
+        const void* src = (b_m[j] < p.M && b_cok[j]) ? (const void*)b_ptr[j] : p.zero;
+        b_ptr[j] += b_step;
+        b_m[j] += BR;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
+      }
     }
   };
   auto elem_off = [&](int RB, int NBLK, int px, int ch) -> int {
@@ -1295,7 +1305,7 @@ void conv_wgrad_dma(const WgradP p) {
   auto compute = [&](int stage) __attribute__((always_inline)) {
     if (DIAG(1)) return;
     const unsigned char* As = smem + stage * BUF;
-    const unsigned char* Bs = As + BR * A_RB;
+    const unsigned char* Bs = GRAM ? As : As + BR * A_RB;
     if (sizeof(T) == 2) {
 #pragma unroll
       for (int ks = 0; ks < BR / 32; ++ks) {
@@ -1323,6 +1333,13 @@ void conv_wgrad_dma(const WgradP p) {
           for (int ni = 0; ni < NI; ++ni)
             acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(bf16x8, bf[ni]), __builtin_bit_cast(bf16x8, af[ki]), acc[ki][ni], 0, 0, 0);
+        if (GRAM && wn == 0) {
+          const u32x4 ones = (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // eight bf16 1.0
+#pragma unroll
+          for (int ki = 0; ki < KI; ++ki)
+            acs[ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
+                                                              __builtin_bit_cast(bf16x8, af[ki]), acs[ki], 0, 0, 0);
+        }
       }
     } else {
 #pragma unroll 4
@@ -1340,6 +1357,10 @@ void conv_wgrad_dma(const WgradP p) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni], af[ki], acc[ki][ni], 0, 0, 0);
+        if (GRAM && wn == 0) {
+#pragma unroll
+          for (int ki = 0; ki < KI; ++ki) acs[ki] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[ki], acs[ki], 0, 0, 0);
+        }
       }
     }
   };
@@ -1353,16 +1374,16 @@ void conv_wgrad_dma(const WgradP p) {
   for (int c = c_begin; c < c_end; ++c) {
     // chunk c must have landed; newer chunks may stay in flight (each wave issued AJ+BJ loads per chunk)
     const int ahead = issued - c - 1;
-    if (STAGES >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AJ + BJ)) : "memory");
-    else if (STAGES >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
+    if (STAGES >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPC) : "memory");
+    else if (STAGES >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (issued < c_end) { issue(is); ++issued; is = (is + 1 == STAGES) ? 0 : is + 1; }
     compute(cs);
     cs = (cs + 1 == STAGES) ? 0 : cs + 1;
   }
-  // D[n = g*4+reg][k row = fl]  ->  slab[split][kk][n .. n+3]
-  float* slab = p.dw + (long long)split * p.K * p.N;
+  // D[n = g*4+reg][k row = fl]  ->  slab[split][kk][n .. n+3]   (GRAM: every slab carries K extra floats = column sums)
+  float* slab = p.dw + (long long)split * ((long long)p.K * p.N + (GRAM ? p.K : 0));
 #pragma unroll
   for (int ki = 0; ki < KI; ++ki) {
     const int kk = kk0 + wk * (KI * 16) + ki * 16 + fl;
@@ -1373,6 +1394,7 @@ void conv_wgrad_dma(const WgradP p) {
         *(float4*)(slab + (long long)kk * p.N + n) =
             make_float4(acc[ki][ni][0], acc[ki][ni][1], acc[ki][ni][2], acc[ki][ni][3]);
     }
+    if (GRAM && wn == 0 && g == 0 && kk < p.K) slab[(long long)p.K * p.N + kk] = acs[ki][0];
   }
 }
 
@@ -1566,6 +1588,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
             make_float4(acc[t][ki][ni][0], acc[t][ki][ni][1], acc[t][ki][ni][2], acc[t][ki][ni][3]);
       }
     }
+}
+
+// C[m][n] = sum_k A[m][k] * B[n][k]   (fp32, row-major, K contiguous in both; m, n multiples of 16, k of 16).
+// Small helper GEMM of the folded BatchNorm backward ((W*b) W^T and (h^T h) W: at most 512 x 2048 x 2048): one wave per
+// 16 x 64 output strip, fragments loaded straight from global memory (the operands are L2 resident), exact f32 MFMA.
+__global__ __launch_bounds__(256) void small_gemm_nt_f32(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fl = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 64 + wave * 16;
+  const int n0 = blockIdx.x * 64;
+  if (m0 >= M) return;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* ap = A + (long long)(m0 + fl) * K + 4 * q;
+  for (int k = 0; k < K; k += 16) {
+    const float4 av = *(const float4*)(ap + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j * 16 + fl;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) bv = *(const float4*)(B + (long long)n * K + k + 4 * q);
+      // D[n-row = g*4+reg][m-col = fl]: B fragment as the first operand, like the conv kernels
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, av.x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, av.y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.z, av.z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.w, av.w, acc[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j * 16 + q * 4;
+    if (n < N) *(float4*)(C + (long long)(m0 + fl) * N + n) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  }
 }
 
 // dw[i] = sum_s slabs[s][i]  (+ dw[i] if accumulate).  One float4 per thread; the slab loop is unrolled by 8
@@ -2245,6 +2302,60 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   const long long numel = (long long)p.K * p.N;
   hipLaunchKernelGGL(slab_reduce, dim3(max(1, min(1 << 20, ceil_div(numel / 4, 256)))), dim3(256), 0, stream,
                      (const float*)workspace, p.splits, numel, dw, accumulate);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// h^T h and the column sums of h for an activation h [M = V*H*W rows][K channels] (T): out [K*K + K] fp32
+// (Gram matrix row-major, then the K column sums).  K in {64, 128, 256}: one tile spans all channels, the activation
+// is streamed ONCE.  workspace: simclr_conv2d_gram_workspace_bytes.
+size_t simclr_conv2d_gram_workspace_bytes(long long M, int K, int dtype) {
+  int cps;
+  const int br = (dtype == SIMCLR_DT_BF16 ? 64 : 32);
+  const int splits = wgrad_splits(M, K, K, K, K, K == 256 ? br / 2 : br, &cps);
+  return (size_t)splits * ((size_t)K * K + K) * sizeof(float);
+}
+int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, int K, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_gram: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(K == 64 || K == 128 || (K == 256 && dtype == SIMCLR_DT_BF16), "conv2d_gram: K=%d not supported (64, 128, bf16 256)", K);
+  SIMCLR_CHECK_ARG(M > 0 && M < (1ll << 31), "conv2d_gram: bad M");
+  WgradP p = {};
+  p.x = h; p.dy = h; p.dw = (float*)workspace;
+  p.V = 1; p.IH = 1; p.IW = (int)M; p.IC = K; p.OH = 1; p.OW = (int)M; p.N = K;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pixpitch = K;
+  p.M = (int)M; p.K = K;
+  const int br = (dtype == SIMCLR_DT_BF16 ? 64 : 32) / (K == 256 ? 2 : 1);
+  p.splits = wgrad_splits(M, K, K, K, K, br, &p.chunks_per_split);
+  p.k_tiles = 1; p.n_tiles = 1; p.xcd_map = 1;
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d_gram: zero page symbol not found");
+  const int grid = ceil_div(p.splits, 8) * 8;
+  const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
+  if (K == 256) {
+    const size_t lds = (size_t)4 * br * (K + K) * esz;
+    hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 256, 1, 4, 2, 4, true>), dim3(grid), dim3(512), lds, stream, p);
+  } else {
+    const size_t lds = (size_t)2 * br * (K + K) * esz;
+    if (dtype == SIMCLR_DT_BF16) {
+      if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 64, 64, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 128, 128, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+    } else {
+      if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<float, 64, 64, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_dma<float, 128, 128, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+    }
+  }
+  SIMCLR_CHECK_LAUNCH();
+  const long long numel = (long long)K * K + K;
+  hipLaunchKernelGGL(slab_reduce, dim3(max(1, min(1 << 20, ceil_div(numel / 4, 256)))), dim3(256), 0, stream,
+                     (const float*)workspace, p.splits, numel, out, 0);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// C [M][N] = A [M][K] B[N][K]^T in fp32 on the matrix cores; M, N multiples of 16, K of 16 (small helper GEMMs)
+int simclr_small_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % 16 == 0 && N % 16 == 0 && K % 16 == 0, "small_gemm_nt_f32: M=%d N=%d K=%d must be multiples of 16", M, N, K);
+  hipLaunchKernelGGL(small_gemm_nt_f32, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, stream, A, B, C, M, N, K);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -566,23 +566,54 @@ def bn_fold_coeffs(scale, mean, rstd, c1, c2):
     return a, b, d
 
 
-def bn_fold_pre(w_d, a, b, d):
-    """w_d [K][N] (compute copy, = the conv's dgrad layout).  Returns (wb [K,N] f32 = w*b, wext [K, N+K] (first N columns
-    = w*a, the rest filled by bn_fold_post), e [K] f32 = w d)."""
+def bn_fold_pre(w_d, scale, mean, rstd, c1, c2):
+    """w_d [K][N] (compute copy, = the conv's dgrad layout) + the BN-backward quantities.  Returns (a, b, d [N],
+    wb [K,N] f32 = w*b, wext [K, N+K] (first N columns = w*a, the rest filled by bn_fold_post), e [K] f32 = w d)."""
     K, N = w_d.shape
-    wb = torch.empty(K, N, device=w_d.device, dtype=torch.float32)
-    wext = torch.empty(K, N + K, device=w_d.device, dtype=w_d.dtype)
-    e = torch.empty(K, device=w_d.device, dtype=torch.float32)
-    lib().bn_fold_pre(_p(w_d), _p(a), _p(b), _p(d), _p(wb), _p(wext), _p(e), K, N, dt(w_d), _s())
-    return wb, wext, e
+    dev = w_d.device
+    a, b, d = (torch.empty(N, device=dev, dtype=torch.float32) for _ in range(3))
+    wb = torch.empty(K, N, device=dev, dtype=torch.float32)
+    wext = torch.empty(K, N + K, device=dev, dtype=w_d.dtype)
+    e = torch.empty(K, device=dev, dtype=torch.float32)
+    lib().bn_fold_pre(_p(w_d), _p(scale), _p(mean), _p(rstd), _p(c1), _p(c2), _p(a), _p(b), _p(d), _p(wb), _p(wext), _p(e),
+                      K, N, dt(w_d), _s())
+    return a, b, d, wb, wext, e
 
 
 def bn_fold_post(t1, gw, cs, a, b, d, q, dw, wext, accumulate=False):
+    """cs: column sums of h, fp64 [>=K] (bn_reduce_slots output) or fp32 [K] (conv2d_gram)."""
     K, N = t1.shape
-    assert cs.dtype == torch.float64 and tuple(q.shape) == (K, K) and tuple(dw.shape) == (K, N)
-    lib().bn_fold_post(_p(t1), _p(gw), _p(cs), _p(a), _p(b), _p(d), _p(q), _p(dw), _p(wext), K, N, int(accumulate),
+    assert tuple(q.shape) == (K, K) and tuple(dw.shape) == (K, N) and cs.is_contiguous()
+    c64, c32 = (_p(cs), None) if cs.dtype == torch.float64 else (None, _p(cs))
+    lib().bn_fold_post(_p(t1), _p(gw), c64, c32, _p(a), _p(b), _p(d), _p(q), _p(dw), _p(wext), K, N, int(accumulate),
                        dt(wext), _s())
     return dw
+
+
+def conv2d_gram(h):
+    """h [..., K] activation -> (h^T h [K, K] fp32, colsum(h) [K] fp32), streaming h once (K in {64, 128, 256 bf16})."""
+    K = h.shape[-1]
+    M = h.numel() // K
+    out = torch.empty(K * K + K, device=h.device, dtype=torch.float32)
+    ws = _workspace(lib().conv2d_gram_workspace_bytes(M, K, dt(h)), h.device)
+    esz = h.element_size()
+    _launch('conv_wgrad', 2.0 * M * K * K, esz * M * K + 4 * K * K,
+            lambda: lib().conv2d_gram(_p(h), _p(out), _p(ws), M, K, dt(h), _s()))
+    return out[:K * K].view(K, K), out[K * K:]
+
+
+def gram_supported(K, dtype):
+    return K in (64, 128) or (K == 256 and dtype == torch.bfloat16)
+
+
+def small_gemm_nt(A, B):
+    """A [M, K] fp32, B [N, K] fp32 -> A B^T [M, N] fp32 (exact f32 MFMA; small matrices)."""
+    M, K = A.shape
+    N = B.shape[0]
+    assert A.dtype == torch.float32 and B.dtype == torch.float32 and B.shape[1] == K
+    C = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    lib().small_gemm_nt_f32(_p(A), _p(B), _p(C), M, N, K, _s())
+    return C
 
 
 def conv2d_dgrad_bn_ext(dm, h, wext, bias, bn, out=None, accumulate=False):

@@ -436,16 +436,18 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         V, H, W, K = h.shape
         N = self.cout_p
         st = bn_out.saved
-        a, b, d = ops.bn_fold_coeffs(st['scale'], st['mean'], st['rstd'], coeffs[0], coeffs[1])
-        wb, wext, e = ops.bn_fold_pre(self.w_d, a, b, d)
+        a, b, d, wb, wext, e = ops.bn_fold_pre(self.w_d, st['scale'], st['mean'], st['rstd'], coeffs[0], coeffs[1])
         w_d32, w_t32 = self._f32_copies()
-        q = ops.conv2d_fwd(wb.view(K, 1, 1, N), w_d32, 1, 1, 1, 0, 1, 1).view(K, K)           # (W*b) W^T
+        q = ops.small_gemm_nt(wb, w_d32)                                                        # (W*b) W^T   [K, K]
         if self.kernel.trainable:
             with _wgrad_side_stream(h, dm):
-                t1 = ops.conv2d_wgrad(h, dm, 1, 1, 1, 0)                                        # h^T dm   [K, N]
-                g = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)                                          # h^T h    [K, K]
-                cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, RT.const(K, 0.0), RT.const(K, 1.0), 0))
-                gw = ops.conv2d_fwd(g.view(K, 1, 1, K), w_t32, 1, 1, 1, 0, 1, 1).view(K, N)    # (h^T h) W
+                t1 = ops.conv2d_wgrad(h, dm, 1, 1, 1, 0)                                        # h^T dm      [K, N]
+                if ops.gram_supported(K, h.dtype):
+                    g, cs = ops.conv2d_gram(h)                                                  # h^T h, colsum(h): ONE pass over h
+                else:
+                    g = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)
+                    cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, RT.const(K, 0.0), RT.const(K, 1.0), 0))
+                gw = ops.small_gemm_nt(g, w_t32)                                                # (h^T h) W   [K, N]
                 ops.bn_fold_post(t1, gw, cs, a, b, d, q, self.kernel.ensure_grad().view(K, N), wext)
         else:
             z = torch.zeros(K, N, device=h.device)

@@ -1178,14 +1178,24 @@ def check_bn_fold(V, H, K, N, dtype, seed=0, mask_mode=2):
     mean = 0.2 * torch.randn(K, device=DEV, generator=g)
     rstd = 0.5 + torch.rand(K, device=DEV, generator=g)
     # device path (the sequence of Conv2dFixedPadding.backward_folded)
-    wb, wext, e = ops.bn_fold_pre(w, a, b, d)
+    # BN quantities that reproduce the chosen (a, b, d): a = scale, b = -scale*c2*rstd, d = scale*(c2*mean*rstd - c1)
+    bscale, brstd = a, torch.ones(N, device=DEV)
+    bmean = 0.3 * torch.randn(N, device=DEV, generator=g)
+    c2v = -b / a
+    c1v = c2v * bmean - d / a
+    a2, b2, d2, wb, wext, e = ops.bn_fold_pre(w, bscale, bmean, brstd, c1v, c2v)
+    a, b, d = a2, b2, d2                                            # use exactly what the kernel derived (fp32 rounding)
     w32 = w.float()
-    q = ops.conv2d_fwd(wb.view(K, 1, 1, N), w32, 1, 1, 1, 0, 1, 1).view(K, K)
+    q = ops.small_gemm_nt(wb, w32)
     t1 = ops.conv2d_wgrad(h, dm, 1, 1, 1, 0)
-    gm = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)
+    gm2 = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)                    # generic path (any K) ...
     ones, zeros = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
-    cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, zeros, ones, 0))
-    gw = ops.conv2d_fwd(gm.view(K, 1, 1, K), w32.t().contiguous(), 1, 1, 1, 0, 1, 1).view(K, N)
+    cs2 = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, zeros, ones, 0))
+    if ops.gram_supported(K, dtype):                            # ... and the single-pass Gram + column-sum kernel
+        gm, cs = ops.conv2d_gram(h)
+    else:
+        gm, cs = gm2, cs2
+    gw = ops.small_gemm_nt(gm, w32.t().contiguous())
     dw = torch.empty(K, N, device=DEV)
     ops.bn_fold_post(t1, gw, cs, a, b, d, q, dw, wext)
     bn = dict(x=bn_x, mask=None, scale=scale, shift=shift, mean=mean, rstd=rstd, mode=mask_mode)
@@ -1204,7 +1214,11 @@ def check_bn_fold(V, H, K, N, dtype, seed=0, mask_mode=2):
     tag = 'V%d %dx%d %d->%d %s' % (V, H, H, K, N, str(dtype).split('.')[-1])
     bf = dtype == torch.bfloat16
     l1 = float((dmi_ref.abs().sum(0) + (dmi_ref * xh).abs().sum(0)).max())
-    return [_res('bn_fold_colsum ' + tag, cs[0], h64.sum(0), 1e-6),
+    gram_ref = h64.t() @ h64
+    return [_res('bn_fold_colsum ' + tag, cs2[0], h64.sum(0), 1e-6),
+            _res('bn_fold_colsum_gramkernel ' + tag, cs[0] if cs.dim() == 2 else cs, h64.sum(0), 2e-6),
+            _res('bn_fold_gram ' + tag, gm, gram_ref, 2e-5), _res('bn_fold_gram_generic ' + tag, gm2, gram_ref, 2e-5),
+            _res('bn_fold_q ' + tag, q, (w.double() * b.double()) @ w.double().t(), 2e-5),
             _res('bn_fold_dw ' + tag, dw, dw_ref, 2e-3 if bf else 2e-4),
             _res('bn_fold_dgrad_dm ' + tag, dmi.double().view(M, K), dmi_ref, 1.5e-2 if bf else 2e-4),
             _res('bn_fold_dgrad_sum ' + tag, sums[0], dmi_ref.sum(0), 0, (2e-3 if bf else 1e-4) * l1),
