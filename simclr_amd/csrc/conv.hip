@@ -1162,7 +1162,7 @@ void conv_wgrad_dma(const WgradP p) {
   constexpr int AJ = BR / A_RPI / NW;         // DMA instructions per wave per chunk
   constexpr int BJ = BR / B_RPI / NW;
   static_assert(AJ >= 1 && BJ >= 1 && A_CPR <= 64 && B_CPR <= 64, "tile / chunk configuration");
-  constexpr int BUF = BR * (A_RB + B_RB);     // bytes per stage: [A tile | B tile]
+  constexpr int BUF = GRAM ? BR * A_RB : BR * (A_RB + B_RB);     // bytes per stage: [A tile | B tile] (GRAM: A only)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -2312,7 +2312,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
 size_t simclr_conv2d_gram_workspace_bytes(long long M, int K, int dtype) {
   int cps;
   const int br = (dtype == SIMCLR_DT_BF16 ? 64 : 32);
-  const int splits = wgrad_splits(M, K, K, K, K, K == 256 ? br / 2 : br, &cps);
+  const int splits = wgrad_splits(M, K, K, K, K, K == 256 ? br / 2 : br, &cps, K == 256 ? 512 : 1024, K == 256 ? 512 : 1024);
   return (size_t)splits * ((size_t)K * K + K) * sizeof(float);
 }
 int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, int K, int dtype, hipStream_t stream) {
@@ -2325,23 +2325,25 @@ int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, 
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pixpitch = K;
   p.M = (int)M; p.K = K;
   const int br = (dtype == SIMCLR_DT_BF16 ? 64 : 32) / (K == 256 ? 2 : 1);
-  p.splits = wgrad_splits(M, K, K, K, K, br, &p.chunks_per_split);
+  // one tile per pixel range: up to 1024 workgroups (4 per CU) share the streaming
+  p.splits = wgrad_splits(M, K, K, K, K, br, &p.chunks_per_split, K == 256 ? 512 : 1024, K == 256 ? 512 : 1024);
   p.k_tiles = 1; p.n_tiles = 1; p.xcd_map = 1;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d_gram: zero page symbol not found");
   const int grid = ceil_div(p.splits, 8) * 8;
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
   if (K == 256) {
-    const size_t lds = (size_t)4 * br * (K + K) * esz;
+    const size_t lds = (size_t)4 * br * K * esz;
     hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 256, 1, 4, 2, 4, true>), dim3(grid), dim3(512), lds, stream, p);
   } else {
-    const size_t lds = (size_t)2 * br * (K + K) * esz;
+    // 4-stage ring of 64-pixel (bf16) chunks holding the activation tile only: three chunks in flight per workgroup
+    const size_t lds = (size_t)4 * br * K * esz;
     if (dtype == SIMCLR_DT_BF16) {
-      if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 64, 64, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
-      else hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 128, 128, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+      if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 64, 64, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 128, 128, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
     } else {
-      if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<float, 64, 64, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
-      else hipLaunchKernelGGL((conv_wgrad_dma<float, 128, 128, 2, 2, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+      if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<float, 64, 64, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((conv_wgrad_dma<float, 128, 128, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
     }
   }
   SIMCLR_CHECK_LAUNCH();
