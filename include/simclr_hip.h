@@ -157,6 +157,17 @@ int simclr_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* sh
 int simclr_maxpool_bwd(const void* dy, const unsigned char* arg, void* dx, int V, int H, int W, int C,
                        int OH, int OW, int ksz, int stride, int pad_t, int pad_l, int dtype,
                        simclr_stream_t stream);
+/* Stem backward with the max-pool backward fused in (the gradient wrt the BN+ReLU output is never written): BN-backward
+ * reduce and apply straight from the pooled gradient + arg-max taps (tf2/resnet.py:602-611 under tape.gradient). */
+int simclr_bn_bwd_pool_slots(long long rows, int C, int dtype);
+int simclr_bn_bwd_reduce_pool(const void* dy, const unsigned char* arg, const void* x, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, int V, int H, int W, int C,
+                              int OH, int OW, int ksz, int stride, int pad_t, int pad_l, float* partial, int nslot,
+                              int dtype, simclr_stream_t stream);
+int simclr_bn_bwd_apply_pool(const void* dy, const unsigned char* arg, const void* x, const float* scale,
+                             const float* shift, const float* mean, const float* rstd, const float* c1, const float* c2,
+                             void* dx, int V, int H, int W, int C, int OH, int OW, int ksz, int stride, int pad_t, int pad_l,
+                             int dtype, simclr_stream_t stream);
 int simclr_global_avgpool_fwd(const void* x, void* y, int V, int HW, int C, int dtype,
                               simclr_stream_t stream);
 int simclr_global_avgpool_fwd_f32(const void* x, float* y32, int V, int HW, int C, int dtype,

@@ -132,6 +132,125 @@ __global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict_
   }
 }
 
+// Gradient wrt the ReLU output at input pixel (v, iy, ix), channels c0..c0+EPC-1, gathered from the pooled gradient and
+// the arg-max taps (the body of maxpool_bwd): the (at most ceil(k/s)^2) windows containing the pixel, fixed order.
+template <typename T>
+__device__ __forceinline__ void maxpool_gather(const T* __restrict__ dy, const uint8_t* __restrict__ arg, int v, int iy, int ix,
+                                               int c0, int C, int OH, int OW, int ksz, int stride, int pad_t, int pad_l,
+                                               float* acc) {
+  constexpr int EPC = Elem<T>::EPC;
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  const int ty = iy + pad_t, tx = ix + pad_l;
+  const int oy_hi = min(OH - 1, ty / stride), ox_hi = min(OW - 1, tx / stride);
+  const int oy_lo = max(0, (ty - ksz + stride) / stride), ox_lo = max(0, (tx - ksz + stride) / stride);
+  for (int oy = oy_hi; oy >= oy_lo; --oy) {
+    const int ky = ty - oy * stride;
+    for (int ox = ox_hi; ox >= ox_lo; --ox) {
+      const int kx = tx - ox * stride;
+      const long long op = (((long long)v * OH + oy) * OW + ox) * C + c0;
+      float d[EPC];
+      chunk_to_f32<T>(*(const u32x4*)(dy + op), d);
+      const uint32_t tapid = (uint32_t)(ky * ksz + kx);
+      const uint32_t* ap = (const uint32_t*)(arg + op);
+#pragma unroll
+      for (int q = 0; q < EPC / 4; ++q) {
+        const uint32_t w = ap[q];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (((w >> (8 * b)) & 0xffu) == tapid) acc[4 * q + b] += d[4 * q + b];
+      }
+    }
+  }
+}
+
+// Stem backward without the un-pooled gradient tensor: BatchNorm-backward REDUCE straight from the pooled gradient.
+// partial[slot][2][C] = (sum dm, sum dm * x^) with dm = maxpool_bwd(dy)[pixel] * (x*scale+shift > 0); one slot per
+// workgroup (plain stores: deterministic).  Same thread layout as bn_bwd_reduce: C/EPC channel chunks x row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool(
+    const T* __restrict__ dy, const uint8_t* __restrict__ arg, const T* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd, int V, int H, int W,
+    int C, int OH, int OW, int ksz, int stride, int pad_t, int pad_l, int rows_per_block, float* __restrict__ partial) {
+  constexpr int EPC = Elem<T>::EPC;
+  __shared__ float red[256 * 2 * EPC];
+  const int cpr = C / EPC;                     // <= 256 (checked by the host)
+  const int rl = 256 / cpr;
+  const int tcol = threadIdx.x % cpr, trow = threadIdx.x / cpr;
+  const long long rows = (long long)V * H * W;
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const int c0 = tcol * EPC;
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (trow < rl) {
+    float mu[EPC], rs[EPC], sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+    for (long long r = r0 + trow; r < r1; r += rl) {
+      const unsigned row = (unsigned)(r / W);
+      const int ix = (int)(r - (long long)row * W), v = (int)(row / (unsigned)H), iy = (int)(row - (unsigned)v * H);
+      float d[EPC], xf[EPC];
+      maxpool_gather<T>(dy, arg, v, iy, ix, c0, C, OH, OW, ksz, stride, pad_t, pad_l, d);
+      chunk_to_f32<T>(*(const u32x4*)(x + r * C + c0), xf);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float dm = fmaf(xf[e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
+        s1[e] += dm;
+        s2[e] += dm * (xf[e] - mu[e]) * rs[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    red[(threadIdx.x * EPC + e) * 2] = s1[e];
+    red[(threadIdx.x * EPC + e) * 2 + 1] = s2[e];
+  }
+  __syncthreads();
+  if (trow == 0) {
+    float* slot = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < rl; ++q) {
+        a += red[((q * cpr + tcol) * EPC + e) * 2];
+        b += red[((q * cpr + tcol) * EPC + e) * 2 + 1];
+      }
+      slot[c0 + e] = a;
+      slot[C + c0 + e] = b;
+    }
+  }
+}
+
+// ... and the APPLY: dx = scale * (dm - c1 - x^ * c2), dm gathered / masked as above
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool(
+    const T* __restrict__ dy, const uint8_t* __restrict__ arg, const T* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ c1, const float* __restrict__ c2, T* __restrict__ dx, int V, int H, int W, int C, int OH,
+    int OW, int ksz, int stride, int pad_t, int pad_l) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long long total = (long long)V * H * W * cpr;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256ll) {
+    const unsigned pix = (unsigned)(i / cpr);
+    const int c0 = (int)(i - (long long)pix * cpr) * EPC;
+    const unsigned row = pix / (unsigned)W;
+    const int ix = (int)(pix - row * W), v = (int)(row / (unsigned)H), iy = (int)(row - (unsigned)v * H);
+    float d[EPC], xf[EPC], o[EPC];
+    maxpool_gather<T>(dy, arg, v, iy, ix, c0, C, OH, OW, ksz, stride, pad_t, pad_l, d);
+    chunk_to_f32<T>(*(const u32x4*)(x + (long long)pix * C + c0), xf);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float sc = scale[c0 + e];
+      const float dm = fmaf(xf[e], sc, shift[c0 + e]) > 0.f ? d[e] : 0.f;
+      const float xh = (xf[e] - mean[c0 + e]) * rstd[c0 + e];
+      o[e] = sc * (dm - c1[c0 + e] - xh * c2[c0 + e]);
+    }
+    *(u32x4*)(dx + (long long)pix * C + c0) = f32_to_chunk<T>(o);
+  }
+}
+
 // y[v][c] = mean over HW of x[v][hw][c]
 // y32 (nullable): also / instead write the fp32 means (the heads may run in fp32 on top of a bf16 encoder: rounding the
 // mean of HW bf16 values back to bf16 would throw away the sqrt(HW) averaging gain right before the head's BatchNorm)
@@ -580,6 +699,57 @@ int simclr_global_avgpool_fwd_f32(const void* x, float* y32, int V, int HW, int 
 }
 
 // dx = dy/HW broadcast; mask_src (nullable, same shape as dx): zero where mask_src <= 0
+// Stem backward fused with the max-pool backward (tf2/resnet.py:602-611 under tape.gradient): the gradient wrt the stem
+// BN+ReLU output is never materialised.  dy [V,OH,OW,C] pooled gradient, arg uint8 tap ids (simclr_bnrelu_maxpool_fwd),
+// x [V,H,W,C] raw stem-conv output.  reduce: partial [slots][2][C] with slots = simclr_bn_bwd_pool_slots (one per workgroup).
+static int bwd_pool_grid(long long rows, int C, int epc, int* rows_per_block) {
+  const int rl = 256 / max(1, C / epc);
+  *rows_per_block = (int)max((long long)rl * 8, (rows + 2047) / 2048);
+  return (int)((rows + *rows_per_block - 1) / *rows_per_block);
+}
+int simclr_bn_bwd_pool_slots(long long rows, int C, int dtype) {
+  int rpb;
+  return bwd_pool_grid(rows, C, dtype == SIMCLR_DT_BF16 ? 8 : 4, &rpb);
+}
+int simclr_bn_bwd_reduce_pool(const void* dy, const unsigned char* arg, const void* x, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, int V, int H, int W, int C,
+                              int OH, int OW, int ksz, int stride, int pad_t, int pad_l, float* partial, int nslot,
+                              int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0 && C / epc <= 256 && 256 % (C / epc) == 0, "bn_bwd_reduce_pool: C=%d not supported", C);
+  SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "bn_bwd_reduce_pool: pixel count overflows int32");
+  int rpb;
+  const int grid = bwd_pool_grid((long long)V * H * W, C, epc, &rpb);
+  SIMCLR_CHECK_ARG(nslot >= grid, "bn_bwd_reduce_pool: need %d slots (simclr_bn_bwd_pool_slots), got %d", grid, nslot);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bn_bwd_reduce_pool<uint16_t>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)dy, arg,
+                                (const uint16_t*)x, scale, shift, mean, rstd, V, H, W, C, OH, OW, ksz, stride, pad_t, pad_l,
+                                rpb, partial),
+             hipLaunchKernelGGL((bn_bwd_reduce_pool<float>), dim3(grid), dim3(256), 0, stream, (const float*)dy, arg,
+                                (const float*)x, scale, shift, mean, rstd, V, H, W, C, OH, OW, ksz, stride, pad_t, pad_l, rpb,
+                                partial));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+int simclr_bn_bwd_apply_pool(const void* dy, const unsigned char* arg, const void* x, const float* scale,
+                             const float* shift, const float* mean, const float* rstd, const float* c1, const float* c2,
+                             void* dx, int V, int H, int W, int C, int OH, int OW, int ksz, int stride, int pad_t, int pad_l,
+                             int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply_pool: C %% %d != 0", epc);
+  SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "bn_bwd_apply_pool: pixel count overflows int32");
+  const long long total = (long long)V * H * W * (C / epc);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bn_bwd_apply_pool<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream, (const uint16_t*)dy,
+                                arg, (const uint16_t*)x, scale, shift, mean, rstd, c1, c2, (uint16_t*)dx, V, H, W, C, OH, OW,
+                                ksz, stride, pad_t, pad_l),
+             hipLaunchKernelGGL((bn_bwd_apply_pool<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)dy, arg,
+                                (const float*)x, scale, shift, mean, rstd, c1, c2, (float*)dx, V, H, W, C, OH, OW, ksz, stride,
+                                pad_t, pad_l));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
 int simclr_global_avgpool_bwd(const void* dy, const void* mask_src, void* dx, int V, int HW, int C,
                               int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;

@@ -634,3 +634,26 @@ def conv2d_dgrad_bn_ext(dm, h, wext, bias, bn, out=None, accumulate=False):
                                                  _p(bn['rstd']), bn['mode'], _p(partial), partial.shape[0], V, H, W, K, N,
                                                  dt(dm), _s()))
     return out, partial
+
+
+# ---------------------------------------------------------------- stem backward fused with the max-pool backward
+def bn_bwd_reduce_pool(dy, arg, x, scale, shift, mean, rstd, ksz=3, stride=2):
+    V, H, W, C = x.shape
+    _, OH, OW, _ = dy.shape
+    _, pt = same_pad(H, ksz, stride)
+    _, pl = same_pad(W, ksz, stride)
+    partial = new_stats(C, x.device, lib().bn_bwd_pool_slots(V * H * W, C, dt(x)))
+    lib().bn_bwd_reduce_pool(_p(dy), _p(arg), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), V, H, W, C, OH, OW, ksz,
+                             stride, pt, pl, _p(partial), partial.shape[0], dt(x), _s())
+    return partial
+
+
+def bn_bwd_apply_pool(dy, arg, x, scale, shift, mean, rstd, c1, c2, ksz=3, stride=2):
+    V, H, W, C = x.shape
+    _, OH, OW, _ = dy.shape
+    _, pt = same_pad(H, ksz, stride)
+    _, pl = same_pad(W, ksz, stride)
+    dx = torch.empty_like(x)
+    lib().bn_bwd_apply_pool(_p(dy), _p(arg), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(c1), _p(c2), _p(dx), V, H,
+                            W, C, OH, OW, ksz, stride, pt, pl, dt(x), _s())
+    return dx

@@ -489,6 +489,11 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
                                 accumulate=accumulate)
 
 
+def _pool_fusion_enabled():
+    import os
+    return os.environ.get('SIMCLR_POOL_FUSION', '1') not in ('', '0')
+
+
 def _bn_fold_enabled():
     import os
     return os.environ.get('SIMCLR_BN_FOLD', '1') not in ('', '0')
@@ -908,8 +913,19 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
             if on_stage is not None:
                 on_stage(i + 1)
         if self._pool is not None:
-            d = ops.maxpool_bwd(d, self._pool['arg'], self._pool['H'], self._pool['W'], 3, 2)
-            draw, _ = self.stem_bn.backward(d, mask_mode=2)      # ReLU mask recomputed from x*scale+shift
+            sb = self.stem_bn.saved
+            C = sb['x'].shape[-1]
+            epc = 16 // sb['x'].element_size()
+            if _pool_fusion_enabled() and C % epc == 0 and C // epc <= 256 and 256 % (C // epc) == 0:
+                # max-pool backward fused into the stem BN's backward reduce + apply: the un-pooled gradient
+                # ([V,112,112,64], the largest tensor of the backward pass) is never written or re-read
+                part = ops.bn_bwd_reduce_pool(d, self._pool['arg'], sb['x'], sb['scale'], sb['shift'], sb['mean'], sb['rstd'])
+                c1, c2 = self.stem_bn._bwd_finalize(part, sb['count'])
+                draw = ops.bn_bwd_apply_pool(d, self._pool['arg'], sb['x'], sb['scale'], sb['shift'], sb['mean'], sb['rstd'], c1, c2)
+                self.stem_bn.saved = None
+            else:
+                d = ops.maxpool_bwd(d, self._pool['arg'], self._pool['H'], self._pool['W'], 3, 2)
+                draw, _ = self.stem_bn.backward(d, mask_mode=2)      # ReLU mask recomputed from x*scale+shift
             self._pool = None
         else:
             draw, _ = self.stem_bn.backward(d)

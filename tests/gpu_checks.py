@@ -1223,3 +1223,42 @@ def check_bn_fold(V, H, K, N, dtype, seed=0, mask_mode=2):
             _res('bn_fold_dgrad_dm ' + tag, dmi.double().view(M, K), dmi_ref, 1.5e-2 if bf else 2e-4),
             _res('bn_fold_dgrad_sum ' + tag, sums[0], dmi_ref.sum(0), 0, (2e-3 if bf else 1e-4) * l1),
             _res('bn_fold_dgrad_sumxhat ' + tag, sums[1], (dmi_ref * xh).sum(0), 0, (2e-3 if bf else 1e-4) * l1)]
+
+
+def check_pool_bn_bwd_fusion(V, H, C, dtype, seed=0):
+    """Stem backward with the max-pool backward fused into the BatchNorm backward (simclr_bn_bwd_reduce_pool /
+    _apply_pool) vs float64 autograd of relu(x*scale+shift) -> max_pool(3, 2, SAME) (tf2/resnet.py:602-611)."""
+    g = torch.Generator().manual_seed(seed)
+    x = _rand((V, H, H, C), dtype, g) * 1.5 + 0.2
+    gamma = 0.5 + torch.rand(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    xr = x.double().requires_grad_(True)
+    axes = (0, 1, 2)
+    mean = xr.mean(axes)
+    var = ((xr - mean) ** 2).mean(axes)
+    rstd = torch.rsqrt(var + 1e-5)
+    y = F.relu((xr - mean) * rstd * gamma.double() + beta.double())
+    OH, pt = ops.same_pad(H, 3, 2)
+    total = max((OH - 1) * 2 + 3 - H, 0)
+    pr = F.max_pool2d(F.pad(y.permute(0, 3, 1, 2), (pt, total - pt, pt, total - pt), value=float('-inf')), 3, 2)
+    dy = _rand((V, OH, OH, C), dtype, g)
+    pr.backward(dy.double().permute(0, 3, 1, 2))
+    # device: forward pool (gives arg), then the fused backward
+    mean_d, rstd_d = mean.detach().float().to(DEV), rstd.detach().float().to(DEV)
+    scale = (gamma.double() * rstd.detach()).float().to(DEV)
+    shift = (beta.double() - mean.detach() * gamma.double() * rstd.detach()).float().to(DEV)
+    xd = x.to(DEV)
+    _, arg = ops.bnrelu_maxpool_fwd(xd, scale, shift)
+    part = ops.bn_bwd_reduce_pool(dy.to(DEV), arg, xd, scale, shift, mean_d, rstd_d)
+    dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    c1, c2 = ops.bn_bwd_finalize(None, None, V * H * H, dgamma, dbeta, partial=part)
+    dx = ops.bn_bwd_apply_pool(dy.to(DEV), arg, xd, scale, shift, mean_d, rstd_d, c1, c2)
+    # the un-fused sequence must agree with the fused one bit for bit in the gradient it would have produced
+    d_un = ops.maxpool_bwd(dy.to(DEV), arg, H, H)
+    part_un = ops.bn_bwd_reduce(d_un, xd, None, scale, shift, mean_d, rstd_d, 2)
+    torch.cuda.synchronize()
+    tag = 'V%d %d C%d %s' % (V, H, C, str(dtype).split('.')[-1])
+    bf = dtype == torch.bfloat16
+    # in bf16 the un-fused path rounds the un-pooled gradient to bf16 before summing; the fused one sums fp32 values
+    return [_res('poolfuse_dx ' + tag, dx, xr.grad, 1e-2 if bf else 5e-5),
+            _res('poolfuse_sums_vs_unfused ' + tag, ops.bn_reduce_slots(part), ops.bn_reduce_slots(part_un), 2e-3 if bf else 1e-5)]

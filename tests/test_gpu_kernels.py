@@ -382,3 +382,10 @@ def test_batchnorm_backward_folded_into_expand_conv(V, H, K, N, dtype):
     tape.gradient): no bn_bwd_apply pass, K-extended dgrad reading (dm, h).  Includes a multi-tile persistent case."""
     from tests import gpu_checks as gc
     _assert(gc.check_bn_fold(V, H, K, N, dtype))
+
+
+@pytest.mark.parametrize('dtype', [F32, BF])
+@pytest.mark.parametrize('V,H', [(2, 16), (3, 15), (2, 112)])
+def test_stem_backward_with_fused_maxpool_backward(V, H, dtype):
+    from tests import gpu_checks as gc
+    _assert(gc.check_pool_bn_bwd_fusion(V, H, 64, dtype))
