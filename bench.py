@@ -327,10 +327,15 @@ def main():
         if default_cfg and args.dtype == 'bf16' and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get('kernel') == best and int(tj.get('launches_per_step', -1)) == roofline['launches_per_step']:
-                    roofline['traffic'] = round(tj['traffic_bytes_per_launch'])
+                # PMC bytes of the family per STEP (committed rocprofv3 passes of this same command) divided by THIS
+                # run's launches per step, so `traffic` and `achieved` use one definition of a launch (= one library
+                # call; a strided dgrad call dispatches one kernel per output-parity class, hence more dispatches)
+                if tj.get('kernel') == best and tj.get('family_bytes_per_step'):
+                    per_launch = tj['family_bytes_per_step'] / max(roofline['launches_per_step'], 1)
+                    roofline['traffic'] = round(per_launch)
                     roofline['traffic_source'] = 'profiles/r02_pmc_traffic.json'
-                    roofline['traffic_over_algorithmic'] = round(tj['traffic_bytes_per_launch'] / roofline['algorithmic_bytes_per_launch'], 3)
+                    roofline['traffic_kernel_dispatches_per_step'] = tj.get('kernel_dispatches_per_step')
+                    roofline['traffic_over_algorithmic'] = round(per_launch / roofline['algorithmic_bytes_per_launch'], 3)
             except Exception:
                 pass
         if 'ntxent_fwd' in summ and 'ntxent_bwd' in summ:

@@ -5,7 +5,7 @@ On the GPU box (separate passes, as MI355X_MICROARCH.md prescribes -- never comb
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_f -o f -- python $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_events
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_w -o w -- python $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_events
 then
-  python tools/pmc_traffic.py gpurun_out/pmc_f/*counter_collection.csv gpurun_out/pmc_w/*counter_collection.csv profiles/r01_pmc_traffic.json
+  python tools/pmc_traffic.py gpurun_out/pmc_f/*counter_collection.csv gpurun_out/pmc_w/*counter_collection.csv profiles/r02_pmc_traffic.json
 
 Counters are in KB.  FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by exactly 2x on gfx950 (guide, HBM
 section); every streaming load in this library is 16 B/lane, so fetch_corrected = 2 x raw.  WRITE_SIZE is taken as is.
@@ -41,7 +41,7 @@ def main():
     for n in names:
         per.append(dict(kernel=n.replace('void (anonymous namespace)::', '')[:110], calls_per_step=calls.get(n, 0) / STEPS,
                         fetch_raw_bytes=fetch.get(n, 0) / STEPS, write_bytes=write.get(n, 0) / STEPS))
-    fam = [n for n in names if 'conv_igemm_persistent' in n]
+    fam = [n for n in names if 'conv_igemm' in n]          # persistent + the plain fallback: the family bench.py calls conv_igemm
     launches = sum(calls[n] for n in fam) / STEPS
     fr = sum(fetch.get(n, 0) for n in fam) / STEPS
     wr = sum(write.get(n, 0) for n in fam) / STEPS
@@ -49,7 +49,8 @@ def main():
     res = dict(
         note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 1`; KB counters '
              'x1024, halved per step; FETCH_SIZE x2 for 16 B/lane loads (MI355X_MICROARCH.md), WRITE_SIZE as is.',
-        kernel_family='conv_igemm_persistent (fwd + dgrad)', launches_per_step=launches,
+        kernel='conv_igemm', kernel_family='conv_igemm_persistent / conv_igemm (fwd + dgrad)', kernel_dispatches_per_step=launches,
+        family_fetch_corrected_bytes_per_step=2 * fr, family_write_bytes_per_step=wr, family_bytes_per_step=2 * fr + wr,
         fetch_raw_bytes_per_launch=fr / max(launches, 1), fetch_corrected_bytes_per_launch=2 * fr / max(launches, 1),
         write_bytes_per_launch=wr / max(launches, 1), traffic_bytes_per_launch=(2 * fr + wr) / max(launches, 1),
         step_total_bytes=total, per_kernel=per[:40])
