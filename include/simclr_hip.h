@@ -102,7 +102,8 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
  * the BatchNorm-backward reductions sum(dm), sum(dm*x^) are fused into the epilogue; dx receives
  * dm = dx*mask.  stats float[nslot][2][Cin] zeroed by the caller.  mask_mode 1: bn_mask>0 (tensor after the
  * ReLU, e.g. the block output of resnet.py:487); 2: bn_x*scale+shift>0; 3: bn_mask = the bit tensor written by
- * simclr_bn_apply(relu_bits) (16x less traffic than mode 1).  stride 1 only. */
+ * simclr_bn_apply(relu_bits) (16x less traffic than mode 1); 4: as 3 but ONLY sum(dm) is produced and bn_x / bn_mean /
+ * bn_rstd are not read (may be NULL) -- sum(dm*x^) then comes from simclr_bn_fold_s2.  stride 1 only. */
 int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumulate, const void* bn_x,
                            const void* bn_mask, const float* bn_scale, const float* bn_shift,
                            const float* bn_mean, const float* bn_rstd, int mask_mode, float* stats, int nslot,
@@ -222,6 +223,9 @@ int simclr_bn_fold_pre(const void* w, const float* scale, const float* mean, con
 int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* cs32, const float* a, const float* b,
                         const float* d, const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype,
                         simclr_stream_t stream);
+/* sum(dm * x^) of the folded BatchNorm from t1 = h^T dm (no pass over the conv output): sums [2][N] fp64, sums[0] = sum dm given */
+int simclr_bn_fold_s2(const float* t1, const void* w, const float* mean, const float* rstd, double* sums, int K, int N,
+                      int dtype, simclr_stream_t stream);
 /* h^T h [K*K] followed by colsum(h) [K] for h [M][K] (T), K in {64, 128, 256(bf16)}: the activation is streamed once */
 size_t simclr_conv2d_gram_workspace_bytes(long long M, int K, int dtype);
 int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, int K, int dtype, simclr_stream_t stream);

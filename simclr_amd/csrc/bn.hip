@@ -344,6 +344,19 @@ __global__ void bn_fold_coeffs(const float* __restrict__ scale, const float* __r
   d[c] = sc * (c2[c] * mean[c] * rstd[c] - c1[c]);
 }
 
+// sum(dm * x^) of the BatchNorm behind c = h W, WITHOUT reading c or x^: sum_m dm[m,j] c[m,j] = sum_k W[k,j] T1[k,j] with
+// T1 = h^T dm (the weight-gradient GEMM that is computed anyway), so
+//   sums[1][j] = rstd[j] * (sum_k W[k][j] * T1[k][j] - mean[j] * sums[0][j]),      sums[0] = sum dm (already there).
+template <typename T>
+__global__ void bn_fold_s2(const float* __restrict__ t1, const T* __restrict__ w, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, double* __restrict__ sums, int K, int N) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) acc += (double)Elem<T>::ld(w + (long long)k * N + j) * (double)t1[(long long)k * N + j];
+  sums[N + j] = (double)rstd[j] * (acc - (double)mean[j] * sums[j]);
+}
+
 // one workgroup per input channel i (row of W [K][N]):  wb[i][j] = W[i][j]*b[j] (fp32),  wext[i][j] = T(W[i][j]*a[j]) for
 // j < N (row pitch N + K),  e[i] = sum_j W[i][j]*d[j]
 // (the coefficient vectors a, b, d are computed here from the BN quantities and written out by workgroup 0)
@@ -576,6 +589,22 @@ int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, cons
     hipLaunchKernelGGL((bn_fold_post<uint16_t>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, cs32, a, b, d, q, dw, (uint16_t*)wext, K, N, accumulate);
   else
     hipLaunchKernelGGL((bn_fold_post<float>), dim3(grid), dim3(256), 0, stream, t1, gw, cs, cs32, a, b, d, q, dw, (float*)wext, K, N, accumulate);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// sums [2][N] fp64 with sums[0] = sum(dm) valid: fills sums[1] = sum(dm * x^) from t1 = h^T dm [K][N] and w [K][N] (T)
+int simclr_bn_fold_s2(const float* t1, const void* w, const float* mean, const float* rstd, double* sums, int K, int N,
+                      int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "bn_fold_s2: bad dtype %d", dtype);
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((bn_fold_s2<uint16_t>), dim3(ceil_div(N, 128)), dim3(128), 0, stream, t1, (const uint16_t*)w, mean, rstd, sums, K, N);
+  else
+    hipLaunchKernelGGL((bn_fold_s2<float>), dim3(ceil_div(N, 128)), dim3(128), 0, stream, t1, (const float*)w, mean, rstd, sums, K, N);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

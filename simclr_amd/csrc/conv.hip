@@ -51,7 +51,8 @@ struct ConvP {
   const void* bn_x;
   const void* bn_mask;
   const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
-  int bn_mode;     // 0 off, 1 mask tensor, 2 recompute
+  int bn_mode;     // 0 off, 1 mask tensor, 2 recompute, 3 mask bits, 4 mask bits and ONLY sum(dm) (no bn_x: the
+                   // sum(dm * x^) of that BatchNorm is derived from the weight-gradient GEMM, csrc/bn.hip bn_fold_s2)
   // K-extension (EXT instantiations, 1x1 stride-1 dgrad only): after the IC channels of x the reduction continues over
   // ic2 channels of a SECOND tensor x2 at the same pixel (weights rows hold [K | ic2] values), and `bias[n]` is added to
   // every output row.  This is how a BatchNorm backward is folded into the consuming convolution by linearity:
@@ -540,8 +541,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       const bool ok = n < p.N;
       bnp[i] = (ok && p.bn_mode == 2) ? p.bn_scale[n] : 0.f;
       bnp[BN + i] = (ok && p.bn_mode == 2) ? p.bn_shift[n] : 0.f;
-      bnp[2 * BN + i] = ok ? p.bn_mean[n] : 0.f;
-      bnp[3 * BN + i] = ok ? p.bn_rstd[n] : 0.f;
+      bnp[2 * BN + i] = (ok && p.bn_mean) ? p.bn_mean[n] : 0.f;
+      bnp[3 * BN + i] = (ok && p.bn_rstd) ? p.bn_rstd[n] : 0.f;
       if (EXT) bnp[4 * BN + i] = (ok && p.bias) ? p.bias[n] : 0.f;
     }
     // visibility: the first barrier of the k-loop (or the explicit one before the flush) orders these writes
@@ -684,12 +685,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
         for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
       }
       if (BNEPI) {
+        if (p.bn_mode != 4) {
 #pragma unroll
-        for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
+          for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < ER; ++i) e_xv[i] = zero16();
+        }
         if (p.bn_mode == 1) {
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_mv[i] = *(const u32x4*)((const uint16_t*)p.bn_mask + eld[i]);
-        } else if (p.bn_mode == 3) {       // one mask byte per 8-channel chunk (written by simclr_bn_apply)
+        } else if (p.bn_mode >= 3) {       // one mask byte per 8-channel chunk (written by simclr_bn_apply)
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_mv[i][0] = ((const unsigned char*)p.bn_mask)[eld[i] >> 3];
         }
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
           chunk_to_f32<uint16_t>(e_xv[i], xf);
           if (p.bn_mode == 1) {
             chunk_to_f32<uint16_t>(e_mv[i], mk);
-          } else if (p.bn_mode == 3) {
+          } else if (p.bn_mode >= 3) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) mk[e] = ((e_mv[i][0] >> e) & 1u) ? 1.f : 0.f;
           } else {
@@ -770,8 +776,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
           if (BNEPI) {
             // v = gradient wrt the BN(+ReLU) output at (row, channels n..n+3)
             const int nl = wn * 64 + ni * 16 + g * 4;
-            float xf[4], mk[4];
-            if (sizeof(T) == 4) {
+            float xf[4] = {0.f, 0.f, 0.f, 0.f}, mk[4];
+            if (p.bn_mode == 4) {
+            } else if (sizeof(T) == 4) {
               const float4 xv = *(const float4*)((const float*)p.bn_x + off + n);
               xf[0] = xv.x; xf[1] = xv.y; xf[2] = xv.z; xf[3] = xv.w;
             } else {
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
               xf[0] = __uint_as_float(xv[0] << 16); xf[1] = __uint_as_float(xv[0] & 0xffff0000u);
               xf[2] = __uint_as_float(xv[1] << 16); xf[3] = __uint_as_float(xv[1] & 0xffff0000u);
             }
-            if (p.bn_mode == 3) {
+            if (p.bn_mode >= 3) {
               const unsigned mb = ((const unsigned char*)p.bn_mask)[(off + n) / EPC] >> (n % EPC);
 #pragma unroll
               for (int r = 0; r < 4; ++r) mk[r] = ((mb >> r) & 1u) ? 1.f : 0.f;
@@ -2054,9 +2061,9 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   SIMCLR_CHECK_ARG(Cin % 4 == 0, "conv2d_dgrad_bn: Cin=%d must be a multiple of 4", Cin);
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad_bn: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9 && stride == 1, "conv2d_dgrad_bn: stride-1 convolutions with <= 9 taps only");
-  SIMCLR_CHECK_ARG(mask_mode >= 1 && mask_mode <= 3, "conv2d_dgrad_bn: mask_mode must be 1, 2 or 3");
-  SIMCLR_CHECK_ARG(bn_x && bn_mean && bn_rstd && stats && nslot > 0, "conv2d_dgrad_bn: null BN argument");
-  SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 / 3 need bn_mask");
+  SIMCLR_CHECK_ARG(mask_mode >= 1 && mask_mode <= 4, "conv2d_dgrad_bn: mask_mode must be 1, 2, 3 or 4");
+  SIMCLR_CHECK_ARG(stats && nslot > 0 && (mask_mode == 4 || (bn_x && bn_mean && bn_rstd)), "conv2d_dgrad_bn: null BN argument");
+  SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 / 3 / 4 need bn_mask");
   SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn: mask_mode 2 needs scale/shift");
   ConvP p = {};
   p.zero = zero_page();
@@ -2088,9 +2095,9 @@ int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext,
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_bn_ext: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0 && Cin % (8 * epc) == 0, "conv2d_dgrad_bn_ext: Cin=%d / Cout=%d must be multiples of %d", Cin, Cout, 8 * epc);
   SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "conv2d_dgrad_bn_ext: M overflows int32");
-  SIMCLR_CHECK_ARG(mask_mode >= 1 && mask_mode <= 3, "conv2d_dgrad_bn_ext: mask_mode must be 1, 2 or 3");
-  SIMCLR_CHECK_ARG(dm && h && w_ext && bn_x && bn_mean && bn_rstd && stats && nslot > 0, "conv2d_dgrad_bn_ext: null argument");
-  SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn_ext: mask_mode 1 / 3 need bn_mask");
+  SIMCLR_CHECK_ARG(mask_mode >= 1 && mask_mode <= 4, "conv2d_dgrad_bn_ext: mask_mode must be 1, 2, 3 or 4");
+  SIMCLR_CHECK_ARG(dm && h && w_ext && stats && nslot > 0 && (mask_mode == 4 || (bn_x && bn_mean && bn_rstd)), "conv2d_dgrad_bn_ext: null argument");
+  SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn_ext: mask_mode 1 / 3 / 4 need bn_mask");
   SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn_ext: mask_mode 2 needs scale/shift");
   ConvP p = {};
   p.zero = zero_page();

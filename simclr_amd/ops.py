@@ -191,9 +191,9 @@ def conv2d_dgrad_bn(dy, w_d, KH, KW, pad, IH, IW, bn, out=None, accumulate=False
     K = KH * KW * Cout
     esz = dy.element_size()
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + V * IH * IW * Cin + K * Cin),
-            impl_bytes=esz * (V * OH * OW * Cout + (2 + (bn['mode'] == 1) + int(accumulate)) * V * IH * IW * Cin + K * Cin),
-            fn=lambda: lib().conv2d_dgrad_bn(_p(dy), _p(w_d), _p(out), int(accumulate), _p(bn['x']), _p(bn.get('mask')),
-                                          _p(bn.get('scale')), _p(bn.get('shift')), _p(bn['mean']), _p(bn['rstd']),
+            impl_bytes=esz * (V * OH * OW * Cout + (1 + (bn['mode'] != 4) + (bn['mode'] == 1) + int(accumulate)) * V * IH * IW * Cin + K * Cin),
+            fn=lambda: lib().conv2d_dgrad_bn(_p(dy), _p(w_d), _p(out), int(accumulate), _p(bn.get('x')), _p(bn.get('mask')),
+                                          _p(bn.get('scale')), _p(bn.get('shift')), _p(bn.get('mean')), _p(bn.get('rstd')),
                                           bn['mode'], _p(partial), partial.shape[0], V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
                                           pad, dt(dy), _s()))
     return out, partial
@@ -657,3 +657,12 @@ def bn_bwd_apply_pool(dy, arg, x, scale, shift, mean, rstd, c1, c2, ksz=3, strid
     lib().bn_bwd_apply_pool(_p(dy), _p(arg), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(c1), _p(c2), _p(dx), V, H,
                             W, C, OH, OW, ksz, stride, pt, pl, dt(x), _s())
     return dx
+
+
+def bn_fold_s2(t1, w_d, mean, rstd, sums):
+    """sums [2, N] fp64 with sums[0] = sum(dm): fills sums[1] = sum(dm * x^) of the BatchNorm behind c = h W from
+    t1 = h^T dm [K, N] and the weight copy w_d [K, N] -- no pass over c."""
+    K, N = t1.shape
+    assert sums.dtype == torch.float64 and tuple(sums.shape) == (2, N) and tuple(w_d.shape) == (K, N)
+    lib().bn_fold_s2(_p(t1), _p(w_d), _p(mean), _p(rstd), _p(sums), K, N, dt(w_d), _s())
+    return sums

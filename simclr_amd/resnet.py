@@ -250,13 +250,17 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         self.saved['masked'] = bool(relu)
         return Act(y, c=inputs.c)
 
-    def fusion_info(self, mask_src=None):
+    def fusion_info(self, mask_src=None, sums_only=False):
         """What a consumer conv's dgrad epilogue needs to fuse this layer's backward reduce
         (simclr_conv2d_dgrad_bn): plain BN+ReLU -> mask recomputed from x (mode 2); residual tail
         -> mask from the block output (mode 1)."""
         s = self.saved
         if mask_src is not None:
             if getattr(self, 'relu_bits', None) is not None:    # 1 bit per element instead of the whole tensor
+                if sums_only:
+                    # the consumer produces sum(dm) only; sum(dm*x^) follows from the weight-gradient GEMM of the conv that
+                    # feeds this BN (Conv2dFixedPadding.backward_folded) -- this BN's input is not read at all
+                    return dict(mask=self.relu_bits, mode=4)
                 return dict(x=s['x'], mask=self.relu_bits, mean=s['mean'], rstd=s['rstd'], mode=3)
             return dict(x=s['x'], mask=mask_src, mean=s['mean'], rstd=s['rstd'], mode=1)
         assert s.get('masked'), 'fusion_info without mask_src needs a BN+ReLU layer'
@@ -284,6 +288,14 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         if local is not None:
             return ops.bn_bwd_finalize(local, glob, count, dgamma, dbeta)
         return ops.bn_bwd_finalize(None, None, count, dgamma, dbeta, partial=partial)
+
+    def finalize_from_sums(self, local):
+        """local: [2, C] fp64 (sum dm, sum dm*x^) of THIS replica -> (c1, c2); dgamma / dbeta from the local sums, the
+        coefficients from the cross-replica sums (SyncBN collective C)."""
+        dgamma = self.gamma.ensure_grad() if self.gamma is not None and self.gamma.trainable else None
+        dbeta = self.beta.ensure_grad() if self.beta is not None and self.beta.trainable else None
+        glob = RT.strategy.all_reduce_sum(local.clone()) if _sync_bn() else local
+        return ops.bn_bwd_finalize(local, glob, self.saved['count'], dgamma, dbeta)
 
     def bwd_reduce(self, dy, mask_src=None, mask_mode=0):
         """First half of the un-fused backward: per-channel (sum dy_m, sum dy_m * x^) partial slots."""
@@ -424,7 +436,7 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             self._v32 = self._version
         return self.w_d32, self.w_t32
 
-    def backward_folded(self, dm, bn_out, coeffs, fuse_bn):
+    def backward_folded(self, dm, bn_out, partial, fuse_bn, s2_from_gemm=False):
         """1x1 stride-1 conv whose output c = h W goes through `bn_out` (BatchNorm, no ReLU before the add): the BN backward
         dh = a*dm + b*c + d is folded into this layer's gradients by linearity (csrc/bn.hip bn_fold_*), so neither the
         streaming BN-backward pass nor dh exists.  dm: masked gradient wrt bn_out's output; coeffs = (c1, c2) of bn_out.
@@ -436,12 +448,19 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         V, H, W, K = h.shape
         N = self.cout_p
         st = bn_out.saved
+        t1 = ops.conv2d_wgrad(h, dm, 1, 1, 1, 0)                                                # h^T dm      [K, N]
+        if s2_from_gemm:
+            # `partial` carries sum(dm) only (dgrad epilogue mode 4): sum(dm*x^) = rstd * (<W, T1>_k - mean * sum(dm))
+            local = ops.bn_reduce_slots(partial)
+            ops.bn_fold_s2(t1, self.w_d, st['mean'], st['rstd'], local)
+            coeffs = bn_out.finalize_from_sums(local)
+        else:
+            coeffs = bn_out._bwd_finalize(partial, st['count'])
         a, b, d, wb, wext, e = ops.bn_fold_pre(self.w_d, st['scale'], st['mean'], st['rstd'], coeffs[0], coeffs[1])
         w_d32, w_t32 = self._f32_copies()
         q = ops.small_gemm_nt(wb, w_d32)                                                        # (W*b) W^T   [K, K]
         if self.kernel.trainable:
             with _wgrad_side_stream(h, dm):
-                t1 = ops.conv2d_wgrad(h, dm, 1, 1, 1, 0)                                        # h^T dm      [K, N]
                 if ops.gram_supported(K, h.dtype):
                     g, cs = ops.conv2d_gram(h)                                                  # h^T h, colsum(h): ONE pass over h
                 else:
@@ -451,8 +470,7 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
                 ops.bn_fold_post(t1, gw, cs, a, b, d, q, self.kernel.ensure_grad().view(K, N), wext)
         else:
             z = torch.zeros(K, N, device=h.device)
-            ops.bn_fold_post(z, z, torch.zeros(2, K, device=h.device, dtype=torch.float64), a, b, d, q,
-                             torch.empty(K, N, device=h.device), wext)
+            ops.bn_fold_post(z, z, torch.zeros(K, device=h.device), a, b, d, q, torch.empty(K, N, device=h.device), wext)
         join_wgrad_stream()                       # wext's last K columns come from bn_fold_post
         return ops.conv2d_dgrad_bn_ext(dm, h, wext, e, fuse_bn)
 
@@ -494,6 +512,11 @@ def _pool_fusion_enabled():
     interleaved runs on one MI355X, profiles/r02_notes.md) -- the 4-window gather is recomputed in both passes."""
     import os
     return os.environ.get('SIMCLR_POOL_FUSION', '0') not in ('', '0')
+
+
+def _bn_s2_enabled():
+    import os
+    return os.environ.get('SIMCLR_BN_S2_GEMM', '1') not in ('', '0')
 
 
 def _bn_fold_enabled():
@@ -657,17 +680,6 @@ def _block_entry(block, inputs, training):
     return raw_sc.t, sc_bn, block.bn1(raw1, training)
 
 
-def _block_tail_coeffs(block, bn_tail, dout, dout_partial):
-    """Like _block_tail_backward for the folded form: statistics exchange + finalize of the tail BN (and of the projection
-    shortcut's BN, which still runs its own backward), but NO apply pass for the tail.  Returns ((c1, c2), dx_shortcut_path)."""
-    dsum = dout
-    if block.shortcut is not None:
-        sc_part = block.shortcut.bn.bwd_reduce(dsum, mask_mode=0)
-        co_t, co_s = bwd_finalize_many([(bn_tail, dout_partial), (block.shortcut.bn, sc_part)])
-        return co_t, block.shortcut.backward(dsum, coeffs=co_s)
-    return bwd_finalize_many([(bn_tail, dout_partial)])[0], dsum
-
-
 def _block_tail_backward(block, bn_tail, dout, dout_partial):
     """Backward of relu(bn_tail(h) + shortcut): returns (dh, dx_shortcut_path).  When the tail's reduce arrived fused
     (dout_partial) and the block has a projection shortcut, the two BatchNorm backward reductions -- same upstream
@@ -755,17 +767,23 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         self.out = out.t
         return out
 
+    def _foldable(self):
+        return self.sk is None and not self.conv3.padded and _bn_fold_enabled()
+
     def tail_info(self):
-        return self.bn3.fusion_info(mask_src=self.out)
+        # foldable tail: the consumer's dgrad epilogue only masks and sums dm (no read of this block's conv3 output)
+        return self.bn3.fusion_info(mask_src=self.out, sums_only=self._foldable() and _bn_s2_enabled())
 
     def backward(self, dout, dout_partial=None, prev_tail=None):
         """See ResidualBlock.backward.  Returns (dx, partial-or-None)."""
-        fold = (dout_partial is not None and self.sk is None and not self.conv3.padded and _bn_fold_enabled())
+        fold = dout_partial is not None and self._foldable()
         if fold:
-            # tail BN3 backward folded into conv3's wgrad / dgrad (no bn_bwd_apply pass, no dh3 tensor)
-            co3, dx = _block_tail_coeffs(self, self.bn3, dout, dout_partial)
+            # tail BN3 backward folded into conv3's wgrad / dgrad (no bn_bwd_apply pass, no dh3 tensor); with
+            # _bn_s2_enabled() the producer of `dout` did not even read conv3's output for the BN3 reduce
+            dx = self.shortcut.backward(dout) if self.shortcut is not None else dout
             self.out = None
-            dm2, part2 = self.conv3.backward_folded(dout, self.bn3, co3, fuse_bn=self.bn2.fusion_info())
+            dm2, part2 = self.conv3.backward_folded(dout, self.bn3, dout_partial, fuse_bn=self.bn2.fusion_info(),
+                                                    s2_from_gemm=_bn_s2_enabled())
             self.bn3.saved = None
             dh2 = self.bn2.backward_fused(dm2, part2)
             if self.conv2.strides == 1:

@@ -257,7 +257,7 @@ def check_dgrad_bn(V, H, Cin, Cout, k, dtype, mask_mode, accumulate, seed=0):
     da = xr.grad.permute(0, 2, 3, 1)
     if accumulate:
         da = da + prev.double()
-    if mask_mode in (1, 3):
+    if mask_mode in (1, 3, 4):
         m = mask_t.double() > 0
     else:
         m = (x_raw.float() * scale + shift).double() > 0          # fp32 fma like the kernel
@@ -269,12 +269,14 @@ def check_dgrad_bn(V, H, Cin, Cout, k, dtype, mask_mode, accumulate, seed=0):
     mask_arg = None
     if mask_mode == 1:
         mask_arg = mask_t.to(DEV)
-    elif mask_mode == 3:      # one byte per 16-byte chunk, bit e = element e (the layout simclr_bn_apply writes)
+    elif mask_mode in (3, 4):      # one byte per 16-byte chunk, bit e = element e (the layout simclr_bn_apply writes)
         epc = 8 if dtype == torch.bfloat16 else 4
         mb = (mask_t > 0).reshape(-1, Cin // epc, epc).to(torch.int32)
         mask_arg = (mb << torch.arange(epc, dtype=torch.int32)).sum(-1).to(torch.uint8).to(DEV)
     bn = dict(x=x_raw.to(DEV), mask=mask_arg, scale=scale.to(DEV),
               shift=shift.to(DEV), mean=mean.to(DEV), rstd=rstd.to(DEV), mode=mask_mode)
+    if mask_mode == 4:        # sums-only epilogue: no BN input, no mean / rstd
+        bn = dict(mask=mask_arg, mode=4)
     out = prev.to(DEV).clone() if accumulate else None
     dm, part = ops.conv2d_dgrad_bn(dy.to(DEV), w_d, k, k, pad, H, H, bn, out=out, accumulate=accumulate)
     sums = ops.bn_reduce_slots(part)
@@ -288,9 +290,11 @@ def check_dgrad_bn(V, H, Cin, Cout, k, dtype, mask_mode, accumulate, seed=0):
         got = torch.where(clear, dm.double().cpu(), dm_ref)
     else:
         got = dm
-    return [_res('dgrad_bn_dm ' + tag, got, dm_ref, t * (2 if accumulate else 1)),
-            _res('dgrad_bn_sum ' + tag, sums[0], s1, 2e-3 if dtype == torch.bfloat16 else 1e-4, 1e-3 * float(dm_ref.abs().sum((0, 1, 2)).max())),
-            _res('dgrad_bn_sumxhat ' + tag, sums[1], s2, 2e-3 if dtype == torch.bfloat16 else 1e-4, 1e-3 * float((dm_ref * xh).abs().sum((0, 1, 2)).max()))]
+    res = [_res('dgrad_bn_dm ' + tag, got, dm_ref, t * (2 if accumulate else 1)),
+           _res('dgrad_bn_sum ' + tag, sums[0], s1, 2e-3 if dtype == torch.bfloat16 else 1e-4, 1e-3 * float(dm_ref.abs().sum((0, 1, 2)).max()))]
+    if mask_mode != 4:
+        res.append(_res('dgrad_bn_sumxhat ' + tag, sums[1], s2, 2e-3 if dtype == torch.bfloat16 else 1e-4, 1e-3 * float((dm_ref * xh).abs().sum((0, 1, 2)).max())))
+    return res
 
 
 def check_stem(V, H, k, stride, Cout, dtype, seed=0):
@@ -1214,11 +1218,18 @@ def check_bn_fold(V, H, K, N, dtype, seed=0, mask_mode=2):
     tag = 'V%d %dx%d %d->%d %s' % (V, H, H, K, N, str(dtype).split('.')[-1])
     bf = dtype == torch.bfloat16
     l1 = float((dmi_ref.abs().sum(0) + (dmi_ref * xh).abs().sum(0)).max())
+    # sum(dm * x^) of the folded BN from T1 (no pass over c): x^ = (c - bmean) * brstd with c = h w
+    sums_s2 = torch.zeros(2, N, device=DEV, dtype=torch.float64)
+    sums_s2[0] = dm.double().view(M, N).sum(0)
+    ops.bn_fold_s2(t1, w, bmean, brstd, sums_s2)
+    torch.cuda.synchronize()
+    s2_ref = (dm64 * ((c - bmean.double()) * brstd.double())).sum(0)
     gram_ref = h64.t() @ h64
     return [_res('bn_fold_colsum ' + tag, cs2[0], h64.sum(0), 1e-6),
             _res('bn_fold_colsum_gramkernel ' + tag, cs[0] if cs.dim() == 2 else cs, h64.sum(0), 2e-6),
             _res('bn_fold_gram ' + tag, gm, gram_ref, 2e-5), _res('bn_fold_gram_generic ' + tag, gm2, gram_ref, 2e-5),
             _res('bn_fold_q ' + tag, q, (w.double() * b.double()) @ w.double().t(), 2e-5),
+            _res('bn_fold_s2_from_gemm ' + tag, sums_s2[1], s2_ref, 0, 2e-5 * float((dm64 * c).abs().sum(0).max())),
             _res('bn_fold_dw ' + tag, dw, dw_ref, 2e-3 if bf else 2e-4),
             _res('bn_fold_dgrad_dm ' + tag, dmi.double().view(M, K), dmi_ref, 1.5e-2 if bf else 2e-4),
             _res('bn_fold_dgrad_sum ' + tag, sums[0], dmi_ref.sum(0), 0, (2e-3 if bf else 1e-4) * l1),

@@ -153,7 +153,8 @@ def test_conv_wgrad_multitap_3x3(V, H, Cin, Cout):
 @pytest.mark.parametrize('dtype', [F32, BF])
 @pytest.mark.parametrize('V,H,Cin,Cout,k,mode,acc', [(3, 9, 128, 64, 1, 2, 0), (2, 14, 64, 128, 3, 2, 0),
                                                      (3, 8, 256, 64, 1, 1, 1), (2, 7, 64, 64, 3, 1, 0),
-                                                     (3, 8, 256, 64, 1, 3, 1), (2, 9, 64, 128, 3, 3, 0)])
+                                                     (3, 8, 256, 64, 1, 3, 1), (2, 9, 64, 128, 3, 3, 0),
+                                                     (3, 8, 256, 64, 1, 4, 1), (40, 14, 128, 64, 1, 4, 1)])
 def test_dgrad_with_fused_bn_backward_reduce(V, H, Cin, Cout, k, mode, acc, dtype):
     from tests import gpu_checks as gc
     _assert(gc.check_dgrad_bn(V, H, Cin, Cout, k, dtype, mode, acc))
