@@ -223,6 +223,8 @@ int simclr_bn_fold_pre(const void* w, const float* scale, const float* mean, con
 int simclr_bn_fold_post(const float* t1, const float* gw, const double* cs, const float* cs32, const float* a, const float* b,
                         const float* d, const float* q, float* dw, void* wext, int K, int N, int accumulate, int dtype,
                         simclr_stream_t stream);
+int simclr_conv2d_dgrad_ext(const void* dm, const void* h, const void* w_ext, const float* bias, void* dx, int accumulate,
+                            int V, int H, int W, int Cin, int Cout, int dtype, simclr_stream_t stream);  /* plain epilogue */
 /* sum(dm * x^) of the folded BatchNorm from t1 = h^T dm (no pass over the conv output): sums [2][N] fp64, sums[0] = sum dm given */
 int simclr_bn_fold_s2(const float* t1, const void* w, const float* mean, const float* rstd, double* sums, int K, int N,
                       int dtype, simclr_stream_t stream);

@@ -535,14 +535,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
     }
   };
 
-  if (BNEPI) {
+  if (BNEPI || EXT) {
     for (int i = tid; i < BN; i += NW * 64) {
       const int n = n0 + i;
       const bool ok = n < p.N;
-      bnp[i] = (ok && p.bn_mode == 2) ? p.bn_scale[n] : 0.f;
-      bnp[BN + i] = (ok && p.bn_mode == 2) ? p.bn_shift[n] : 0.f;
-      bnp[2 * BN + i] = (ok && p.bn_mean) ? p.bn_mean[n] : 0.f;
-      bnp[3 * BN + i] = (ok && p.bn_rstd) ? p.bn_rstd[n] : 0.f;
+      if (BNEPI) {
+        bnp[i] = (ok && p.bn_mode == 2) ? p.bn_scale[n] : 0.f;
+        bnp[BN + i] = (ok && p.bn_mode == 2) ? p.bn_shift[n] : 0.f;
+        bnp[2 * BN + i] = (ok && p.bn_mean) ? p.bn_mean[n] : 0.f;
+        bnp[3 * BN + i] = (ok && p.bn_rstd) ? p.bn_rstd[n] : 0.f;
+      }
       if (EXT) bnp[4 * BN + i] = (ok && p.bias) ? p.bias[n] : 0.f;
     }
     // visibility: the first barrier of the k-loop (or the explicit one before the flush) orders these writes
@@ -1910,7 +1912,10 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     const size_t plds = 2 * (128 + BN) * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long);
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
-    if (p.bn_mode && p.x2) {   // K-extended dgrad (folded BatchNorm backward of the consumer's output) + fused BN reduce
+    if (!p.bn_mode && p.x2) {  // K-extended dgrad, plain epilogue (the conv input is not a BatchNorm output: block entry)
+      if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 64, 4, 2, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
+      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
+    } else if (p.bn_mode && p.x2) {   // K-extended dgrad (folded BatchNorm backward of the consumer's output) + fused BN reduce
       if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 64, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
       else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
     } else if (p.bn_mode) {    // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
@@ -2109,6 +2114,29 @@ int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext,
   p.x2 = h; p.ic2 = Cin; p.pixpitch2 = Cin; p.bias = bias;
   p.bn_x = bn_x; p.bn_mask = bn_mask; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
   p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.bn_mode = mask_mode;
+  if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
+  else launch_igemm<float, MODE_DGRAD>(p, stream);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// The same K-extended 1x1 data gradient with a plain epilogue (dx [+]= dm (a*W)^T + h (W diag(b) W^T) + W d): for a folded
+// BatchNorm whose conv input is not itself a BatchNorm output (the projection shortcut at a block entry).
+int simclr_conv2d_dgrad_ext(const void* dm, const void* h, const void* w_ext, const float* bias, void* dx, int accumulate,
+                            int V, int H, int W, int Cin, int Cout, int dtype, hipStream_t stream) {
+  const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_ext: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0 && Cin % (8 * epc) == 0, "conv2d_dgrad_ext: Cin=%d / Cout=%d must be multiples of %d", Cin, Cout, 8 * epc);
+  SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "conv2d_dgrad_ext: M overflows int32");
+  SIMCLR_CHECK_ARG(dm && h && w_ext && dx, "conv2d_dgrad_ext: null argument");
+  ConvP p = {};
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
+  p.x = dm; p.w = w_ext; p.y = dx; p.stats = nullptr; p.nslot = 1; p.accumulate = accumulate;
+  p.V = V; p.IH = H; p.IW = W; p.IC = Cout; p.OH = H; p.OW = W; p.N = Cin;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pixpitch = Cout;
+  p.M = V * H * W; p.K = Cout + Cin;
+  p.x2 = h; p.ic2 = Cin; p.pixpitch2 = Cin; p.bias = bias;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
   else launch_igemm<float, MODE_DGRAD>(p, stream);
   SIMCLR_CHECK_LAUNCH();

@@ -666,3 +666,19 @@ def bn_fold_s2(t1, w_d, mean, rstd, sums):
     assert sums.dtype == torch.float64 and tuple(sums.shape) == (2, N) and tuple(w_d.shape) == (K, N)
     lib().bn_fold_s2(_p(t1), _p(w_d), _p(mean), _p(rstd), _p(sums), K, N, dt(w_d), _s())
     return sums
+
+
+def conv2d_dgrad_ext(dm, h, wext, bias, out=None, accumulate=False):
+    """K-extended 1x1 dgrad with a plain epilogue (see conv2d_dgrad_bn_ext): dx [+]= dm (a*W)^T + h Q + W d."""
+    V, H, W, N = dm.shape
+    K = h.shape[3]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(V, H, W, K, device=dm.device, dtype=dm.dtype)
+    esz = dm.element_size()
+    M = V * H * W
+    _launch('conv_igemm_dgrad', 2.0 * M * N * K, esz * (M * N + M * K + N * K),
+            impl_bytes=esz * (M * N + (2 + int(accumulate)) * M * K + (N + K) * K),
+            fn=lambda: lib().conv2d_dgrad_ext(_p(dm), _p(h), _p(wext), _p(bias), _p(out), int(accumulate), V, H, W, K, N,
+                                              dt(dm), _s()))
+    return out

@@ -436,7 +436,7 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             self._v32 = self._version
         return self.w_d32, self.w_t32
 
-    def backward_folded(self, dm, bn_out, partial, fuse_bn, s2_from_gemm=False):
+    def backward_folded(self, dm, bn_out, partial, fuse_bn, s2_from_gemm=False, dx_out=None, accumulate=False):
         """1x1 stride-1 conv whose output c = h W goes through `bn_out` (BatchNorm, no ReLU before the add): the BN backward
         dh = a*dm + b*c + d is folded into this layer's gradients by linearity (csrc/bn.hip bn_fold_*), so neither the
         streaming BN-backward pass nor dh exists.  dm: masked gradient wrt bn_out's output; coeffs = (c1, c2) of bn_out.
@@ -472,6 +472,8 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             z = torch.zeros(K, N, device=h.device)
             ops.bn_fold_post(z, z, torch.zeros(K, device=h.device), a, b, d, q, torch.empty(K, N, device=h.device), wext)
         join_wgrad_stream()                       # wext's last K columns come from bn_fold_post
+        if fuse_bn is None:                       # conv input is not a BatchNorm output (projection shortcut at a block entry)
+            return ops.conv2d_dgrad_ext(dm, h, wext, e, out=dx_out, accumulate=accumulate), None
         return ops.conv2d_dgrad_bn_ext(dm, h, wext, e, fuse_bn)
 
     def backward(self, dy, need_dx=True, dx_out=None, accumulate=False, fuse_bn=None):
@@ -660,6 +662,20 @@ class _Shortcut(Layer):
         scale, shift = self.bn.prepare(raw, training)
         return raw.t, (scale, shift)
 
+    def foldable(self):
+        """Stride-1 1x1 projection (no avg-pool) with a supported channel count: its BN backward folds into the conv."""
+        import os
+        c = self.conv
+        return (os.environ.get('SIMCLR_SC_FOLD', '1') not in ('', '0') and
+                not self.resnet_d and c.strides == 1 and c.kernel is not None and not c.padded and
+                ops.gram_supported(c.cin_p, RT.dtype) and _bn_fold_enabled() and _bn_s2_enabled())
+
+    def backward_folded(self, d_sum, partial):
+        """partial: slots whose sum(dm) part is valid for d_sum (the tail BN's, same upstream gradient)."""
+        d, _ = self.conv.backward_folded(d_sum, self.bn, partial, None, s2_from_gemm=True)
+        self.bn.saved = None
+        return d
+
     def backward(self, d_sum, coeffs=None):
         d_raw, _ = self.bn.backward(d_sum, mask_mode=0, coeffs=coeffs)
         d = self.conv.backward(d_raw)
@@ -780,7 +796,12 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         if fold:
             # tail BN3 backward folded into conv3's wgrad / dgrad (no bn_bwd_apply pass, no dh3 tensor); with
             # _bn_s2_enabled() the producer of `dout` did not even read conv3's output for the BN3 reduce
-            dx = self.shortcut.backward(dout) if self.shortcut is not None else dout
+            if self.shortcut is None:
+                dx = dout
+            elif self.shortcut.foldable():
+                dx = self.shortcut.backward_folded(dout, dout_partial)
+            else:
+                dx = self.shortcut.backward(dout)
             self.out = None
             dm2, part2 = self.conv3.backward_folded(dout, self.bn3, dout_partial, fuse_bn=self.bn2.fusion_info(),
                                                     s2_from_gemm=_bn_s2_enabled())
