@@ -1,8 +1,8 @@
 #!/bin/bash
 # One gpurun call that produces everything a round needs (run ON the GPU box, from the repo root):
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_checks.sh rNN [full|quick]'
-# quick: conv/BN parity subset + bench (about 1.5 min);  full: whole GPU suite, smoke, bench with CPU baseline,
-# microbench, rocprofv3 kernel stats and the two PMC passes (about 7-8 min).  Everything lands in gpurun_out/<tag>/;
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_round_checks.sh rNN [full|quick]'
+# quick: conv/BN parity subset + bench (about 1.5 min);  full: whole GPU suite, smoke, bench with CPU baseline and fp32 mode,
+# microbench, rocprofv3 kernel stats and the two PMC passes (about 12 min).  Everything lands in gpurun_out/<tag>/;
 # copy what should be judged into profiles/ afterwards (tools/pmc_traffic.py, tools/per_layer_roofline.py).
 set -u
 TAG=${1:-r00}
@@ -12,20 +12,20 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$R"
 if [ "$MODE" = "quick" ]; then
-  timeout 200 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "test_conv or dgrad or batch_norm or pooling" 2>&1 | tail -3
-  timeout 120 python bench.py --steps 6 --warmup 2 --no_cpu_baseline > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
+  timeout 200 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "test_conv_fwd or dgrad or batch_norm or pooling" 2>&1 | tail -3
+  timeout 120 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_f32 > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
   python -c "import json,sys;d=json.load(open('$OUT/bench_quick.json'));print(d['value'],d['ms_per_step']);[print(k,v) for k,v in d['kernels'].items()]"
   exit 0
 fi
-timeout 700 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -1
-timeout 300 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-240 "$OUT/bench.json" | tail -1
-timeout 200 python tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.txt" 2>&1
+timeout 1200 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -4 "$OUT/pytest_gpu.log"
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
+timeout 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-300 "$OUT/bench.json" | tail -1
+timeout 300 python tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.txt" 2>&1
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --no_cpu_baseline --no_kernel_events"
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- $B --steps 3 --warmup 1 > "$OUT/prof.log" 2>&1
+B="python $R/bench.py --no_cpu_baseline --no_kernel_events --no_f32"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- $B --steps 3 --warmup 1 > "$OUT/prof.log" 2>&1
 rm -f "$OUT"/*kernel_trace.csv
-timeout 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --steps 1 --warmup 1 > "$OUT/pmc_f.log" 2>&1
-timeout 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --steps 1 --warmup 1 > "$OUT/pmc_w.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --steps 1 --warmup 1 > "$OUT/pmc_f.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --steps 1 --warmup 1 > "$OUT/pmc_w.log" 2>&1
 gzip -f "$OUT"/pmc_f/*counter_collection.csv "$OUT"/pmc_w/*counter_collection.csv 2>/dev/null
 ls "$OUT"
