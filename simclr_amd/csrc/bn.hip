@@ -348,13 +348,25 @@ __global__ void bn_fold_coeffs(const float* __restrict__ scale, const float* __r
 // T1 = h^T dm (the weight-gradient GEMM that is computed anyway), so
 //   sums[1][j] = rstd[j] * (sum_k W[k][j] * T1[k][j] - mean[j] * sums[0][j]),      sums[0] = sum dm (already there).
 template <typename T>
-__global__ void bn_fold_s2(const float* __restrict__ t1, const T* __restrict__ w, const float* __restrict__ mean,
-                           const float* __restrict__ rstd, double* __restrict__ sums, int K, int N) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
+__global__ __launch_bounds__(256) void bn_fold_s2(const float* __restrict__ t1, const T* __restrict__ w, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, double* __restrict__ sums, int K, int N) {
+  // 32 channels x 8 k-lanes per workgroup; lane kl adds rows kl, kl+8, ... (ascending), the lanes are joined in order
+  __shared__ double sh[256];
+  const int jl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl;
   double acc = 0.0;
-  for (int k = 0; k < K; ++k) acc += (double)Elem<T>::ld(w + (long long)k * N + j) * (double)t1[(long long)k * N + j];
-  sums[N + j] = (double)rstd[j] * (acc - (double)mean[j] * sums[j]);
+  if (j < N) {
+#pragma unroll 4
+    for (int k = kl; k < K; k += 8) acc += (double)Elem<T>::ld(w + (long long)k * N + j) * (double)t1[(long long)k * N + j];
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (kl == 0 && j < N) {
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += sh[q * 32 + jl];
+    sums[N + j] = (double)rstd[j] * (a - (double)mean[j] * sums[j]);
+  }
 }
 
 // one workgroup per input channel i (row of W [K][N]):  wb[i][j] = W[i][j]*b[j] (fp32),  wext[i][j] = T(W[i][j]*a[j]) for
@@ -602,9 +614,9 @@ int simclr_bn_fold_s2(const float* t1, const void* w, const float* mean, const f
                       int dtype, hipStream_t stream) {
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "bn_fold_s2: bad dtype %d", dtype);
   if (dtype == SIMCLR_DT_BF16)
-    hipLaunchKernelGGL((bn_fold_s2<uint16_t>), dim3(ceil_div(N, 128)), dim3(128), 0, stream, t1, (const uint16_t*)w, mean, rstd, sums, K, N);
+    hipLaunchKernelGGL((bn_fold_s2<uint16_t>), dim3(ceil_div(N, 32)), dim3(256), 0, stream, t1, (const uint16_t*)w, mean, rstd, sums, K, N);
   else
-    hipLaunchKernelGGL((bn_fold_s2<float>), dim3(ceil_div(N, 128)), dim3(128), 0, stream, t1, (const float*)w, mean, rstd, sums, K, N);
+    hipLaunchKernelGGL((bn_fold_s2<float>), dim3(ceil_div(N, 32)), dim3(256), 0, stream, t1, (const float*)w, mean, rstd, sums, K, N);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

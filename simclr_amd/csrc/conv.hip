@@ -1613,7 +1613,8 @@ __global__ __launch_bounds__(256) void small_gemm_nt_f32(const float* __restrict
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float* ap = A + (long long)(m0 + fl) * K + 4 * q;
-  for (int k = 0; k < K; k += 16) {
+#pragma unroll 4
+  for (int k = 0; k < K; k += 16) {       // unrolled: the loads of four k-steps are in flight together
     const float4 av = *(const float4*)(ap + k);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -575,13 +575,25 @@ __global__ void bias_softmax_xent(const T* __restrict__ z, const float* __restri
 
 // out[c] (+)= sum over rows of x[row][c]   (bias gradient)
 template <typename T>
-__global__ void colsum(const T* __restrict__ x, int rows, int C, int cvalid, float* __restrict__ out,
-                       int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cvalid) return;
+__global__ __launch_bounds__(256) void colsum(const T* __restrict__ x, int rows, int C, int cvalid, float* __restrict__ out,
+                                              int accumulate) {
+  // 16 columns x 16 row-lanes per workgroup: lane rl adds rows rl, rl+16, ... (ascending); fixed-order join -> deterministic
+  __shared__ float sh[256];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float a = 0.f;
-  for (int r = 0; r < rows; ++r) a += Elem<T>::ld(x + (long long)r * C + c);
-  out[c] = accumulate ? out[c] + a : a;
+  if (c < cvalid) {
+#pragma unroll 4
+    for (int r = rl; r < rows; r += 16) a += Elem<T>::ld(x + (long long)r * C + c);
+  }
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (rl == 0 && c < cvalid) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q * 16 + cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 template <typename TI, typename TO>
@@ -883,9 +895,9 @@ int simclr_bias_softmax_xent(const void* z, const float* bias, const int* labels
 int simclr_colsum(const void* x, int rows, int C, int cvalid, float* out, int accumulate, int dtype,
                   hipStream_t stream) {
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((colsum<uint16_t>), dim3(ceil_div(cvalid, 256)), dim3(256), 0, stream,
+             hipLaunchKernelGGL((colsum<uint16_t>), dim3(ceil_div(cvalid, 16)), dim3(256), 0, stream,
                                 (const uint16_t*)x, rows, C, cvalid, out, accumulate),
-             hipLaunchKernelGGL((colsum<float>), dim3(ceil_div(cvalid, 256)), dim3(256), 0, stream,
+             hipLaunchKernelGGL((colsum<float>), dim3(ceil_div(cvalid, 16)), dim3(256), 0, stream,
                                 (const float*)x, rows, C, cvalid, out, accumulate));
   SIMCLR_CHECK_LAUNCH();
   return 0;
