@@ -373,6 +373,35 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
 
+    augment = None
+    if world == 1:
+        # the two-view augmentation on the device (tf2/data_util.py:443-475 x 2 views), NOT part of the timed
+        # step (inputs are resident); reported so that the input pipeline's rate can be compared with the step's
+        try:
+            from simclr_amd import data_util as du
+            b_aug, src = args.per_gpu_batch, 256
+            raw = torch.randint(0, 256, (b_aug, src, src, 3), dtype=torch.uint8, device=dev)
+            prm = torch.from_numpy(du.draw_train_params(b_aug, src, src, args.image_size, args.image_size, 1.0)).to(dev)
+            for _ in range(2):
+                du.two_view_batch(raw, args.image_size, args.image_size, 1.0, params=prm)
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(5):
+                du.two_view_batch(raw, args.image_size, args.image_size, 1.0, params=prm)
+            ev[1].record()
+            torch.cuda.synchronize()
+            ms = ev[0].elapsed_time(ev[1]) / 5
+            t0c = time.perf_counter()
+            du.draw_train_params(b_aug, src, src, args.image_size, args.image_size, 1.0)
+            draw_ms = (time.perf_counter() - t0c) * 1e3
+            augment = dict(ms_per_batch=round(ms, 3), images_per_s=round(b_aug / (ms * 1e-3), 1), batch=b_aug,
+                           source='uint8 %dx%d' % (src, src), host_param_draw_ms=round(draw_ms, 2),
+                           note='crop + bicubic resize + flip + colour jitter + grayscale, both views, on the device; outside the timed step')
+            del raw, prm
+        except Exception as e:      # never let the side measurement break the benchmark line
+            augment = dict(error=repr(e))
+
     line = {
         'metric': 'images/sec (whole node), ResNet-%d %dx%s SimCLR pretraining step @%dpx' % (
             args.resnet_depth, args.width_multiplier, '+SK' if args.sk_ratio > 0 else '', args.image_size),
@@ -394,6 +423,7 @@ def main():
         'kernels': kernels,
         'f32_mode': f32_mode,
         'allgather': coll,
+        'augment': augment,
         'train_metrics': {k: round(v, 5) for k, v in metrics.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
