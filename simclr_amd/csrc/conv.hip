@@ -60,6 +60,10 @@ struct ConvP {
   const void* x2;
   const float* bias;
   int ic2, pixpitch2;
+  // Halo-window instantiations (WIN: 3x3, stride 1, pad 1, bf16): the gathered operand of a 128-pixel tile is ONE window
+  // of win_j*32 consecutive pixels (the tile plus W+1 pixels either side) per 64-channel chunk, loaded once and read at
+  // nine row offsets, instead of nine separately gathered 128-row tiles.  win_bytes = LDS bytes of the window region.
+  int win_j, win_bytes;
   const void* zero;  // 16 zero bytes in device memory (source of padding chunks for direct-to-LDS loads):
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
@@ -406,8 +410,13 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 // N-tiles) sit on the same XCD and advance in lockstep, so the gathered A tile is served by
 // that XCD's L2.
 // ------------------------------------------------------------------------------------
-template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false>
-__global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void conv_igemm_persistent(const ConvP p) {
+#ifndef SIMCLR_BN64_WPE
+#define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
+#endif
+template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
+          bool WIN = false>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
+  static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int WN = BN / 64;           // waves along N
@@ -423,8 +432,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
   constexpr int STG = (BM + BN) * 8;              // u32x4 per stage
   u32x4* As = (u32x4*)smem;                       // stage s: As + s*STG
   u32x4* Bs = As + BM * 8;                        // stage s: Bs + s*STG
-  float* bnp = (float*)(As + STAGES * STG);       // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile (+ [BN] bias if EXT)
+  // WIN layout: [window region (win_bytes; doubles as the C staging buffer)] [2 x B tile] [bnp] [rowoff] [one zero row]
+  u32x4* Wn = (u32x4*)smem;
+  u32x4* Bw = (u32x4*)(smem + (WIN ? p.win_bytes : 0));
+  float* bnp = WIN ? (float*)(Bw + 2 * BN * 8)
+                   : (float*)(As + STAGES * STG);  // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile (+ [BN] bias if EXT)
   long long* rowoff = (long long*)(bnp + (4 + (EXT ? 1 : 0)) * BN); // [BM] output offsets of the tile rows (LDS epilogue)
+  const int zrow = WIN ? (int)(((unsigned char*)(rowoff + BM) - smem) >> 7) : 0;   // WIN: index of a 128-byte row of zeros
   constexpr bool LDS_EPI = sizeof(T) == 2;        // bf16: coalesced row-wise epilogue through LDS
   constexpr int NTH = NW * 64;
   constexpr int CPR = BN / 8;                     // 16-byte chunks (8 channels) per C row
@@ -457,8 +471,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
 
   const int kc = (lane & 7) ^ (lane >> 3);
   // 1x1 stride-1 (and the Dense layers): output row m reads input pixel m -- no decode at all
-  const bool flat = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.cs == 1 &&
-                    p.IH == p.OH && p.IW == p.OW;
+  const bool flat = WIN || (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.cs == 1 &&
+                            p.IH == p.OH && p.IW == p.OW);   // WIN: same geometry in and out, output row m = pixel m
   // Row state: (a_ry, a_rx) = base input pixel of the row, a_rb = its address (chunk kc, channel 0).
   // Tap i reads pixel (a_ry + tap_dy[i], a_rx + tap_dx[i]) -- offsets are uniform per tap and
   // precomputed on the host, so a tap change costs two adds, two unsigned compares and one 64-bit
@@ -580,7 +594,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       if (it < count && iti < p.ntaps) set_tap(iti);
     }
   };
-  if (count > 0) {
+  // ---- halo-window variant: B tiles run one step ahead through the 2-stage ring, the A window is per (tile, chunk)
+  const int Wd = p.IW;
+  int wti = 0, wci = 0;                    // B issue cursor: (tap, chunk), chunk-major steps
+  auto issue_b = [&]() __attribute__((always_inline)) {
+    const int k0 = (int)((p.tap_w >> (4 * wti)) & 15) * p.IC + wci * BK;
+    unsigned char* b_dst = (unsigned char*)(Bw + ibuf * (BN * 8)) + wave * BJ * 1024;
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const void* src = b_ok[j] ? (const void*)(b_src[j] + k0) : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(b_dst + j * 1024), 16, 0, 0);
+    }
+    ibuf ^= 1;
+    ++issued;
+    if (++wti == 9) { wti = 0; if (++wci == kpt) wci = 0; }
+  };
+  auto issue_win = [&](int m0w, int c) __attribute__((always_inline)) {
+    for (int j = 0; j < p.win_j; ++j) {
+      const int blk = wave * p.win_j + j;                     // wave-uniform 8-row block of the window
+      const long long pix = (long long)m0w - (Wd + 1) + 8 * blk + (lane >> 3);
+      const void* src = (pix >= 0 && pix < p.M) ? (const void*)(X + pix * p.pixpitch + c * BK + kc * EPC) : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + blk * 1024), 16, 0, 0);
+    }
+  };
+  if (WIN) {
+    if (tid < 8) Wn[zrow * 8 + tid] = zero16();
+    if (count > 0) issue_b();
+  } else if (count > 0) {
     setup_rows(mslot);
     set_tap(0);
 #pragma unroll
@@ -593,6 +633,70 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (WIN) {
+      const int m0w = (mslot + ct * mslots) * BM;
+      // per fragment row: window row of the centre pixel and the 9-bit validity mask of its 3x3 neighbourhood
+      int rb[MI];
+      unsigned vm[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int ml = wm * (MI * 16) + i * 16 + fl;
+        rb[i] = ml + Wd + 1;
+        const int m = m0w + ml;
+        unsigned msk = 0;
+        if (m < p.M) {
+          const int q = m / Wd, x = m - q * Wd, y = q % p.IH;
+          const unsigned cm = (x > 0 ? 1u : 0u) | 2u | (x < Wd - 1 ? 4u : 0u);
+          msk = (y > 0 ? cm : 0u) | (cm << 3) | (y < p.IH - 1 ? cm << 6 : 0u);
+        }
+        vm[i] = msk;
+      }
+      // window row (or the zero row) every fragment row reads at step t
+      auto win_rows = [&](int t, int zr, int* rr) __attribute__((always_inline)) {
+        const int ody = (int)((p.dy_w >> (4 * t)) & 15) - 8 - (MODE == MODE_FWD ? p.pad : 0);
+        const int odx = (int)((p.dx_w >> (4 * t)) & 15) - 8 - (MODE == MODE_FWD ? p.pad : 0);
+        const int doff = ody * Wd + odx, vbit = (ody + 1) * 3 + (odx + 1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) rr[i] = ((vm[i] >> vbit) & 1u) ? rb[i] + doff : zr;
+      };
+      auto win_load = [&](const u32x4* Wc, const int* rr, const u32x4* Bt, int ks, u32x4* af, u32x4* bf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = Wc[rr[i] * 8 + ((ks * 4 + g) ^ (rr[i] & 7))];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int r = wn * 64 + i * 16 + fl;
+          bf[i] = Bt[r * 8 + ((ks * 4 + g) ^ (r & 7))];
+        }
+      };
+      auto win_mma = [&](const u32x4* af, const u32x4* bf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MMA<T>::run(bf[ni], af[mi], acc[ni][mi]);
+      };
+      auto win_step = [&](const u32x4* Wc, int zr, const u32x4* Bt, int t) __attribute__((always_inline)) {
+        int rr[MI];
+        win_rows(t, zr, rr);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 af[MI], bf[NI];
+          win_load(Wc, rr, Bt, ks, af, bf);
+          win_mma(af, bf);
+        }
+      };
+      for (int c = 0; c < kpt; ++c) {
+        __syncthreads();                     // every wave is done with the previous window / C staging contents
+        issue_win(m0w, c);
+        for (int t = 0; t < 9; ++t) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (issued < total) issue_b();
+          win_step(Wn, zrow, Bw + buf * (BN * 8), t);
+          buf ^= 1;
+          ++consumed;
+        }
+      }
+    } else
     for (int kt = 0; kt < KT; ++kt) {
       // the tile about to be consumed must have landed; newer tiles may stay in flight
       if (STAGES == 3 && issued - consumed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
@@ -645,7 +749,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : 2) void con
       // XOR-swizzled by row)  3) barrier  4) row-wise pass: 16-byte coalesced loads of the BN input /
       // mask / previous value, ReLU mask, per-channel sums, 16-byte coalesced stores.
       const int cst = (buf == 0) ? STAGES - 1 : buf - 1;
-      unsigned char* Cs = (unsigned char*)(As + cst * STG);
+      unsigned char* Cs = WIN ? smem : (unsigned char*)(As + cst * STG);
       __syncthreads();
       if (tid < BM) rowoff[tid] = row_off(m0 + tid);
 #pragma unroll
@@ -1913,6 +2017,22 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     const size_t plds = 2 * (128 + BN) * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long);
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
+    // 3x3 stride-1 bf16: halo-window operand path (one window load per 64-channel chunk instead of nine gathers)
+    static const bool no_win = []{ const char* e = getenv("SIMCLR_CONV3_WIN"); return e && e[0] == '0'; }();
+    if (sizeof(T) == 2 && !no_win && !p.x2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.cs == 1 &&
+        p.ntaps == 9 && p.IH == p.OH && p.IW == p.OW && p.IW <= 62) {
+      const int rows = ((128 + 2 * (p.IW + 1)) + 31) / 32 * 32;
+      p.win_j = rows / 32;
+      p.win_bytes = rows * 128 > 128 * BN * 2 ? rows * 128 : 128 * BN * 2;
+      const size_t wlds = (size_t)p.win_bytes + 2 * BN * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long) + 128;
+#define LW(BNv, STv, BEv) \
+      hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, BNv, 4, 2, STv, BEv, false, true>), dim3(pg), dim3(256), wlds, stream, p)
+      if (p.bn_mode) { if (BN == 64) LW(64, true, true); else LW(128, true, true); }
+      else if (BN == 64) { if (st) LW(64, true, false); else LW(64, false, false); }
+      else { if (st) LW(128, true, false); else LW(128, false, false); }
+#undef LW
+      return;
+    }
     if (!p.bn_mode && p.x2) {  // K-extended dgrad, plain epilogue (the conv input is not a BatchNorm output: block entry)
       if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 64, 4, 2, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
       else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, false, false, true>), dim3(pg), dim3(256), plds, stream, p);

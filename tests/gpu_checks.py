@@ -876,6 +876,7 @@ def check_conv_bench_path(V, H, Cin, Cout, k, stride, dtype, seed=0, nsample=409
     b1 = torch.zeros(Cin, device=DEV, dtype=torch.float64)
     b2 = torch.zeros_like(b1)
     l1 = torch.zeros_like(b1)
+    xh_max = 0.0
     dw64 = None
     for v0, v1, y64, dx64, dw64 in _ref64_conv(x, w, dy, k, stride, pad, OH, OW, vchunk):
         e_y = max(e_y, float((y[v0:v1].double() - y64).abs().max())); m_y = max(m_y, float(y64.abs().max()))
@@ -889,6 +890,7 @@ def check_conv_bench_path(V, H, Cin, Cout, k, stride, dtype, seed=0, nsample=409
                 mk = (bn_x[v0:v1].double() * scale.double() + shift.double()) > 0
             dmr = torch.where(mk, da, torch.zeros((), device=DEV, dtype=torch.float64))
             xh = (bn_x[v0:v1].double() - mean.double()) * rstd.double()
+            xh_max = max(xh_max, float(xh.abs().max()))
             b1 += dmr.sum((0, 1, 2)); b2 += (dmr * xh).sum((0, 1, 2)); l1 += (dmr * xh).abs().sum((0, 1, 2)) + dmr.abs().sum((0, 1, 2))
             e_dm = max(e_dm, float((dm[v0:v1].double() - dmr).abs().max())); m_dm = max(m_dm, float(dmr.abs().max()))
         del y64, dx64
@@ -907,8 +909,12 @@ def check_conv_bench_path(V, H, Cin, Cout, k, stride, dtype, seed=0, nsample=409
     if dm is not None:
         btag = ' mode%d acc%d' % (mode, acc)
         res.append(ent('bigconv_dgrad_bn_dm' + btag, e_dm, m_dm, t * (2 if acc else 1)))
-        res.append(ent('bigconv_dgrad_bn_sum' + btag, float((bsum[0] - b1).abs().max()), float(l1.max()), sum_tol))
-        res.append(ent('bigconv_dgrad_bn_sumxhat' + btag, float((bsum[1] - b2).abs().max()), float(l1.max()), sum_tol))
+        # bf16: the kernel sums the ROUNDED dm it stores (what the BatchNorm backward apply will read); against the unrounded
+        # float64 sums that is a random walk of M steps of half-ulp size, which dominates the L1-relative term for small M
+        walk = 0.0 if dtype == torch.float32 else 6.0 * (V * H * W) ** 0.5 * 2.0 ** -9 * m_dm
+        res.append(ent('bigconv_dgrad_bn_sum' + btag, float((bsum[0] - b1).abs().max()), float(l1.max()), sum_tol, walk))
+        res.append(ent('bigconv_dgrad_bn_sumxhat' + btag, float((bsum[1] - b2).abs().max()), float(l1.max()), sum_tol,
+                       walk * max(1.0, xh_max)))
 
     # ---- (b) sampled rows vs float64 on the CPU (independent gather formulation)
     gs = torch.Generator().manual_seed(seed + 99)

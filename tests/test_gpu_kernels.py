@@ -101,6 +101,11 @@ BENCH_PATH_CASES = [
     (1024, 14, 256, 256, 3, 1, (2, 0)),    # 3x3 @14^2 (256x256 wgrad tile)
     (1024, 7, 512, 2048, 1, 1, (2, 0)),    # group 4 expand
     (1024, 7, 512, 512, 3, 1, (1, 0)),     # 3x3 @7^2
+    # halo-window 3x3 path (bf16): tiles that straddle image boundaries, ragged last tile, widest supported row
+    (256, 28, 128, 128, 3, 1, (3, 1)),     # 3x3 @28^2, residual accumulate + ReLU bits in the dgrad epilogue
+    (5, 9, 64, 64, 3, 1, (2, 0)),          # M = 405: four tiles, 81-pixel images (every tile holds image borders)
+    (3, 62, 64, 128, 3, 1, None),          # W = 62: the 256-row window exactly covers tile + halo
+    (2, 64, 64, 64, 3, 1, (2, 0)),         # W = 64: falls back to the gathered path
 ]
 
 

@@ -76,12 +76,18 @@ def main():
             t_n = timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=None, out=y), args.iters)
             t_d = timeit(lambda: ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H, out=dx), args.iters)
             t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, k, k, s, pad, out=dw), args.iters)
+            t_db = 0.0
+            if s == 1:      # dgrad with the fused BatchNorm-backward reduce (mask recomputed from the BN input: mode 2)
+                bn = dict(x=x, mask=None, scale=torch.rand(Cin, device=dev) - 0.4, shift=torch.randn(Cin, device=dev) * 0.3,
+                          mean=torch.randn(Cin, device=dev) * 0.2, rstd=torch.rand(Cin, device=dev) + 0.5, mode=2)
+                t_db = timeit(lambda: ops.conv2d_dgrad_bn(dy, w_d, k, k, pad, H, H, bn, out=dx), args.iters)
             fl = 2.0 * V * OH * OH * k * k * Cin * Cout
             by = x.element_size() * (x.numel() + y.numel())
             name = '%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt)
-            print('%-26s %9.0f %9.0f %9.0f %9.0f | %6.0f %6.0f %6.0f | %6.0f' % (
-                name, t_f, t_n, t_d, t_w, fl / t_f / 1e6, fl / t_d / 1e6, fl / t_w / 1e6, by / t_f / 1e3), flush=True)
-            res.append(dict(layer=name, fwd_us=t_f, fwd_nostats_us=t_n, dgrad_us=t_d, wgrad_us=t_w, flops=fl, bytes=by, count=cnt))
+            print('%-26s %9.0f %9.0f %9.0f %9.0f | %6.0f %6.0f %6.0f | %6.0f | dgrad_bn %4.0f' % (
+                name, t_f, t_n, t_d, t_w, fl / t_f / 1e6, fl / t_d / 1e6, fl / t_w / 1e6, by / t_f / 1e3, t_db), flush=True)
+            res.append(dict(layer=name, fwd_us=t_f, fwd_nostats_us=t_n, dgrad_us=t_d, wgrad_us=t_w, dgrad_bn_us=t_db, flops=fl,
+                            bytes=by, count=cnt))
             tot['fwd'] += cnt * t_f; tot['fwd_nostats'] += cnt * t_n; tot['dgrad'] += cnt * t_d; tot['wgrad'] += cnt * t_w
             del x, dy, y, dx
         print('per-step totals (ms): fwd %.2f (no stats %.2f)  dgrad %.2f  wgrad %.2f' % (
