@@ -79,6 +79,14 @@ int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin,
 /* modes 0 (dst_t) and 1 (dst_d) of the same weight in one launch. */
 int simclr_prep_weights_pair(const float* w_hwio, void* dst_t, void* dst_d, int KH, int KW, int Cin, int Cout,
                              int CinP, int CoutP, int dtype, simclr_stream_t stream);
+/* The (dst_t, dst_d) pairs of MANY convolutions in one launch: the refresh of every compute copy after an optimizer
+ * step (tf2/resnet.py:183-208 has 52 of these layers in ResNet-50).  table: device int64 [T][8] = {w_hwio, dst_t, dst_d,
+ * KH*KW, Cin, Cout, CinP, CoutP}; chunks: device int64 [nchunks][2] = {tensor index, tile}: one entry per E x E tile
+ * (E = simclr_prep_chunk_elems()) of every tap's padded (CinP, CoutP) plane, tile = (tap * nci + ci_tile) * nco + co_tile,
+ * nci = ceil(CinP / E), nco = ceil(CoutP / E). */
+int simclr_prep_chunk_elems(void);
+int simclr_prep_weights_pair_multi(const long long* table, const long long* chunks, int nchunks, int dtype,
+                                   simclr_stream_t stream);
 /* Partial-statistics slots.  Every `stats` / `partial` argument below is float [nslot][2][C], zeroed by the caller.
  * With nslot >= the number returned here each producing workgroup stores into its OWN slot (no float atomics) and the
  * slot reduction of simclr_bn_finalize / simclr_bn_bwd_finalize / simclr_bn_reduce_slots adds the slots in a fixed

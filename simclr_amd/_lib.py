@@ -74,7 +74,8 @@ class _Lib:
             fn.argtypes = argtypes
         self._int_fns = {n for n, (r, _) in self.signatures.items() if r is ctypes.c_int}
         self._no_check = {'simclr_abi_version', 'simclr_lars_chunk_elems', 'simclr_conv2d_stats_slots',
-                          'simclr_stem_stats_slots', 'simclr_bn_bwd_reduce_slots', 'simclr_bn_bwd_pool_slots'}
+                          'simclr_stem_stats_slots', 'simclr_bn_bwd_reduce_slots', 'simclr_bn_bwd_pool_slots',
+                          'simclr_prep_chunk_elems'}
 
     def last_error(self):
         return self._dll.simclr_last_error().decode()

@@ -17,44 +17,49 @@
 
 namespace {
 
-// Fixed-order reduction of the partial-statistics slots: a 256-thread workgroup owns 32 channels; thread
-// (sl = tid / 32, cl = tid % 32) adds slots sl, sl+8, sl+16, ... of channel c0+cl in ascending order (coalesced
-// 128-byte rows, several loads in flight), then the eight lane sums are added in the order sl = 0..7.  The order
-// never depends on timing, so the result is bit-identical from run to run whatever wrote the slots.
+// Fixed-order reduction of the partial-statistics slots: a 1024-thread workgroup owns 32 channels; thread
+// (sl = tid / 32, cl = tid % 32) adds slots sl, sl+32, sl+64, ... of channel c0+cl in ascending order (coalesced
+// 128-byte rows, four loads per statistic in flight), then the 32 lane sums are added in the order sl = 0..31.  The
+// order never depends on timing, so the result is bit-identical from run to run whatever wrote the slots.  32 slot
+// lanes: with up to 768 slots (one per persistent conv workgroup) the walk is 6 dependent round trips instead of 24
+// -- these launches sit on the critical path between a convolution and its BatchNorm apply, ~130 of them per step.
 // Returns the two sums of channel c0 + (tid % 32) in the threads with tid < 32 (others: partial values).
 constexpr int kSlotCh = 32;
+constexpr int kSlotLanes = 32;
+constexpr int kSlotThreads = kSlotCh * kSlotLanes;
 __device__ __forceinline__ void slot_sums(const float* __restrict__ partial, int nslot, int C, int c0,
-                                          double* sh /* [2][8][32] */, double& s1, double& s2) {
+                                          double* sh /* [2][kSlotLanes][32] */, double& s1, double& s2) {
   const int sl = threadIdx.x >> 5, cl = threadIdx.x & 31, c = c0 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
     int s = sl;
-    for (; s + 24 < nslot; s += 32) {            // four independent loads per statistic in flight
+    const long long st = 2ll * kSlotLanes * C;    // floats between slots s and s + kSlotLanes
+    for (; s + 3 * kSlotLanes < nslot; s += 4 * kSlotLanes) {
       const float* q = partial + (long long)s * 2 * C + c;
-      const float a0 = q[0], a1 = q[16ll * C], a2 = q[32ll * C], a3 = q[48ll * C];
-      const float b0 = q[C], b1 = q[16ll * C + C], b2 = q[32ll * C + C], b3 = q[48ll * C + C];
+      const float a0 = q[0], a1 = q[st], a2 = q[2 * st], a3 = q[3 * st];
+      const float b0 = q[C], b1 = q[st + C], b2 = q[2 * st + C], b3 = q[3 * st + C];
       a += (double)a0; a += (double)a1; a += (double)a2; a += (double)a3;
       b += (double)b0; b += (double)b1; b += (double)b2; b += (double)b3;
     }
-    for (; s < nslot; s += 8) {
+    for (; s < nslot; s += kSlotLanes) {
       a += (double)partial[(long long)s * 2 * C + c];
       b += (double)partial[(long long)s * 2 * C + C + c];
     }
   }
   sh[sl * 32 + cl] = a;
-  sh[256 + sl * 32 + cl] = b;
+  sh[kSlotThreads + sl * 32 + cl] = b;
   __syncthreads();
   s1 = 0.0; s2 = 0.0;
   if (threadIdx.x < 32) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1 += sh[j * 32 + cl]; s2 += sh[256 + j * 32 + cl]; }
+#pragma unroll 8
+    for (int j = 0; j < kSlotLanes; ++j) { s1 += sh[j * 32 + cl]; s2 += sh[kSlotThreads + j * 32 + cl]; }
   }
 }
 
 // sums[2][C] (double) = sum over slots of partial[slot][2][C] (float)
-__global__ __launch_bounds__(256) void bn_reduce_slots(const float* __restrict__ partial, int nslot, int C,
+__global__ __launch_bounds__(kSlotThreads) void bn_reduce_slots(const float* __restrict__ partial, int nslot, int C,
                                                        double* __restrict__ sums) {
-  __shared__ double sh[512];
+  __shared__ double sh[2 * kSlotThreads];
   const int c0 = blockIdx.x * kSlotCh;
   double s1, s2;
   slot_sums(partial, nslot, C, c0, sh, s1, s2);
@@ -64,14 +69,14 @@ __global__ __launch_bounds__(256) void bn_reduce_slots(const float* __restrict__
 
 // From global sums -> mean/rstd/scale/shift, moving-stat update.  If `partial` is given (single
 // replica: no all-reduce between) the slot reduction is done here instead of a separate launch.
-__global__ __launch_bounds__(256) void bn_finalize(const double* __restrict__ sums, const float* __restrict__ partial,
+__global__ __launch_bounds__(kSlotThreads) void bn_finalize(const double* __restrict__ sums, const float* __restrict__ partial,
                             int nslot, double count, int C,
                             const float* __restrict__ gamma, const float* __restrict__ beta,
                             float* __restrict__ moving_mean, float* __restrict__ moving_var,
                             float decay, float eps, float* __restrict__ mean_out,
                             float* __restrict__ rstd_out, float* __restrict__ scale,
                             float* __restrict__ shift) {
-  __shared__ double sh[512];
+  __shared__ double sh[2 * kSlotThreads];
   const int c0 = blockIdx.x * kSlotCh;
   double s1 = 0.0, s2 = 0.0;
   if (partial) slot_sums(partial, nslot, C, c0, sh, s1, s2);
@@ -251,12 +256,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(
 }
 
 // local sums -> dgamma/dbeta (+=), global sums/count -> c1 = mean(dy), c2 = mean(dy*x^)
-__global__ __launch_bounds__(256) void bn_bwd_finalize(const double* __restrict__ local_sums,
+__global__ __launch_bounds__(kSlotThreads) void bn_bwd_finalize(const double* __restrict__ local_sums,
                                 const double* __restrict__ global_sums, const float* __restrict__ partial,
                                 int nslot, double count, int C,
                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                 float* __restrict__ c1, float* __restrict__ c2) {
-  __shared__ double sh[512];
+  __shared__ double sh[2 * kSlotThreads];
   const int c0 = blockIdx.x * kSlotCh;
   double l1 = 0.0, l2 = 0.0, g1, g2;
   if (partial) slot_sums(partial, nslot, C, c0, sh, l1, l2);     // single replica: local == global
@@ -444,7 +449,7 @@ int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype) {
 // partial [nslot][2][C] fp32 -> sums [2][C] fp64 (the buffer the host all-reduces)
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, hipStream_t stream) {
   SIMCLR_CHECK_ARG(nslot > 0 && C > 0, "bn_reduce_slots: bad shape");
-  hipLaunchKernelGGL(bn_reduce_slots, dim3(ceil_div(C, kSlotCh)), dim3(256), 0, stream, partial, nslot, C, sums);
+  hipLaunchKernelGGL(bn_reduce_slots, dim3(ceil_div(C, kSlotCh)), dim3(kSlotThreads), 0, stream, partial, nslot, C, sums);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -458,7 +463,7 @@ int simclr_bn_finalize(const double* sums, const float* partial, int nslot, doub
                        hipStream_t stream) {
   SIMCLR_CHECK_ARG(C > 0 && count > 0, "bn_finalize: bad shape");
   SIMCLR_CHECK_ARG((sums != nullptr) != (partial != nullptr), "bn_finalize: give sums OR partial slots");
-  hipLaunchKernelGGL(bn_finalize, dim3(ceil_div(C, kSlotCh)), dim3(256), 0, stream, sums, partial, nslot, count, C,
+  hipLaunchKernelGGL(bn_finalize, dim3(ceil_div(C, kSlotCh)), dim3(kSlotThreads), 0, stream, sums, partial, nslot, count, C,
                      gamma, beta, moving_mean, moving_var, decay, eps, mean, rstd, scale, shift);
   SIMCLR_CHECK_LAUNCH();
   return 0;
@@ -525,7 +530,7 @@ int simclr_bn_bwd_finalize(const double* local_sums, const double* global_sums, 
                            float* c1, float* c2, hipStream_t stream) {
   SIMCLR_CHECK_ARG((local_sums != nullptr && global_sums != nullptr) != (partial != nullptr),
                    "bn_bwd_finalize: give (local, global) sums OR partial slots");
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(C, kSlotCh)), dim3(256), 0, stream, local_sums, global_sums,
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(ceil_div(C, kSlotCh)), dim3(kSlotThreads), 0, stream, local_sums, global_sums,
                      partial, nslot, count, C, dgamma, dbeta, accumulate, c1, c2);
   SIMCLR_CHECK_LAUNCH();
   return 0;

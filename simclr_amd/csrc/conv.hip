@@ -1739,28 +1739,39 @@ __global__ __launch_bounds__(256) void small_gemm_nt_f32(const float* __restrict
   }
 }
 
-// dw[i] = sum_s slabs[s][i]  (+ dw[i] if accumulate).  One float4 per thread; the slab loop is unrolled by 8
-// with independent loads so that eight 16-byte requests per lane are in flight (a plain dependent loop keeps
-// one).  Summation order is fixed (s ascending), so the result does not depend on the launch geometry.
+// dw[i] = sum_s slabs[s][i]  (+ dw[i] if accumulate).  A workgroup owns 16 float4 columns; its 256 threads are 16 columns
+// x 16 slab lanes: lane l adds slabs l, l+16, l+32, ... (four independent loads in flight), the 16 partial sums meet in
+// LDS and are added in lane order.  The summation tree depends only on `splits`, never on the launch geometry, so the
+// gradient is bit-identical from run to run; spreading the slab loop over 16 lanes matters because the layers with few
+// weights (64 x 64 ... 64 x 256) have up to 256 slabs and only a few thousand columns -- a one-thread-per-column loop
+// is a chain of 32 dependent memory round trips (22 us per launch, 73 launches per step).
 __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ slabs, int splits, long long numel,
                                                    float* __restrict__ out, int accumulate) {
+  __shared__ float4 red[16][16];
   const long long n4 = numel / 4;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int tx = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long i = blockIdx.x * 16ll + tx;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
     const float* src = slabs + i * 4;
-    int s = 0;
-    for (; s + 8 <= splits; s += 8) {
-      float4 v[8];
+    int s = sl;
+    for (; s + 48 < splits; s += 64) {
+      float4 v[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *(const float4*)(src + (long long)(s + j) * numel);
+      for (int j = 0; j < 4; ++j) v[j] = *(const float4*)(src + (long long)(s + 16 * j) * numel);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+      for (int j = 0; j < 4; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
     }
-    for (; s < splits; ++s) {
+    for (; s < splits; s += 16) {
       const float4 v = *(const float4*)(src + (long long)s * numel);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+  }
+  red[sl][tx] = a;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { const float4 v = red[l][tx]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
     if (accumulate) {
       const float4 v = *(const float4*)(out + i * 4);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
@@ -1952,6 +1963,43 @@ __global__ void prep_weights_pair(const float* __restrict__ w, T* __restrict__ d
     const float v = (ci < CI && co < CO) ? w[((long long)tap * CI + ci) * CO + co] : 0.f;
     Elem<T>::st(dst_t + (long long)co * taps * CIP + (long long)tap * CIP + ci, v);
     Elem<T>::st(dst_d + (long long)ci * taps * COP + (long long)tap * COP + co, v);
+  }
+}
+
+// prep_weights_pair for MANY convolutions in one launch (the per-step refresh of every bf16 compute copy after the
+// optimizer step: 52 launches of ~8 us each otherwise, all of them dominated by 2-byte scattered stores).
+// table[t] = {src, dst_t, dst_d, taps, CI, CO, CIP, COP}; workgroup b handles the 64 x 64 (ci, co) tile chunks[b] =
+// {t, tile} of one tap: the tile goes through LDS so that BOTH copies are written in 128-byte runs (dst_d along co as
+// read, dst_t along ci after the transpose).
+constexpr int kPrepTile = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weights_pair_multi(const long long* __restrict__ table,
+                                                               const long long* __restrict__ chunks) {
+  __shared__ float tile[kPrepTile][kPrepTile + 1];
+  const long long t = chunks[2 * blockIdx.x];
+  int idx = (int)chunks[2 * blockIdx.x + 1];
+  const long long* e = table + 8 * t;
+  const float* __restrict__ w = (const float*)e[0];
+  T* __restrict__ dst_t = (T*)e[1];
+  T* __restrict__ dst_d = (T*)e[2];
+  const int taps = (int)e[3], CI = (int)e[4], CO = (int)e[5], CIP = (int)e[6], COP = (int)e[7];
+  const int nci = (CIP + kPrepTile - 1) / kPrepTile, nco = (COP + kPrepTile - 1) / kPrepTile;
+  const int tap = idx / (nci * nco);
+  idx -= tap * nci * nco;
+  const int ci0 = (idx / nco) * kPrepTile, co0 = (idx % nco) * kPrepTile;
+  const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int r = r0; r < kPrepTile; r += 4) {
+    const int ci = ci0 + r, co = co0 + c;
+    const float v = (ci < CI && co < CO) ? w[((long long)tap * CI + ci) * CO + co] : 0.f;
+    tile[r][c] = v;
+    if (ci < CIP && co < COP) Elem<T>::st(dst_d + ((long long)ci * taps + tap) * COP + co, v);
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int r = r0; r < kPrepTile; r += 4) {
+    const int co = co0 + r, ci = ci0 + c;
+    if (ci < CIP && co < COP) Elem<T>::st(dst_t + ((long long)co * taps + tap) * CIP + ci, tile[c][r]);
   }
 }
 
@@ -2365,7 +2413,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     hipLaunchKernelGGL(conv_wgrad3x3_bf16, dim3(grid3), dim3(256), lds3, stream, q);
     SIMCLR_CHECK_LAUNCH();
     const long long numel3 = (long long)p.K * p.N;
-    hipLaunchKernelGGL(slab_reduce, dim3(max(1, min(1 << 20, ceil_div(numel3 / 4, 256)))), dim3(256), 0, stream,
+    hipLaunchKernelGGL(slab_reduce, dim3(max(1, (int)ceil_div(numel3 / 4, 16))), dim3(256), 0, stream,
                        (const float*)workspace, q.splits, numel3, dw, accumulate);
     SIMCLR_CHECK_LAUNCH();
     return 0;
@@ -2456,7 +2504,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
 #undef LW
   SIMCLR_CHECK_LAUNCH();
   const long long numel = (long long)p.K * p.N;
-  hipLaunchKernelGGL(slab_reduce, dim3(max(1, min(1 << 20, ceil_div(numel / 4, 256)))), dim3(256), 0, stream,
+  hipLaunchKernelGGL(slab_reduce, dim3(max(1, (int)ceil_div(numel / 4, 16))), dim3(256), 0, stream,
                      (const float*)workspace, p.splits, numel, dw, accumulate);
   SIMCLR_CHECK_LAUNCH();
   return 0;
@@ -2504,7 +2552,7 @@ int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, 
   }
   SIMCLR_CHECK_LAUNCH();
   const long long numel = (long long)K * K + K;
-  hipLaunchKernelGGL(slab_reduce, dim3(max(1, min(1 << 20, ceil_div(numel / 4, 256)))), dim3(256), 0, stream,
+  hipLaunchKernelGGL(slab_reduce, dim3(max(1, (int)ceil_div(numel / 4, 16))), dim3(256), 0, stream,
                      (const float*)workspace, p.splits, numel, out, 0);
   SIMCLR_CHECK_LAUNCH();
   return 0;
@@ -2582,6 +2630,22 @@ int simclr_prep_weights_pair(const float* w_hwio, void* dst_t, void* dst_d, int 
   else
     hipLaunchKernelGGL((prep_weights_pair<float>), dim3(grid), dim3(256), 0, stream, w_hwio, (float*)dst_t,
                        (float*)dst_d, KH * KW, Cin, Cout, CinP, CoutP);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// Every (w_t, w_d) pair of a model in one launch.  table: device int64 [T][8] = {w_hwio, dst_t, dst_d, KH*KW, Cin, Cout,
+// CinP, CoutP}; chunks: device int64 [nchunks][2] = {tensor, tile}, tile = (tap * nci + ci_tile) * nco + co_tile with
+// nci = ceil(CinP / E), nco = ceil(CoutP / E), E = simclr_prep_chunk_elems() (the tile edge).
+int simclr_prep_chunk_elems(void) { return kPrepTile; }
+int simclr_prep_weights_pair_multi(const long long* table, const long long* chunks, int nchunks, int dtype,
+                                   hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "prep_weights_pair_multi: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(table && chunks && nchunks > 0, "prep_weights_pair_multi: empty table");
+  if (dtype == SIMCLR_DT_BF16)
+    hipLaunchKernelGGL((prep_weights_pair_multi<uint16_t>), dim3(nchunks), dim3(256), 0, stream, table, chunks);
+  else
+    hipLaunchKernelGGL((prep_weights_pair_multi<float>), dim3(nchunks), dim3(256), 0, stream, table, chunks);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

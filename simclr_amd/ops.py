@@ -152,6 +152,41 @@ def prep_weights_pair(w_hwio, dtype, cin_p=0, cout_p=0):
     return w_t, w_d
 
 
+class WeightPairBatch:
+    """Refreshes the (w_t, w_d) compute copies of many convolutions with ONE launch (simclr_prep_weights_pair_multi).
+    entries: list of (w_hwio fp32 [KH,KW,CI,CO], cin_p, cout_p); the output buffers are allocated once and keep their
+    addresses, so the descriptor table is built once per (dtype, set of master pointers)."""
+
+    def __init__(self, entries, dtype):
+        dev = entries[0][0].device
+        self.dtype = dtype
+        self.key = tuple(w.data_ptr() for w, _, _ in entries)
+        self.pairs = []
+        chunk = lib().prep_chunk_elems()
+        table, chunks = [], []
+        for t, (w, cip, cop) in enumerate(entries):
+            KH, KW, CI, CO = w.shape
+            cip, cop = cip or CI, cop or CO
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            w_t = torch.empty(cop, KH * KW * cip, device=dev, dtype=dtype)
+            w_d = torch.empty(cip, KH * KW * cop, device=dev, dtype=dtype)
+            self.pairs.append((w_t, w_d))
+            table += [w.data_ptr(), w_t.data_ptr(), w_d.data_ptr(), KH * KW, CI, CO, cip, cop]
+            ntile = KH * KW * ((cip + chunk - 1) // chunk) * ((cop + chunk - 1) // chunk)
+            chunks += [(t, i) for i in range(ntile)]
+        self.table = torch.tensor(table, dtype=torch.int64).to(dev)
+        self.chunks = torch.tensor(chunks, dtype=torch.int64).view(-1).to(dev)
+        self.nchunks = len(chunks)
+
+    def matches(self, entries, dtype):
+        return dtype == self.dtype and self.key == tuple(w.data_ptr() for w, _, _ in entries)
+
+    def run(self):
+        lib().prep_weights_pair_multi(_p(self.table), _p(self.chunks), self.nchunks,
+                                      DT_BF16 if self.dtype == torch.bfloat16 else DT_F32, _s())
+        return self.pairs
+
+
 def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None):
     V, IH, IW, Cin = x.shape
     Cout = w_t.shape[0]
@@ -290,7 +325,7 @@ class _StatsArena:
         self.missed = 0
         self.want = 0
 
-    def begin_step(self, device, nfloats=32 << 20):
+    def begin_step(self, device, nfloats=64 << 20):
         want = max(nfloats, getattr(self, 'want', 0))
         if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < want:
             self.buf = torch.zeros(want, device=device, dtype=torch.float32)

@@ -21,6 +21,7 @@ dim, 32*w stem) are zero-padded internally.  Not built (fail loudly): SE (se_rat
 DropBlock (:81-157, unreachable in the reference too), channels_first.
 """
 import math
+import weakref
 
 import torch
 
@@ -30,6 +31,7 @@ from .flags import FLAGS
 from .lars_optimizer import Variable
 
 BATCH_NORM_EPSILON = 1e-5  # tf2/resnet.py:28
+_PREP_PER_LAYER = __import__('os').environ.get('SIMCLR_PREP_BATCH', '1') == '0'   # A/B: one weight-copy launch per layer
 
 
 # --------------------------------------------------------------------------- runtime context
@@ -48,6 +50,8 @@ class _Runtime:
         self.weights_version = 0     # bumped by the optimizer step; compute copies refresh lazily
         self._wgrad_stream = None
         self._consts = {}
+        self.convs = []              # every built Conv2dFixedPadding with a (w_t, w_d) pair: refreshed in one launch
+        self._conv_batch = None
 
     def const(self, C, value):
         """Cached constant fp32 vector on the device (means 0 / rstd 1 for plain column sums)."""
@@ -57,6 +61,20 @@ class _Runtime:
             t = torch.full((C,), float(value), device=self.device, dtype=torch.float32)
             self._consts[key] = t
         return t
+
+    def refresh_conv_weights(self):
+        """Rewrite the compute copies (w_t, w_d) of EVERY registered convolution from the fp32 masters with one launch
+        and mark them current.  Called by the first stale layer after an optimizer step / checkpoint restore."""
+        self.convs = [r for r in self.convs if r() is not None]      # weak references: models may have been dropped
+        convs = [r() for r in self.convs]
+        convs = [c for c in convs if c is not None and c.kernel is not None]
+        entries = [(c.kernel.value, c.cin_p, c.cout_p) for c in convs]
+        if self._conv_batch is None or not self._conv_batch.matches(entries, self.dtype):
+            self._conv_batch = ops.WeightPairBatch(entries, self.dtype)
+        for c, (w_t, w_d) in zip(convs, self._conv_batch.run()):
+            c.w_t, c.w_d = w_t, w_d
+            c._version = self.weights_version
+            c._dtype = self.dtype
 
     def wgrad_stream(self):
         """Side stream for the weight-gradient kernels (SIMCLR_WGRAD_STREAM=1), else None."""
@@ -387,6 +405,8 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         self.cin_p = cin if cin_p is None else cin_p
         self.cout_p = pad64(self.filters) if self.filters % 64 else self.filters
         self.padded = self.cin_p != cin or self.cout_p != self.filters
+        if not getattr(self, 'is_stem', False) and cin > 4:
+            RT.convs.append(weakref.ref(self))
 
     def _refresh(self, stem_geo=None):
         if self._version == RT.weights_version and getattr(self, '_dtype', None) == RT.dtype:
@@ -395,7 +415,11 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         if stem_geo is not None:
             self.w_s = ops.prep_weights(w, 2, RT.dtype, stem_geo['KHP'], stem_geo['KWP'], cout_p=self.cout_p)
         else:
-            self.w_t, self.w_d = ops.prep_weights_pair(w, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
+            if _PREP_PER_LAYER or not any(r() is self for r in RT.convs):   # (built under an earlier RT.reset())
+                self.w_t, self.w_d = ops.prep_weights_pair(w, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
+            else:
+                RT.refresh_conv_weights()
+                return
         self._version = RT.weights_version
         self._dtype = RT.dtype
 
