@@ -239,7 +239,8 @@ int simclr_bn_fold_s2(const float* t1, const void* w, const float* mean, const f
 /* h^T h [K*K] followed by colsum(h) [K] for h [M][K] (T), K in {64, 128, 256(bf16)}: the activation is streamed once */
 size_t simclr_conv2d_gram_workspace_bytes(long long M, int K, int dtype);
 int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, int K, int dtype, simclr_stream_t stream);
-/* C [M][N] = A [M][K] B[N][K]^T, fp32 on the matrix cores (the small K x K / K x N products of the folded form) */
+/* C [M][N] = A [M][K] B[N][K]^T, fp32 on the matrix cores (the small K x K / K x N products of the folded form);
+ * M, N multiples of 16, K of 32 */
 int simclr_small_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, simclr_stream_t stream);
 int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext, const float* bias, void* dx,
                                int accumulate, const void* bn_x, const void* bn_mask, const float* bn_scale,

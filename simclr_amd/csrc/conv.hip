@@ -1703,39 +1703,77 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
     }
 }
 
-// C[m][n] = sum_k A[m][k] * B[n][k]   (fp32, row-major, K contiguous in both; m, n multiples of 16, k of 16).
-// Small helper GEMM of the folded BatchNorm backward ((W*b) W^T and (h^T h) W: at most 512 x 2048 x 2048): one wave per
-// 16 x 64 output strip, fragments loaded straight from global memory (the operands are L2 resident), exact f32 MFMA.
+// C[m][n] = sum_k A[m][k] * B[n][k]   (fp32, row-major, K contiguous in both; m, n multiples of 16, k of 32).
+// Small helper GEMM of the folded BatchNorm backward ((W*b) W^T and (h^T h) W: at most 512 x 2048 x 2048), exact f32
+// MFMA.  A workgroup owns a TT x TT tile (64: waves 2 x 2 of 32 x 32; 32: waves 2 x 2 of 16 x 16 -- picked so that the
+// launch has >= 1024 waves, one per SIMD, whenever the problem has that many fragments); the operands go global ->
+// registers -> LDS in 32-wide k-chunks with full 128-byte rows per request (the former one-wave-per-strip version read
+// 64-byte row pieces straight from L2 and spent 150 us on the 512 x 512 x 2048 product against an MFMA floor of 27).
+template <int TT>
 __global__ __launch_bounds__(256) void small_gemm_nt_f32(const float* __restrict__ A, const float* __restrict__ B,
                                                          float* __restrict__ C, int M, int N, int K) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int LDR = 36;                          // padded row (floats): 16-byte aligned, rows 4 banks apart
+  constexpr int FR = TT / 32;                      // 16 x 16 fragments per wave along each dimension
+  constexpr int LPT = TT * 8 / 256;                // float4 loads per thread per operand per chunk
+  __shared__ __attribute__((aligned(16))) float As[TT * LDR], Bs[TT * LDR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fl = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * 64 + wave * 16;
-  const int n0 = blockIdx.x * 64;
-  if (m0 >= M) return;
-  f32x4 acc[4];
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * TT, n0 = blockIdx.x * TT;
+  f32x4 acc[FR][FR];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float* ap = A + (long long)(m0 + fl) * K + 4 * q;
-#pragma unroll 4
-  for (int k = 0; k < K; k += 16) {       // unrolled: the loads of four k-steps are in flight together
-    const float4 av = *(const float4*)(ap + k);
+  for (int i = 0; i < FR; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + j * 16 + fl;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N) bv = *(const float4*)(B + (long long)n * K + k + 4 * q);
-      // D[n-row = g*4+reg][m-col = fl]: B fragment as the first operand, like the conv kernels
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, av.x, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, av.y, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.z, av.z, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.w, av.w, acc[j], 0, 0, 0);
+    for (int j = 0; j < FR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ra[LPT], rb[LPT];
+  auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+      const int idx = tid + l * 256, r = idx >> 3, c = (idx & 7) * 4;
+      ra[l] = (m0 + r < M) ? *(const float4*)(A + (long long)(m0 + r) * K + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[l] = (n0 + r < N) ? *(const float4*)(B + (long long)(n0 + r) * K + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    __syncthreads();                               // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+      const int idx = tid + l * 256, r = idx >> 3, c = (idx & 7) * 4;
+      *(float4*)(As + r * LDR + c) = ra[l];
+      *(float4*)(Bs + r * LDR + c) = rb[l];
+    }
+    __syncthreads();
+    if (k0 + 32 < K) gload(k0 + 32);               // in flight during the MFMAs of this chunk
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 af[FR], bf[FR];
+#pragma unroll
+      for (int i = 0; i < FR; ++i) {
+        af[i] = *(const float4*)(As + (wm * (FR * 16) + i * 16 + fl) * LDR + h * 16 + 4 * q);
+        bf[i] = *(const float4*)(Bs + (wn * (FR * 16) + i * 16 + fl) * LDR + h * 16 + 4 * q);
+      }
+      // D[n-row = g*4+reg][m-col = fl]: B fragment as the first operand, like the conv kernels; the four k values of a
+      // lane's float4 go to four MFMAs (any k order: both operands use the same one)
+#pragma unroll
+      for (int i = 0; i < FR; ++i)
+#pragma unroll
+        for (int j = 0; j < FR; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].x, af[i].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].y, af[i].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].z, af[i].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j].w, af[i].w, acc[i][j], 0, 0, 0);
+        }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + j * 16 + q * 4;
-    if (n < N) *(float4*)(C + (long long)(m0 + fl) * N + n) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  for (int i = 0; i < FR; ++i) {
+    const int m = m0 + wm * (FR * 16) + i * 16 + fl;
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+      const int n = n0 + wn * (FR * 16) + j * 16 + q * 4;
+      if (m < M && n < N) *(float4*)(C + (long long)m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
   }
 }
 
@@ -2560,8 +2598,11 @@ int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, 
 
 // C [M][N] = A [M][K] B[N][K]^T in fp32 on the matrix cores; M, N multiples of 16, K of 16 (small helper GEMMs)
 int simclr_small_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t stream) {
-  SIMCLR_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % 16 == 0 && N % 16 == 0 && K % 16 == 0, "small_gemm_nt_f32: M=%d N=%d K=%d must be multiples of 16", M, N, K);
-  hipLaunchKernelGGL(small_gemm_nt_f32, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, stream, A, B, C, M, N, K);
+  SIMCLR_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % 16 == 0 && N % 16 == 0 && K % 32 == 0, "small_gemm_nt_f32: M=%d N=%d must be multiples of 16, K=%d of 32", M, N, K);
+  if ((long long)ceil_div(M, 64) * ceil_div(N, 64) >= 256)
+    hipLaunchKernelGGL((small_gemm_nt_f32<64>), dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, stream, A, B, C, M, N, K);
+  else
+    hipLaunchKernelGGL((small_gemm_nt_f32<32>), dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, stream, A, B, C, M, N, K);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

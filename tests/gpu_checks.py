@@ -1279,3 +1279,17 @@ def check_pool_bn_bwd_fusion(V, H, C, dtype, seed=0):
     # in bf16 the un-fused path rounds the un-pooled gradient to bf16 before summing; the fused one sums fp32 values
     return [_res('poolfuse_dx ' + tag, dx, xr.grad, 1e-2 if bf else 5e-5),
             _res('poolfuse_sums_vs_unfused ' + tag, ops.bn_reduce_slots(part), ops.bn_reduce_slots(part_un), 2e-3 if bf else 1e-5)]
+
+
+def check_small_gemm(M, N, K, seed=0):
+    """simclr_small_gemm_nt_f32 (C = A B^T, exact f32 MFMA) vs float64; both tile shapes (32 / 64) are reached by the
+    sizes the folded BatchNorm backward uses (K x K x 4K and K x 4K x K, K = 64 ... 512)."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    B = torch.randn(N, K, device=DEV, generator=g)
+    C = ops.small_gemm_nt(A, B)
+    ref = A.double() @ B.double().t()
+    err = float((C.double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    tol = 4e-6 * scale * max(1.0, (K / 256.0) ** 0.5)
+    return [dict(name='small_gemm_nt_f32 %dx%dx%d' % (M, N, K), err=err, tol=tol, scale=scale, ok=bool(err <= tol), nbad=0, numel=M * N)]

@@ -395,3 +395,11 @@ def test_batchnorm_backward_folded_into_expand_conv(V, H, K, N, dtype):
 def test_stem_backward_with_fused_maxpool_backward(V, H, dtype):
     from tests import gpu_checks as gc
     _assert(gc.check_pool_bn_bwd_fusion(V, H, 64, dtype))
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 64, 256), (64, 256, 64), (512, 512, 2048), (512, 2048, 512), (256, 1024, 256),
+                                   (48, 80, 96), (128, 128, 32)])
+def test_small_gemm_nt_f32(M, N, K):
+    """The helper GEMMs of the folded BatchNorm backward: both workgroup tile shapes, ragged tile edges."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_small_gemm(M, N, K))
