@@ -98,10 +98,20 @@ int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype);
 
 /* y[V,OH,OW,Cout] = conv(x[V,IH,IW,Cin], w), explicit symmetric padding `pad` (resnet.py:167-180).
  * stats (nullable) float[nslot][2][Cout], zeroed by caller: per-channel partial (sum, sum sq) of y
- * for BatchNorm (resnet.py:50-78).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0. */
+ * for BatchNorm (resnet.py:50-78).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0.
+ * y == NULL (bf16, stats required): statistics-only pass -- the convolution is computed, nothing is stored. */
 int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V, int IH,
                       int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
                       int dtype, simclr_stream_t stream);
+/* The same convolution with its consumer's BatchNorm apply in the epilogue (bf16 only; resnet.py:470-487, conv3 -> bn3 ->
+ * + shortcut -> relu):  y = act(bf16(conv(x)) * scale + shift + res);  relu_bits[i] bit e = (y[8 i + e] > 0).
+ * Bitwise equal to simclr_conv2d_fwd followed by simclr_bn_apply; the convolution output never reaches memory.
+ * scale / shift [Cout]: from simclr_bn_finalize over the statistics of a first simclr_conv2d_fwd(y = NULL) pass.
+ * res (nullable) [V,OH,OW,Cout]; relu: 0 | 1; relu_bits (nullable) uint8 [V*OH*OW*Cout/8]. */
+int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const float* scale, const float* shift,
+                               const void* res, int relu, unsigned char* relu_bits, int V, int IH, int IW, int Cin,
+                               int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,
+                               simclr_stream_t stream);
 /* dx[V,IH,IW,Cin] (+)= conv_transpose(dy[V,OH,OW,Cout], w); autodiff of the above (run.py:621). */
 int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulate, int V, int IH, int IW,
                         int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,

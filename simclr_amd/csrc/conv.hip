@@ -64,6 +64,8 @@ struct ConvP {
   // of win_j*32 consecutive pixels (the tile plus W+1 pixels either side) per 64-channel chunk, loaded once and read at
   // nine row offsets, instead of nine separately gathered 128-row tiles.  win_bytes = LDS bytes of the window region.
   int win_j, win_bytes;
+  int fapply;      // forward with the fused BatchNorm-apply epilogue (FAPPLY instantiations): bn_scale / bn_shift = the
+                   // BatchNorm's scale / shift, bn_x = residual (nullable), bn_mask = ReLU bit mask OUT (nullable), bn_mode = relu
   const void* zero;  // 16 zero bytes in device memory (source of padding chunks for direct-to-LDS loads):
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
@@ -414,9 +416,14 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false>
+          bool WIN = false, bool FAPPLY = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
   static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
+  // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
+  // before it is stored -- y = act(bf16(conv) * scale + shift + res) with exactly the arithmetic of bn_apply (csrc/bn.hip),
+  // so the convolution output itself never travels to HBM.  The statistics that scale / shift derive from come from a
+  // first, store-free pass of the same convolution (STATS instantiation with y == nullptr).
+  static_assert(!FAPPLY || (sizeof(T) == 2 && MODE == MODE_FWD && !STATS && !BNEPI && !EXT), "fused BN-apply epilogue: forward bf16");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int WN = BN / 64;           // waves along N
@@ -549,10 +556,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     }
   };
 
-  if (BNEPI || EXT) {
+  if (BNEPI || EXT || FAPPLY) {
     for (int i = tid; i < BN; i += NW * 64) {
       const int n = n0 + i;
       const bool ok = n < p.N;
+      if (FAPPLY) {
+        bnp[i] = ok ? p.bn_scale[n] : 0.f;
+        bnp[BN + i] = ok ? p.bn_shift[n] : 0.f;
+      }
       if (BNEPI) {
         bnp[i] = (ok && p.bn_mode == 2) ? p.bn_scale[n] : 0.f;
         bnp[BN + i] = (ok && p.bn_mode == 2) ? p.bn_shift[n] : 0.f;
@@ -748,6 +759,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       // 1) barrier (every wave is done reading it)  2) accumulators -> bf16 C tile (8-byte granules,
       // XOR-swizzled by row)  3) barrier  4) row-wise pass: 16-byte coalesced loads of the BN input /
       // mask / previous value, ReLU mask, per-channel sums, 16-byte coalesced stores.
+      if (STATS && !BNEPI && Y == nullptr) {
+        // statistics-only pass (first half of the fused conv + BatchNorm-apply forward): nothing is staged or stored
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
+        continue;
+      }
       const int cst = (buf == 0) ? STAGES - 1 : buf - 1;
       unsigned char* Cs = WIN ? smem : (unsigned char*)(As + cst * STG);
       __syncthreads();
@@ -790,6 +811,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
 #pragma unroll
         for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
       }
+      if (FAPPLY && p.bn_x) {          // residual operand of the fused BatchNorm apply
+#pragma unroll
+        for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
+      }
       if (BNEPI) {
         if (p.bn_mode != 4) {
 #pragma unroll
@@ -814,6 +839,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         uint16_t* dst = (uint16_t*)Y + eoff[i];
         float v[8];
         chunk_to_f32<uint16_t>(cv, v);
+        if (FAPPLY) {
+          // the arithmetic of bn_apply<RES = 0 | 1> on the bf16-rounded convolution result: bitwise the same output as
+          // conv -> HBM -> bn_apply
+          float qv[8];
+          if (p.bn_x) chunk_to_f32<uint16_t>(e_xv[i], qv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float o = fmaf(v[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
+            if (p.bn_x) o += qv[e];
+            v[e] = p.bn_mode ? fmaxf(o, 0.f) : o;          // bn_mode doubles as the ReLU flag here
+          }
+          const u32x4 packed = f32_to_chunk<uint16_t>(v);
+          *(u32x4*)dst = packed;
+          if (p.bn_mask) {                                  // bit e = (stored y[e] > 0), one byte per 16-byte chunk
+            float w8[8];
+            chunk_to_f32<uint16_t>(packed, w8);
+            unsigned bits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bits |= (w8[e] > 0.f ? 1u : 0u) << e;
+            ((unsigned char*)p.bn_mask)[eoff[i] >> 3] = (unsigned char)bits;
+          }
+          continue;
+        }
         if (EXT) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bnp[4 * BN + e_cc * 8 + e];
@@ -2093,7 +2141,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   const bool st = p.stats != nullptr;
   static const bool no_glds = getenv("SIMCLR_NO_GLDS") != nullptr;   // A/B switches for benchmarking
   static const bool no_persist = getenv("SIMCLR_NO_PERSISTENT") != nullptr;
-  if ((p.bn_mode || (!no_glds && !no_persist)) && p.ntaps > 0 && p.n_tiles <= 64) {
+  if ((p.bn_mode || p.fapply || !p.y || (!no_glds && !no_persist)) && p.ntaps > 0 && p.n_tiles <= 64) {
     // Tile choice: 128x128 / 128x64, 4 waves, 2-stage LDS ring, 2-3 workgroups per CU.  Measured
     // alternatives that were slower on every ResNet-50 layer (profiles/r01_notes.md): 256x128 with 8
     // waves (one workgroup per CU), and 3-stage rings with counted vmcnt for either tile.
@@ -2103,6 +2151,11 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     const size_t plds = 2 * (128 + BN) * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long);
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
+    if (p.fapply) {
+      if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, 64, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
+      else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, 128, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
+      return;
+    }
     // 3x3 stride-1 bf16: halo-window operand path (one window load per 64-channel chunk instead of nine gathers)
     static const bool no_win = []{ const char* e = getenv("SIMCLR_CONV3_WIN"); return e && e[0] == '0'; }();
     if (sizeof(T) == 2 && !no_win && !p.x2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.cs == 1 &&
@@ -2220,6 +2273,7 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd: M overflows int32");
   SIMCLR_CHECK_ARG(!stats || nslot > 0, "conv2d_fwd: nslot must be > 0 with stats");
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd: at most 9 taps (got %dx%d)", KH, KW);
+  SIMCLR_CHECK_ARG(y || (stats && dtype == SIMCLR_DT_BF16), "conv2d_fwd: y == NULL (statistics-only pass) needs stats and bf16");
   ConvP p = {};
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
@@ -2229,6 +2283,36 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   p.M = V * OH * OW; p.K = KH * KW * Cin;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_FWD>(p, stream);
   else launch_igemm<float, MODE_FWD>(p, stream);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// Forward conv with the BatchNorm apply of its consumer fused into the epilogue (bf16 only):
+//   y = act(bf16(conv(x)) * scale + shift + res),   relu_bits[i] bit e = (y[8 i + e] > 0)
+// -- bitwise what simclr_conv2d_fwd followed by simclr_bn_apply produces, without the convolution output ever reaching
+// memory.  scale / shift [Cout] come from the statistics of a first pass (simclr_conv2d_fwd with y == NULL: statistics
+// only) through simclr_bn_finalize.  res (nullable): residual [V,OH,OW,Cout]; relu_bits (nullable): uint8 [V*OH*OW*Cout/8].
+// tf2/resnet.py:470-487 (conv3 -> bn3 -> + shortcut -> relu of the bottleneck block).
+int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const float* scale, const float* shift,
+                               const void* res, int relu, unsigned char* relu_bits, int V, int IH, int IW, int Cin,
+                               int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,
+                               hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16, "conv2d_fwd_bn_apply: bf16 only (dtype %d)", dtype);
+  SIMCLR_CHECK_ARG(Cin % 64 == 0, "conv2d_fwd_bn_apply: Cin=%d must be a multiple of 64", Cin);
+  SIMCLR_CHECK_ARG(Cout % 8 == 0, "conv2d_fwd_bn_apply: Cout=%d must be a multiple of 8", Cout);
+  SIMCLR_CHECK_ARG(x && w_t && y && scale && shift, "conv2d_fwd_bn_apply: null argument");
+  SIMCLR_CHECK_ARG(V > 0 && OH > 0 && OW > 0 && stride >= 1, "conv2d_fwd_bn_apply: bad geometry");
+  SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd_bn_apply: M overflows int32");
+  SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd_bn_apply: at most 9 taps (got %dx%d)", KH, KW);
+  ConvP p = {};
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
+  p.x = x; p.w = w_t; p.y = y;
+  p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
+  p.M = V * OH * OW; p.K = KH * KW * Cin;
+  p.fapply = 1; p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
+  launch_igemm<uint16_t, MODE_FWD>(p, stream);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

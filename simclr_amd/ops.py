@@ -187,17 +187,37 @@ class WeightPairBatch:
         return self.pairs
 
 
-def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None):
+def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None, store=True):
+    """store=False (bf16, stats required): statistics-only pass, nothing is written and None is returned (first half
+    of the fused conv + BatchNorm-apply forward, conv2d_fwd_bn_apply)."""
     V, IH, IW, Cin = x.shape
     Cout = w_t.shape[0]
-    if out is None:
+    if not store:
+        assert stats is not None and out is None
+    elif out is None:
         out = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
     M, K = V * OH * OW, KH * KW * Cin
     esz = x.element_size()
-    _launch('conv_igemm_fwd', 2.0 * M * K * Cout, esz * (V * IH * IW * Cin + M * Cout + K * Cout),
+    _launch('conv_igemm_fwd', 2.0 * M * K * Cout, esz * (V * IH * IW * Cin + (M * Cout if store else 0) + K * Cout),
             lambda: lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0] if stats is not None else 0, V,
                                      IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
     return out
+
+
+def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=None, relu=True, want_bits=False):
+    """y = act(bf16(conv(x)) * scale + shift + res) in ONE kernel (bf16): what conv2d_fwd + bn_apply produce, bit for
+    bit, without the convolution output travelling to memory.  Returns y or (y, relu_bits)."""
+    V, IH, IW, Cin = x.shape
+    Cout = w_t.shape[0]
+    assert x.dtype == torch.bfloat16
+    y = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
+    M, K = V * OH * OW, KH * KW * Cin
+    bits = torch.empty(M, Cout // 8, device=x.device, dtype=torch.uint8) if want_bits else None
+    nb = 2 * (V * IH * IW * Cin + M * Cout * (2 if res is not None else 1) + K * Cout) + (M * Cout // 8 if want_bits else 0)
+    _launch('conv_igemm_fwd', 2.0 * M * K * Cout, nb,
+            lambda: lib().conv2d_fwd_bn_apply(_p(x), _p(w_t), _p(y), _p(scale), _p(shift), _p(res), int(relu), _p(bits), V,
+                                              IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
+    return (y, bits) if want_bits else y
 
 
 def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=False):

@@ -119,12 +119,14 @@ def pad64(c):
 class Act:
     """An activation tensor plus (optionally) the fused per-channel statistics partials.  `c` is the
     logical channel count when the tensor carries zero-padded channels (t.shape[-1] = pad64(c))."""
-    __slots__ = ('t', 'stats', 'c')
+    __slots__ = ('t', 'stats', 'c', 'shape')
 
-    def __init__(self, t, stats=None, c=None):
+    def __init__(self, t, stats=None, c=None, shape=None):
+        # t is None for a statistics-only convolution pass (the tensor is never materialised): shape tells its geometry
         self.t = t
         self.stats = stats
-        self.c = t.shape[-1] if c is None else c
+        self.shape = tuple(t.shape) if t is not None else tuple(shape)
+        self.c = self.shape[-1] if c is None else c
 
 
 class PackedInput:
@@ -226,11 +228,11 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         """sums: the cross-replica [2,C] fp64 sums (SyncBatchNormalization, :50-60) or None (one replica /
         global_bn off: the slot reduction is fused into the finalize kernel)."""
         x = inputs.t
-        C = x.shape[-1]
+        C = inputs.shape[-1]
         if self.moving_mean is None:
             self.build(inputs.c, C)
         g, b = self._pg, self._pb
-        rows = x.numel() // C
+        rows = math.prod(inputs.shape[:-1])
         if training:
             if inputs.stats is None:
                 raise NotImplementedError('BatchNormRelu input must come from a conv/dense epilogue')
@@ -339,6 +341,12 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
                                        mask_mode, want_masked=want_masked)
         self.saved = None
         return dx, dmasked
+
+
+def _conv3_fused_enabled():
+    """SIMCLR_CONV3_FUSED=0: the tail of an identity bottleneck block runs as conv3 -> HBM -> bn_apply again."""
+    import os
+    return os.environ.get('SIMCLR_CONV3_FUSED', '1') not in ('', '0')
 
 
 def _sync_bn():
@@ -459,6 +467,34 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             self.w_t32 = self.w_t if self.w_t.dtype == torch.float32 else ops.cast(self.w_t, torch.float32)
             self._v32 = self._version
         return self.w_d32, self.w_t32
+
+    def forward_stats_only(self, inputs):
+        """First half of the fused conv + BatchNorm-apply forward: the statistics of this convolution's output, which is
+        not stored.  Saves the input for the backward like __call__."""
+        k, s = self.kernel_size, self.strides
+        x = inputs.t
+        V, H, W, cin_p = x.shape
+        if self.kernel is None:
+            self.build(inputs.c, cin_p)
+        self._refresh()
+        pad = (k - 1) // 2
+        OH = (H + (k - 1) - k) // s + 1
+        OW = (W + (k - 1) - k) // s + 1
+        stats = ops.conv_stats(V * OH * OW, self.cout_p, RT.device)
+        ops.conv2d_fwd(x, self.w_t, k, k, s, pad, OH, OW, stats=stats, store=False)
+        self.saved = dict(x=x, H=H, W=W, pad=pad)
+        return Act(None, stats, c=self.filters, shape=(V, OH, OW, self.cout_p))
+
+    def forward_bn_apply(self, inputs, scale, shift, res=None, relu=True, want_bits=False):
+        """Second half: the convolution again, with y = act(bn(conv) + res) applied in its epilogue."""
+        k, s = self.kernel_size, self.strides
+        x = inputs.t
+        V, H, W, _ = x.shape
+        pad = (k - 1) // 2
+        OH = (H + (k - 1) - k) // s + 1
+        OW = (W + (k - 1) - k) // s + 1
+        return ops.conv2d_fwd_bn_apply(x, self.w_t, k, k, s, pad, OH, OW, scale, shift, res=res, relu=relu,
+                                       want_bits=want_bits)
 
     def backward_folded(self, dm, bn_out, partial, fuse_bn, s2_from_gemm=False, dx_out=None, accumulate=False):
         """1x1 stride-1 conv whose output c = h W goes through `bn_out` (BatchNorm, no ReLU before the add): the BN backward
@@ -802,13 +838,33 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
             h = self.sk(h, training)
         else:
             h = self.bn2(self.conv2(h, training), training)
-        h = self.conv3(h, training)
-        out = self.bn3(h, training, relu=True, add=sc, add_bn=sc_bn, want_bits=training)     # relu(inputs + shortcut), :487
+        self.fused_tail = self._fused_tail(training, sc_bn, h)
+        if self.fused_tail:
+            # conv3's output is 4x wider than its input and only feeds bn3: compute it twice instead of storing it.
+            # Pass 1 produces the statistics, pass 2 applies relu(bn3(.) + shortcut) in the epilogue; the backward of this
+            # block never reads conv3's output either (folded BatchNorm backward, sum(dm*x^) from the weight-gradient GEMM).
+            st = self.conv3.forward_stats_only(h)
+            scale, shift = self.bn3.prepare(st, training)
+            y, bits = self.conv3.forward_bn_apply(h, scale, shift, res=sc, relu=True, want_bits=True)
+            self.bn3.relu_bits = bits
+            self.bn3.saved['y'] = y
+            self.bn3.saved['masked'] = True
+            out = Act(y, c=st.c)
+        else:
+            h = self.conv3(h, training)
+            out = self.bn3(h, training, relu=True, add=sc, add_bn=sc_bn, want_bits=training)     # relu(inputs + shortcut), :487
         self.out = out.t
         return out
 
     def _foldable(self):
         return self.sk is None and not self.conv3.padded and _bn_fold_enabled()
+
+    def _fused_tail(self, training, sc_bn, h):
+        # identity blocks whose tail BatchNorm backward will arrive folded (every block but the network's last one)
+        if self.conv3.kernel is None:
+            self.conv3.build(h.c, h.t.shape[-1])
+        return (training and sc_bn is None and self.shortcut is None and not getattr(self, 'is_final', False)
+                and RT.dtype == torch.bfloat16 and self._foldable() and _bn_s2_enabled() and _conv3_fused_enabled())
 
     def tail_info(self):
         # foldable tail: the consumer's dgrad epilogue only masks and sums dm (no read of this block's conv3 output)
@@ -817,6 +873,9 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
     def backward(self, dout, dout_partial=None, prev_tail=None):
         """See ResidualBlock.backward.  Returns (dx, partial-or-None)."""
         fold = dout_partial is not None and self._foldable()
+        if getattr(self, 'fused_tail', False) and not fold:
+            raise RuntimeError('bottleneck block ran the fused conv3 + bn3 forward (conv3 output not stored) but its '
+                               'backward did not receive the folded tail reduction; set SIMCLR_CONV3_FUSED=0')
         if fold:
             # tail BN3 backward folded into conv3's wgrad / dgrad (no bn_bwd_apply pass, no dh3 tensor); with
             # _bn_s2_enabled() the producer of `dout` did not even read conv3's output for the BN3 reduce
@@ -927,6 +986,7 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
                                                     data_format=data_format,
                                                     dropblock_keep_prob=dropblock_keep_probs[i],
                                                     dropblock_size=dropblock_size))
+            self.block_groups[-1].layers[-1].is_final = True     # its output feeds the pooling: no consumer conv folds its tail
 
     @property
     def stem_kernel_stride(self):

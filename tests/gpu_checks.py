@@ -1087,7 +1087,8 @@ def check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f3
     return res
 
 
-def check_step_determinism(depth=18, image_size=32, batch=16, compute_dtype='bf16', steps=2, num_classes=10, seed=0):
+def check_step_determinism(depth=18, image_size=32, batch=16, compute_dtype='bf16', steps=2, num_classes=10, seed=0,
+                           env_second=None):
     """Two fresh models, same weights, same batches: every weight, BN moving statistic and LARS momentum must be
     BIT-IDENTICAL after `steps` steps (the reference's step is deterministic on TPU, tf2/resnet.py:54-60)."""
     from simclr_amd import model as model_lib
@@ -1099,7 +1100,15 @@ def check_step_determinism(depth=18, image_size=32, batch=16, compute_dtype='bf1
     labs = [{'labels': torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes).float().to(DEV)}
             for _ in range(steps)]
     snaps = []
+    import os
     for run in range(2):
+        # env_second: environment switches applied to the SECOND run only -- an optimisation that claims to be bitwise
+        # neutral (e.g. SIMCLR_CONV3_FUSED=0 vs the default fused conv3 + bn3 forward) must leave every weight identical
+        saved_env = {}
+        if run == 1 and env_second:
+            for k_, v_ in env_second.items():
+                saved_env[k_] = os.environ.get(k_)
+                os.environ[k_] = v_
         FLAGS.reset()
         FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype=compute_dtype, use_blur=False, train_batch_size=batch)
         RT.reset()
@@ -1114,9 +1123,14 @@ def check_step_determinism(depth=18, image_size=32, batch=16, compute_dtype='bf1
         snap = {v.name: v.value.clone() for v in model.variables}
         snap.update({'momentum/' + v.name: opt.get_slot(v, 'Momentum').clone() for v in model._flat_order})
         snaps.append(snap)
+        for k_, v_ in saved_env.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
     diff = [k for k in snaps[0] if not torch.equal(snaps[0][k], snaps[1][k])]
     worst = max([float((snaps[0][k] - snaps[1][k]).abs().max()) for k in diff] + [0.0])
-    tag = 'R%d %dpx b%d %s %d steps' % (depth, image_size, batch, compute_dtype, steps)
+    tag = 'R%d %dpx b%d %s %d steps%s' % (depth, image_size, batch, compute_dtype, steps, ' vs %s' % env_second if env_second else '')
     return [dict(name='step_bitwise_deterministic ' + tag, err=float(len(diff)), tol=0.0, scale=worst, ok=not diff, nbad=len(diff),
                  numel=len(snaps[0]), first=diff[:3])]
 
@@ -1293,3 +1307,52 @@ def check_small_gemm(M, N, K, seed=0):
     scale = float(ref.abs().max())
     tol = 4e-6 * scale * max(1.0, (K / 256.0) ** 0.5)
     return [dict(name='small_gemm_nt_f32 %dx%dx%d' % (M, N, K), err=err, tol=tol, scale=scale, ok=bool(err <= tol), nbad=0, numel=M * N)]
+
+
+def check_conv_fwd_bn_apply(V, H, Cin, Cout, k=1, stride=1, with_res=True, relu=True, seed=0):
+    """simclr_conv2d_fwd(y = NULL) + simclr_conv2d_fwd_bn_apply (the conv3 -> bn3 -> + shortcut -> relu tail of
+    tf2/resnet.py:470-487 in two passes over the convolution, its output never stored) against the three-kernel path
+    conv2d_fwd -> bn_finalize -> bn_apply: statistics, output and ReLU bit mask must be BIT-IDENTICAL."""
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    pad = (k - 1) // 2
+    OH = (H + (k - 1) - k) // stride + 1
+    x = (torch.randn(V, H, H, Cin, device=DEV, generator=g)).to(dtype)
+    w = torch.randn(k, k, Cin, Cout, device=DEV, generator=g) * (k * k * Cin) ** -0.5
+    res = torch.randn(V, OH, OH, Cout, device=DEV, generator=g).to(dtype) if with_res else None
+    gamma = torch.rand(Cout, device=DEV, generator=g) + 0.5
+    beta = 0.2 * torch.randn(Cout, device=DEV, generator=g)
+    w_t = ops.prep_weights(w, 0, dtype)
+    M = V * OH * OH
+    # reference path
+    st_a = ops.conv_stats(M, Cout, DEV)
+    c = ops.conv2d_fwd(x, w_t, k, k, stride, pad, OH, OH, stats=st_a)
+    mm, mv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean, rstd, scale, shift = ops.bn_finalize(None, M, gamma, beta, mm, mv, 0.9, partial=st_a)
+    y_ref, bits_ref = ops.bn_apply(c, scale, shift, relu, res=res, want_bits=True) if relu else (ops.bn_apply(c, scale, shift, relu, res=res), None)
+    # fused path
+    st_b = ops.conv_stats(M, Cout, DEV)
+    ops.conv2d_fwd(x, w_t, k, k, stride, pad, OH, OH, stats=st_b, store=False)
+    mm2, mv2 = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    _, _, scale2, shift2 = ops.bn_finalize(None, M, gamma, beta, mm2, mv2, 0.9, partial=st_b)
+    out = ops.conv2d_fwd_bn_apply(x, w_t, k, k, stride, pad, OH, OH, scale2, shift2, res=res, relu=relu, want_bits=relu)
+    y, bits = out if relu else (out, None)
+    torch.cuda.synchronize()
+    tag = 'V%d %dx%d %d->%d k%d s%d res%d relu%d' % (V, H, H, Cin, Cout, k, stride, int(with_res), int(relu))
+
+    def same(name, a, b):
+        ok = bool(torch.equal(a, b))
+        nbad = 0 if ok else int((a != b).sum())
+        return dict(name='fwd_bn_apply_%s %s' % (name, tag), err=float(nbad), tol=0.0, scale=0.0, ok=ok, nbad=nbad, numel=a.numel())
+    res_l = [same('stats', ops.bn_reduce_slots(st_a), ops.bn_reduce_slots(st_b)), same('scale', scale, scale2),
+             same('y', y_ref.view(torch.int16), y.view(torch.int16))]
+    if relu:
+        res_l.append(same('bits', bits_ref, bits))
+    # and the output is right in the first place: float64 reference of relu(bn(conv) + res) from the bf16-rounded conv
+    ref = c.double() * scale.double() + shift.double() + (res.double() if with_res else 0.0)
+    if relu:
+        ref = ref.clamp_min(0.0)
+    err = float((y.double() - ref).abs().max())
+    sc_ = float(ref.abs().max())
+    res_l.append(dict(name='fwd_bn_apply_value ' + tag, err=err, tol=2.0 ** -7 * sc_, scale=sc_, ok=bool(err <= 2.0 ** -7 * sc_), nbad=0, numel=y.numel()))
+    return res_l

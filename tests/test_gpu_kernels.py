@@ -403,3 +403,25 @@ def test_small_gemm_nt_f32(M, N, K):
     """The helper GEMMs of the folded BatchNorm backward: both workgroup tile shapes, ragged tile edges."""
     from tests import gpu_checks as gc
     _assert(gc.check_small_gemm(M, N, K))
+
+
+@pytest.mark.parametrize('V,H,Cin,Cout,k,stride,with_res,relu', [
+    (64, 56, 64, 256, 1, 1, True, True),       # group-1 tail
+    (1024, 7, 512, 2048, 1, 1, True, True),    # group-4 tail: 16 N-tiles
+    (37, 14, 256, 1024, 1, 1, True, True),     # ragged last M-tile
+    (16, 28, 128, 512, 1, 1, False, True),     # no residual
+    (16, 28, 128, 64, 1, 1, True, False),      # 64-wide tile, no ReLU
+    (16, 28, 128, 512, 1, 2, True, True),      # strided 1x1 through the same epilogue
+])
+def test_conv_fwd_bn_apply_bitwise(V, H, Cin, Cout, k, stride, with_res, relu):
+    """Fused conv + BatchNorm-apply forward == conv2d_fwd -> bn_finalize -> bn_apply, bit for bit."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_conv_fwd_bn_apply(V, H, Cin, Cout, k, stride, with_res, relu))
+
+
+def test_train_step_fused_conv3_is_bitwise_neutral():
+    """ResNet-50 bf16: two steps with the fused conv3 + bn3 forward (default) and with SIMCLR_CONV3_FUSED=0 end in
+    bit-identical weights, BatchNorm statistics and LARS momenta."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_step_determinism(depth=50, image_size=64, batch=8, compute_dtype='bf16', steps=2,
+                                      env_second={'SIMCLR_CONV3_FUSED': '0'}))
