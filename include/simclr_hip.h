@@ -104,12 +104,15 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
                       int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
                       int dtype, simclr_stream_t stream);
 /* The same convolution with its consumer's BatchNorm apply in the epilogue (bf16 only; resnet.py:470-487, conv3 -> bn3 ->
- * + shortcut -> relu):  y = act(bf16(conv(x)) * scale + shift + res);  relu_bits[i] bit e = (y[8 i + e] > 0).
+ * + shortcut -> relu):  y = act(bf16(conv(x)) * scale + shift + r), r = res or res * rscale + rshift (projection shortcut
+ * whose BatchNorm is applied here too, resnet.py:411-421);  relu_bits[i] bit e = (y[8 i + e] > 0).
  * Bitwise equal to simclr_conv2d_fwd followed by simclr_bn_apply; the convolution output never reaches memory.
  * scale / shift [Cout]: from simclr_bn_finalize over the statistics of a first simclr_conv2d_fwd(y = NULL) pass.
- * res (nullable) [V,OH,OW,Cout]; relu: 0 | 1; relu_bits (nullable) uint8 [V*OH*OW*Cout/8]. */
+ * res (nullable) [V,OH,OW,Cout]; rscale / rshift (nullable, both or none) [Cout]; relu: 0 | 1; relu_bits (nullable)
+ * uint8 [V*OH*OW*Cout/8]. */
 int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const float* scale, const float* shift,
-                               const void* res, int relu, unsigned char* relu_bits, int V, int IH, int IW, int Cin,
+                               const void* res, const float* rscale, const float* rshift, int relu,
+                               unsigned char* relu_bits, int V, int IH, int IW, int Cin,
                                int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,
                                simclr_stream_t stream);
 /* dx[V,IH,IW,Cin] (+)= conv_transpose(dy[V,OH,OW,Cout], w); autodiff of the above (run.py:621). */
@@ -143,6 +146,12 @@ int simclr_unpack_stem_dw(const float* src, float* dst, int KH, int KW, int Cin,
 
 /* ---- BatchNorm: tf2/resnet.py:31-78 (BatchNormRelu), residual tail :382/:487 ------------------- */
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, simclr_stream_t stream);
+/* BatchNorm statistics of c = h W (1x1 convolution, tf2/resnet.py:470-474 conv3 -> bn3) without forming c:
+ * sums[0][n] = sum_k colsum(h)[k] W[k][n], sums[1][n] = sum_k GW[k][n] W[k][n] with GW = (h^T h) W [K][N] (fp32, from
+ * simclr_conv2d_gram + simclr_small_gemm_nt_f32), w_kn = the weights as multiplied, fp32 [K][N]; colsum(h) as fp64
+ * (cs64) or fp32 (cs32), exactly one non-NULL.  sums: double [2][N], the operand of simclr_bn_finalize. */
+int simclr_bn_sums_from_gram(const float* gw, const float* w_kn, const double* cs64, const float* cs32, int K, int N,
+                             double* sums, simclr_stream_t stream);
 /* sums [2][C] fp64 (after the cross-replica all-reduce) OR partial [nslot][2][C] fp32 (single replica). */
 int simclr_bn_finalize(const double* sums, const float* partial, int nslot, double count, int C,
                        const float* gamma, const float* beta, float* moving_mean, float* moving_var,

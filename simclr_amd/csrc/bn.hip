@@ -67,6 +67,28 @@ __global__ __launch_bounds__(kSlotThreads) void bn_reduce_slots(const float* __r
   if (threadIdx.x < 32 && c < C) { sums[c] = s1; sums[C + c] = s2; }
 }
 
+// BatchNorm statistics of c = h W (a 1x1 convolution, M rows) WITHOUT forming c: per output channel n
+//   sum_m c[m][n]   = sum_k colsum(h)[k] W[k][n]
+//   sum_m c[m][n]^2 = w_n^T (h^T h) w_n = sum_k GW[k][n] W[k][n],   GW = (h^T h) W
+// (h^T h and colsum(h) come from one pass over h, simclr_conv2d_gram -- the same two quantities the folded BatchNorm
+// backward needs, so the forward's statistics pass and the backward's Gram pass are ONE pass).  fp64 accumulation,
+// k ascending: deterministic.  One thread per channel, coalesced rows.
+__global__ __launch_bounds__(256) void bn_sums_from_gram(const float* __restrict__ gw, const float* __restrict__ w,
+                                                         const double* __restrict__ cs64, const float* __restrict__ cs32,
+                                                         int K, int N, double* __restrict__ sums) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  double a = 0.0, b = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < K; ++k) {
+    const double wv = (double)w[(long long)k * N + n];
+    a += (cs64 ? cs64[k] : (double)cs32[k]) * wv;
+    b += (double)gw[(long long)k * N + n] * wv;
+  }
+  sums[n] = a;
+  sums[N + n] = b;
+}
+
 // From global sums -> mean/rstd/scale/shift, moving-stat update.  If `partial` is given (single
 // replica: no all-reduce between) the slot reduction is done here instead of a separate launch.
 __global__ __launch_bounds__(kSlotThreads) void bn_finalize(const double* __restrict__ sums, const float* __restrict__ partial,
@@ -447,6 +469,15 @@ int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype) {
 }
 
 // partial [nslot][2][C] fp32 -> sums [2][C] fp64 (the buffer the host all-reduces)
+int simclr_bn_sums_from_gram(const float* gw, const float* w_kn, const double* cs64, const float* cs32, int K, int N,
+                             double* sums, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(gw && w_kn && sums && ((cs64 != nullptr) != (cs32 != nullptr)) && K > 0 && N > 0,
+                   "bn_sums_from_gram: bad arguments (exactly one of cs64 / cs32)");
+  hipLaunchKernelGGL(bn_sums_from_gram, dim3(ceil_div(N, 256)), dim3(256), 0, stream, gw, w_kn, cs64, cs32, K, N, sums);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, hipStream_t stream) {
   SIMCLR_CHECK_ARG(nslot > 0 && C > 0, "bn_reduce_slots: bad shape");
   hipLaunchKernelGGL(bn_reduce_slots, dim3(ceil_div(C, kSlotCh)), dim3(kSlotThreads), 0, stream, partial, nslot, C, sums);

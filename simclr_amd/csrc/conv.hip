@@ -563,6 +563,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       if (FAPPLY) {
         bnp[i] = ok ? p.bn_scale[n] : 0.f;
         bnp[BN + i] = ok ? p.bn_shift[n] : 0.f;
+        bnp[2 * BN + i] = (ok && p.bn_mean) ? p.bn_mean[n] : 1.f;      // the residual's own BatchNorm (projection shortcut):
+        bnp[3 * BN + i] = (ok && p.bn_rstd) ? p.bn_rstd[n] : 0.f;      // scale / shift travel in bn_mean / bn_rstd
       }
       if (BNEPI) {
         bnp[i] = (ok && p.bn_mode == 2) ? p.bn_scale[n] : 0.f;
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float o = fmaf(v[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
-            if (p.bn_x) o += qv[e];
+            if (p.bn_x) o += p.bn_mean ? fmaf(qv[e], bnp[2 * BN + e_cc * 8 + e], bnp[3 * BN + e_cc * 8 + e]) : qv[e];
             v[e] = p.bn_mode ? fmaxf(o, 0.f) : o;          // bn_mode doubles as the ReLU flag here
           }
           const u32x4 packed = f32_to_chunk<uint16_t>(v);
@@ -2288,19 +2290,22 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
 }
 
 // Forward conv with the BatchNorm apply of its consumer fused into the epilogue (bf16 only):
-//   y = act(bf16(conv(x)) * scale + shift + res),   relu_bits[i] bit e = (y[8 i + e] > 0)
+//   y = act(bf16(conv(x)) * scale + shift + r),  r = res or res * rscale + rshift (a projection shortcut's own BatchNorm),
+//   relu_bits[i] bit e = (y[8 i + e] > 0)
 // -- bitwise what simclr_conv2d_fwd followed by simclr_bn_apply produces, without the convolution output ever reaching
 // memory.  scale / shift [Cout] come from the statistics of a first pass (simclr_conv2d_fwd with y == NULL: statistics
 // only) through simclr_bn_finalize.  res (nullable): residual [V,OH,OW,Cout]; relu_bits (nullable): uint8 [V*OH*OW*Cout/8].
 // tf2/resnet.py:470-487 (conv3 -> bn3 -> + shortcut -> relu of the bottleneck block).
 int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const float* scale, const float* shift,
-                               const void* res, int relu, unsigned char* relu_bits, int V, int IH, int IW, int Cin,
+                               const void* res, const float* rscale, const float* rshift, int relu,
+                               unsigned char* relu_bits, int V, int IH, int IW, int Cin,
                                int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,
                                hipStream_t stream) {
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16, "conv2d_fwd_bn_apply: bf16 only (dtype %d)", dtype);
   SIMCLR_CHECK_ARG(Cin % 64 == 0, "conv2d_fwd_bn_apply: Cin=%d must be a multiple of 64", Cin);
   SIMCLR_CHECK_ARG(Cout % 8 == 0, "conv2d_fwd_bn_apply: Cout=%d must be a multiple of 8", Cout);
   SIMCLR_CHECK_ARG(x && w_t && y && scale && shift, "conv2d_fwd_bn_apply: null argument");
+  SIMCLR_CHECK_ARG((rscale == nullptr) == (rshift == nullptr) && (!rscale || res), "conv2d_fwd_bn_apply: rscale / rshift come together and need res");
   SIMCLR_CHECK_ARG(V > 0 && OH > 0 && OW > 0 && stride >= 1, "conv2d_fwd_bn_apply: bad geometry");
   SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd_bn_apply: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd_bn_apply: at most 9 taps (got %dx%d)", KH, KW);
@@ -2312,6 +2317,7 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
   p.M = V * OH * OW; p.K = KH * KW * Cin;
   p.fapply = 1; p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
+  p.bn_mean = rscale; p.bn_rstd = rshift;
   launch_igemm<uint16_t, MODE_FWD>(p, stream);
   SIMCLR_CHECK_LAUNCH();
   return 0;

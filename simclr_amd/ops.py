@@ -204,7 +204,8 @@ def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None, store=
     return out
 
 
-def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=None, relu=True, want_bits=False):
+def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=None, relu=True, want_bits=False,
+                        rscale=None, rshift=None):
     """y = act(bf16(conv(x)) * scale + shift + res) in ONE kernel (bf16): what conv2d_fwd + bn_apply produce, bit for
     bit, without the convolution output travelling to memory.  Returns y or (y, relu_bits)."""
     V, IH, IW, Cin = x.shape
@@ -215,7 +216,8 @@ def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=N
     bits = torch.empty(M, Cout // 8, device=x.device, dtype=torch.uint8) if want_bits else None
     nb = 2 * (V * IH * IW * Cin + M * Cout * (2 if res is not None else 1) + K * Cout) + (M * Cout // 8 if want_bits else 0)
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, nb,
-            lambda: lib().conv2d_fwd_bn_apply(_p(x), _p(w_t), _p(y), _p(scale), _p(shift), _p(res), int(relu), _p(bits), V,
+            lambda: lib().conv2d_fwd_bn_apply(_p(x), _p(w_t), _p(y), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift),
+                                              int(relu), _p(bits), V,
                                               IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
     return (y, bits) if want_bits else y
 
@@ -655,6 +657,16 @@ def conv2d_gram(h):
     _launch('conv_wgrad', 2.0 * M * K * K, esz * M * K + 4 * K * K,
             lambda: lib().conv2d_gram(_p(h), _p(out), _p(ws), M, K, dt(h), _s()))
     return out[:K * K].view(K, K), out[K * K:]
+
+
+def bn_sums_from_gram(gw, w_kn, cs):
+    """(sum c, sum c^2) per output channel of c = h W from GW = (h^T h) W [K, N], W [K, N] fp32 and colsum(h) -> fp64 [2, N]."""
+    K, N = gw.shape
+    assert tuple(w_kn.shape) == (K, N) and gw.dtype == torch.float32 and w_kn.dtype == torch.float32
+    sums = torch.empty(2, N, device=gw.device, dtype=torch.float64)
+    c64, c32 = (_p(cs), None) if cs.dtype == torch.float64 else (None, _p(cs))
+    lib().bn_sums_from_gram(_p(gw), _p(w_kn), c64, c32, K, N, _p(sums), _s())
+    return sums
 
 
 def gram_supported(K, dtype):

@@ -119,12 +119,14 @@ def pad64(c):
 class Act:
     """An activation tensor plus (optionally) the fused per-channel statistics partials.  `c` is the
     logical channel count when the tensor carries zero-padded channels (t.shape[-1] = pad64(c))."""
-    __slots__ = ('t', 'stats', 'c', 'shape')
+    __slots__ = ('t', 'stats', 'c', 'shape', 'sums')
 
-    def __init__(self, t, stats=None, c=None, shape=None):
-        # t is None for a statistics-only convolution pass (the tensor is never materialised): shape tells its geometry
+    def __init__(self, t, stats=None, c=None, shape=None, sums=None):
+        # t is None for a statistics-only convolution pass (the tensor is never materialised): shape tells its geometry;
+        # sums: this replica's [2, C] fp64 (sum, sum of squares) when the statistics did not come as partial slots
         self.t = t
         self.stats = stats
+        self.sums = sums
         self.shape = tuple(t.shape) if t is not None else tuple(shape)
         self.c = self.shape[-1] if c is None else c
 
@@ -234,7 +236,7 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         g, b = self._pg, self._pb
         rows = math.prod(inputs.shape[:-1])
         if training:
-            if inputs.stats is None:
+            if inputs.stats is None and sums is None:
                 raise NotImplementedError('BatchNormRelu input must come from a conv/dense epilogue')
             if sums is not None:
                 count = rows * num_replicas(RT.strategy)
@@ -343,10 +345,19 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         return dx, dmasked
 
 
-def _conv3_fused_enabled():
-    """SIMCLR_CONV3_FUSED=0: the tail of an identity bottleneck block runs as conv3 -> HBM -> bn_apply again."""
+def _conv3_fused_level():
+    """SIMCLR_CONV3_FUSED: 0 = every bottleneck tail runs as conv3 -> HBM -> bn_apply; 1 (default) = identity blocks use the
+    fused two-pass forward; 2 = projection blocks too (measured slower, profiles/r02_notes.md)."""
     import os
-    return os.environ.get('SIMCLR_CONV3_FUSED', '1') not in ('', '0')
+    v = os.environ.get('SIMCLR_CONV3_FUSED', '1')
+    return int(v) if v.isdigit() else 1
+
+
+def _conv3_stats_from_gram():
+    """SIMCLR_CONV3_STATS=conv: the statistics pass of the fused tail is a store-free run of the convolution (bitwise the
+    statistics of the unfused path); default: from the Gram matrix of conv3's input (shared with the backward)."""
+    import os
+    return os.environ.get('SIMCLR_CONV3_STATS', 'gram') != 'conv'
 
 
 def _sync_bn():
@@ -357,9 +368,10 @@ def prepare_many(items, training):
     """items: [(BatchNormRelu, Act)] whose inputs do not depend on each other (a projection shortcut's BN and bn1 of
     the same block).  Cross-replica statistics (tf2/resnet.py:50-60) of all of them travel in ONE all-reduce.
     Returns [(scale, shift)] and leaves each result cached on its layer for the following __call__ / prepare."""
-    sums = [None] * len(items)
+    sums = [a.sums if training else None for _, a in items]
     if training and _sync_bn():
-        sums = RT.strategy.all_reduce_sum_many([ops.bn_reduce_slots(a.stats) for _, a in items])
+        sums = RT.strategy.all_reduce_sum_many([a.sums.clone() if a.sums is not None else ops.bn_reduce_slots(a.stats)
+                                                for _, a in items])
     out = []
     for (bn, a), sm in zip(items, sums):
         scale, shift = bn._prepare_with(a, training, sm)
@@ -485,7 +497,30 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         self.saved = dict(x=x, H=H, W=W, pad=pad)
         return Act(None, stats, c=self.filters, shape=(V, OH, OW, self.cout_p))
 
-    def forward_bn_apply(self, inputs, scale, shift, res=None, relu=True, want_bits=False):
+    def forward_gram_stats(self, inputs):
+        """Statistics of this 1x1 convolution's output from the Gram matrix of its INPUT (csrc/bn.hip bn_sums_from_gram):
+        one pass over the input, 4x narrower than the output, and h^T h, colsum(h), (h^T h) W are exactly what the folded
+        BatchNorm backward of this layer needs -- kept in self.saved['gram'] so that the backward does not stream the
+        input again."""
+        assert self.kernel_size == 1 and self.strides == 1
+        x = inputs.t
+        V, H, W, cin_p = x.shape
+        if self.kernel is None:
+            self.build(inputs.c, cin_p)
+        self._refresh()
+        K = cin_p
+        if ops.gram_supported(K, x.dtype):
+            g, cs = ops.conv2d_gram(x)
+        else:
+            g = ops.conv2d_wgrad(x, x, 1, 1, 1, 0)
+            cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(x, x, None, None, None, RT.const(K, 0.0), RT.const(K, 1.0), 0))
+        w_d32, w_t32 = self._f32_copies()
+        gw = ops.small_gemm_nt(g, w_t32)                       # (h^T h) W   [K, N]
+        sums = ops.bn_sums_from_gram(gw, w_d32, cs)
+        self.saved = dict(x=x, H=H, W=W, pad=0, gram=(g, cs, gw), gram_version=self._version)
+        return Act(None, None, c=self.filters, shape=(V, H, W, self.cout_p), sums=sums)
+
+    def forward_bn_apply(self, inputs, scale, shift, res=None, relu=True, want_bits=False, res_bn=None):
         """Second half: the convolution again, with y = act(bn(conv) + res) applied in its epilogue."""
         k, s = self.kernel_size, self.strides
         x = inputs.t
@@ -493,8 +528,9 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         pad = (k - 1) // 2
         OH = (H + (k - 1) - k) // s + 1
         OW = (W + (k - 1) - k) // s + 1
+        rs, rb = res_bn if res_bn is not None else (None, None)
         return ops.conv2d_fwd_bn_apply(x, self.w_t, k, k, s, pad, OH, OW, scale, shift, res=res, relu=relu,
-                                       want_bits=want_bits)
+                                       want_bits=want_bits, rscale=rs, rshift=rb)
 
     def backward_folded(self, dm, bn_out, partial, fuse_bn, s2_from_gemm=False, dx_out=None, accumulate=False):
         """1x1 stride-1 conv whose output c = h W goes through `bn_out` (BatchNorm, no ReLU before the add): the BN backward
@@ -521,12 +557,15 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         q = ops.small_gemm_nt(wb, w_d32)                                                        # (W*b) W^T   [K, K]
         if self.kernel.trainable:
             with _wgrad_side_stream(h, dm):
-                if ops.gram_supported(K, h.dtype):
-                    g, cs = ops.conv2d_gram(h)                                                  # h^T h, colsum(h): ONE pass over h
+                if sv.get('gram') is not None and sv.get('gram_version') == self._version:
+                    g, cs, gw = sv['gram']                  # the forward's statistics pass already produced all three
                 else:
-                    g = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)
-                    cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, RT.const(K, 0.0), RT.const(K, 1.0), 0))
-                gw = ops.small_gemm_nt(g, w_t32)                                                # (h^T h) W   [K, N]
+                    if ops.gram_supported(K, h.dtype):
+                        g, cs = ops.conv2d_gram(h)                                              # h^T h, colsum(h): ONE pass over h
+                    else:
+                        g = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)
+                        cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, RT.const(K, 0.0), RT.const(K, 1.0), 0))
+                    gw = ops.small_gemm_nt(g, w_t32)                                            # (h^T h) W   [K, N]
                 ops.bn_fold_post(t1, gw, cs, a, b, d, q, self.kernel.ensure_grad().view(K, N), wext)
         else:
             z = torch.zeros(K, N, device=h.device)
@@ -840,12 +879,13 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
             h = self.bn2(self.conv2(h, training), training)
         self.fused_tail = self._fused_tail(training, sc_bn, h)
         if self.fused_tail:
-            # conv3's output is 4x wider than its input and only feeds bn3: compute it twice instead of storing it.
-            # Pass 1 produces the statistics, pass 2 applies relu(bn3(.) + shortcut) in the epilogue; the backward of this
-            # block never reads conv3's output either (folded BatchNorm backward, sum(dm*x^) from the weight-gradient GEMM).
-            st = self.conv3.forward_stats_only(h)
+            # conv3's output is 4x wider than its input and only feeds bn3: it is never stored.  Its BatchNorm statistics
+            # come from the Gram matrix of conv3's input (or a store-free run of the convolution), then the convolution runs
+            # with relu(bn3(.) + shortcut) applied in its epilogue; the backward of this block never reads conv3's output
+            # either (folded BatchNorm backward, sum(dm*x^) from the weight-gradient GEMM).
+            st = self.conv3.forward_gram_stats(h) if _conv3_stats_from_gram() else self.conv3.forward_stats_only(h)
             scale, shift = self.bn3.prepare(st, training)
-            y, bits = self.conv3.forward_bn_apply(h, scale, shift, res=sc, relu=True, want_bits=True)
+            y, bits = self.conv3.forward_bn_apply(h, scale, shift, res=sc, relu=True, want_bits=True, res_bn=sc_bn)
             self.bn3.relu_bits = bits
             self.bn3.saved['y'] = y
             self.bn3.saved['masked'] = True
@@ -860,11 +900,12 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         return self.sk is None and not self.conv3.padded and _bn_fold_enabled()
 
     def _fused_tail(self, training, sc_bn, h):
-        # identity blocks whose tail BatchNorm backward will arrive folded (every block but the network's last one)
+        # blocks whose tail BatchNorm backward will arrive folded (every block but the network's last one)
         if self.conv3.kernel is None:
             self.conv3.build(h.c, h.t.shape[-1])
-        return (training and sc_bn is None and self.shortcut is None and not getattr(self, 'is_final', False)
-                and RT.dtype == torch.bfloat16 and self._foldable() and _bn_s2_enabled() and _conv3_fused_enabled())
+        level = _conv3_fused_level()
+        return (training and not getattr(self, 'is_final', False) and RT.dtype == torch.bfloat16
+                and self._foldable() and _bn_s2_enabled() and (level >= 2 or (level == 1 and sc_bn is None)))
 
     def tail_info(self):
         # foldable tail: the consumer's dgrad epilogue only masks and sums dm (no read of this block's conv3 output)

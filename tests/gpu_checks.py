@@ -1088,7 +1088,7 @@ def check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f3
 
 
 def check_step_determinism(depth=18, image_size=32, batch=16, compute_dtype='bf16', steps=2, num_classes=10, seed=0,
-                           env_second=None):
+                           env_second=None, env_both=None):
     """Two fresh models, same weights, same batches: every weight, BN moving statistic and LARS momentum must be
     BIT-IDENTICAL after `steps` steps (the reference's step is deterministic on TPU, tf2/resnet.py:54-60)."""
     from simclr_amd import model as model_lib
@@ -1105,8 +1105,11 @@ def check_step_determinism(depth=18, image_size=32, batch=16, compute_dtype='bf1
         # env_second: environment switches applied to the SECOND run only -- an optimisation that claims to be bitwise
         # neutral (e.g. SIMCLR_CONV3_FUSED=0 vs the default fused conv3 + bn3 forward) must leave every weight identical
         saved_env = {}
+        envs = dict(env_both or {})
         if run == 1 and env_second:
-            for k_, v_ in env_second.items():
+            envs.update(env_second)
+        if envs:
+            for k_, v_ in envs.items():
                 saved_env[k_] = os.environ.get(k_)
                 os.environ[k_] = v_
         FLAGS.reset()
@@ -1309,7 +1312,7 @@ def check_small_gemm(M, N, K, seed=0):
     return [dict(name='small_gemm_nt_f32 %dx%dx%d' % (M, N, K), err=err, tol=tol, scale=scale, ok=bool(err <= tol), nbad=0, numel=M * N)]
 
 
-def check_conv_fwd_bn_apply(V, H, Cin, Cout, k=1, stride=1, with_res=True, relu=True, seed=0):
+def check_conv_fwd_bn_apply(V, H, Cin, Cout, k=1, stride=1, with_res=True, relu=True, seed=0, res_bn=False):
     """simclr_conv2d_fwd(y = NULL) + simclr_conv2d_fwd_bn_apply (the conv3 -> bn3 -> + shortcut -> relu tail of
     tf2/resnet.py:470-487 in two passes over the convolution, its output never stored) against the three-kernel path
     conv2d_fwd -> bn_finalize -> bn_apply: statistics, output and ReLU bit mask must be BIT-IDENTICAL."""
@@ -1329,16 +1332,20 @@ def check_conv_fwd_bn_apply(V, H, Cin, Cout, k=1, stride=1, with_res=True, relu=
     c = ops.conv2d_fwd(x, w_t, k, k, stride, pad, OH, OH, stats=st_a)
     mm, mv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
     mean, rstd, scale, shift = ops.bn_finalize(None, M, gamma, beta, mm, mv, 0.9, partial=st_a)
-    y_ref, bits_ref = ops.bn_apply(c, scale, shift, relu, res=res, want_bits=True) if relu else (ops.bn_apply(c, scale, shift, relu, res=res), None)
+    rs = (torch.rand(Cout, device=DEV, generator=g) + 0.5) if res_bn else None
+    rb = (0.3 * torch.randn(Cout, device=DEV, generator=g)) if res_bn else None
+    y_ref, bits_ref = (ops.bn_apply(c, scale, shift, relu, res=res, rscale=rs, rshift=rb, want_bits=True) if relu
+                       else (ops.bn_apply(c, scale, shift, relu, res=res, rscale=rs, rshift=rb), None))
     # fused path
     st_b = ops.conv_stats(M, Cout, DEV)
     ops.conv2d_fwd(x, w_t, k, k, stride, pad, OH, OH, stats=st_b, store=False)
     mm2, mv2 = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
     _, _, scale2, shift2 = ops.bn_finalize(None, M, gamma, beta, mm2, mv2, 0.9, partial=st_b)
-    out = ops.conv2d_fwd_bn_apply(x, w_t, k, k, stride, pad, OH, OH, scale2, shift2, res=res, relu=relu, want_bits=relu)
+    out = ops.conv2d_fwd_bn_apply(x, w_t, k, k, stride, pad, OH, OH, scale2, shift2, res=res, relu=relu, want_bits=relu,
+                                  rscale=rs, rshift=rb)
     y, bits = out if relu else (out, None)
     torch.cuda.synchronize()
-    tag = 'V%d %dx%d %d->%d k%d s%d res%d relu%d' % (V, H, H, Cin, Cout, k, stride, int(with_res), int(relu))
+    tag = 'V%d %dx%d %d->%d k%d s%d res%d relu%d resbn%d' % (V, H, H, Cin, Cout, k, stride, int(with_res), int(relu), int(res_bn))
 
     def same(name, a, b):
         ok = bool(torch.equal(a, b))
@@ -1349,10 +1356,53 @@ def check_conv_fwd_bn_apply(V, H, Cin, Cout, k=1, stride=1, with_res=True, relu=
     if relu:
         res_l.append(same('bits', bits_ref, bits))
     # and the output is right in the first place: float64 reference of relu(bn(conv) + res) from the bf16-rounded conv
-    ref = c.double() * scale.double() + shift.double() + (res.double() if with_res else 0.0)
+    rterm = 0.0
+    if with_res:
+        rterm = res.double() * rs.double() + rb.double() if res_bn else res.double()
+    ref = c.double() * scale.double() + shift.double() + rterm
     if relu:
         ref = ref.clamp_min(0.0)
     err = float((y.double() - ref).abs().max())
     sc_ = float(ref.abs().max())
     res_l.append(dict(name='fwd_bn_apply_value ' + tag, err=err, tol=2.0 ** -7 * sc_, scale=sc_, ok=bool(err <= 2.0 ** -7 * sc_), nbad=0, numel=y.numel()))
     return res_l
+
+
+def check_gram_stats(V, H, K, N, seed=0):
+    """BatchNorm statistics of c = h W from the Gram matrix of h (simclr_conv2d_gram -> simclr_small_gemm_nt_f32 ->
+    simclr_bn_sums_from_gram) against (a) float64 sums of the exact products and (b) the statistics the convolution
+    epilogue accumulates.  h is a post-ReLU-like activation (non-negative, mean ~ 0.6 sigma: the cancellation-prone case)."""
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    h = torch.relu(torch.randn(V, H, H, K, device=DEV, generator=g) + 0.3).to(dtype)
+    w = torch.randn(1, 1, K, N, device=DEV, generator=g) * K ** -0.5
+    w_t = ops.prep_weights(w, 0, dtype)                      # [N, K] bf16
+    w_d = ops.prep_weights(w, 1, dtype)                      # [K, N] bf16
+    M = V * H * H
+    if ops.gram_supported(K, dtype):
+        gm, cs = ops.conv2d_gram(h)
+    else:
+        gm = ops.conv2d_wgrad(h, h, 1, 1, 1, 0)
+        ones, zeros = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+        cs = ops.bn_reduce_slots(ops.bn_bwd_reduce(h, h, None, None, None, zeros, ones, 0))
+    gw = ops.small_gemm_nt(gm, w_t.float())
+    sums = ops.bn_sums_from_gram(gw, w_d.float(), cs)
+    st = ops.conv_stats(M, N, DEV)
+    ops.conv2d_fwd(h, w_t, 1, 1, 1, 0, H, H, stats=st)
+    sums_conv = ops.bn_reduce_slots(st)
+    torch.cuda.synchronize()
+    c64 = h.reshape(M, K).double() @ w_d.double()
+    ref = torch.stack([c64.sum(0), (c64 * c64).sum(0)])
+    mean_ref = ref[0] / M
+    var_ref = ref[1] / M - mean_ref ** 2
+    out = []
+    for name, sm in (('gram', sums), ('conv_epilogue', sums_conv)):
+        mean = sm[0] / M
+        var = sm[1] / M - mean ** 2
+        sd = var_ref.sqrt()
+        e_mean = float(((mean - mean_ref).abs() / sd).max())           # in units of the channel's standard deviation
+        e_var = float(((var - var_ref).abs() / var_ref).max())
+        tag = '%s V%d %dx%d %d->%d' % (name, V, H, H, K, N)
+        out.append(dict(name='bn_stats_mean ' + tag, err=e_mean, tol=2e-5, scale=1.0, ok=e_mean <= 2e-5, nbad=0, numel=N))
+        out.append(dict(name='bn_stats_var ' + tag, err=e_var, tol=1e-4, scale=1.0, ok=e_var <= 1e-4, nbad=0, numel=N))
+    return out

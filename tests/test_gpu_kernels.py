@@ -405,6 +405,13 @@ def test_small_gemm_nt_f32(M, N, K):
     _assert(gc.check_small_gemm(M, N, K))
 
 
+def test_conv_fwd_bn_apply_projection_shortcut_bitwise():
+    """The residual carries its own BatchNorm (projection shortcut, bn_apply RES = 2)."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_conv_fwd_bn_apply(64, 56, 64, 256, 1, 1, True, True, res_bn=True))
+    _assert(gc.check_conv_fwd_bn_apply(33, 14, 256, 1024, 1, 1, True, True, res_bn=True))
+
+
 @pytest.mark.parametrize('V,H,Cin,Cout,k,stride,with_res,relu', [
     (64, 56, 64, 256, 1, 1, True, True),       # group-1 tail
     (1024, 7, 512, 2048, 1, 1, True, True),    # group-4 tail: 16 N-tiles
@@ -420,8 +427,17 @@ def test_conv_fwd_bn_apply_bitwise(V, H, Cin, Cout, k, stride, with_res, relu):
 
 
 def test_train_step_fused_conv3_is_bitwise_neutral():
-    """ResNet-50 bf16: two steps with the fused conv3 + bn3 forward (default) and with SIMCLR_CONV3_FUSED=0 end in
-    bit-identical weights, BatchNorm statistics and LARS momenta."""
+    """ResNet-50 bf16: two steps with the fused conv3 + bn3 forward (statistics from a store-free convolution pass, so that
+    they are bitwise those of the unfused path) and with SIMCLR_CONV3_FUSED=0 end in bit-identical weights, BatchNorm
+    statistics and LARS momenta."""
     from tests import gpu_checks as gc
     _assert(gc.check_step_determinism(depth=50, image_size=64, batch=8, compute_dtype='bf16', steps=2,
-                                      env_second={'SIMCLR_CONV3_FUSED': '0'}))
+                                      env_second={'SIMCLR_CONV3_FUSED': '0'}, env_both={'SIMCLR_CONV3_STATS': 'conv'}))
+
+
+@pytest.mark.parametrize('V,H,K,N', [(256, 56, 64, 256), (256, 28, 128, 512), (512, 14, 256, 1024), (1024, 7, 512, 2048)])
+def test_bn_statistics_from_gram_matrix(V, H, K, N):
+    """Default statistics path of the fused tail: mean to 2e-5 standard deviations, variance to 1e-4 relative, the same
+    gates the convolution-epilogue statistics meet."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_gram_stats(V, H, K, N))

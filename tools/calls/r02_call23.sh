@@ -1,0 +1,24 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r02_call23
+mkdir -p "$OUT"
+cd "$R"
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "fwd_bn_apply or fused_conv3 or gram or deterministic or folded or resnet50_f32_reference or resnet18" > "$OUT/pytest.log" 2>&1
+tail -3 "$OUT/pytest.log" | cut -c1-250; grep -n "Error\|FAILED" "$OUT/pytest.log" | head | cut -c1-300
+B="python bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_f32 --prof_steps 0"
+for v in a b; do
+timeout 200 $B > "$OUT/bench_gram_$v.json" 2> "$OUT/bench.err"
+SIMCLR_CONV3_STATS=conv timeout 200 $B > "$OUT/bench_conv_$v.json" 2> "$OUT/bench_off.err"
+SIMCLR_CONV3_FUSED=0 timeout 200 $B > "$OUT/bench_off_$v.json" 2> "$OUT/bench_off.err"
+done
+for f in gram_a conv_a off_a gram_b conv_b off_b; do
+python - "$OUT/bench_$f.json" $f <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1])); print(sys.argv[2], d['value'], d['ms_per_step'], d['step_ms'], d['train_metrics']['train/total_loss'])
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+done
+tail -5 "$OUT/bench.err"
