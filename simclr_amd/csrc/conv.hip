@@ -761,16 +761,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       // 1) barrier (every wave is done reading it)  2) accumulators -> bf16 C tile (8-byte granules,
       // XOR-swizzled by row)  3) barrier  4) row-wise pass: 16-byte coalesced loads of the BN input /
       // mask / previous value, ReLU mask, per-channel sums, 16-byte coalesced stores.
-      if (STATS && !BNEPI && Y == nullptr) {
-        // statistics-only pass (first half of the fused conv + BatchNorm-apply forward): nothing is staged or stored
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
-        continue;
-      }
       const int cst = (buf == 0) ? STAGES - 1 : buf - 1;
       unsigned char* Cs = WIN ? smem : (unsigned char*)(As + cst * STG);
       __syncthreads();
@@ -802,7 +792,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
 #pragma unroll
       for (int i = 0; i < ER; ++i) {
         const long long off = rowoff[tid / CPR + i * RPP];
-        erok[i] = off >= 0 && ncol < p.N;
+        erok[i] = off >= 0 && ncol < p.N && Y != nullptr;     // y == NULL: statistics-only pass, nothing is stored
         eoff[i] = erok[i] ? off + ncol : 0;       // masked rows read (and ignore) element 0
       }
       long long eld[ER];
