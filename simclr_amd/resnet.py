@@ -347,7 +347,7 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
 
 def _conv3_fused_level():
     """SIMCLR_CONV3_FUSED: 0 = every bottleneck tail runs as conv3 -> HBM -> bn_apply; 1 (default) = identity blocks use the
-    fused two-pass forward; 2 = projection blocks too (measured slower, profiles/r02_notes.md)."""
+    fused forward; 2 = projection blocks too (no consistent gain: -0.2 ms in one run, +0.7 ms in another, profiles/r02_notes.md)."""
     import os
     v = os.environ.get('SIMCLR_CONV3_FUSED', '1')
     return int(v) if v.isdigit() else 1
