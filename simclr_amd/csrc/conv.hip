@@ -865,22 +865,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           for (int e = 0; e < 8; ++e) v[e] += o[e];
         }
         if (BNEPI) {
-          float xf[8], mk[8];
-          chunk_to_f32<uint16_t>(e_xv[i], xf);
-          if (p.bn_mode == 1) {
-            chunk_to_f32<uint16_t>(e_mv[i], mk);
-          } else if (p.bn_mode >= 3) {
+          // This pass is VALU-bound (profiles/r02_notes.md), so it accumulates the RAW moment sum(dm * x) -- one fma per
+          // element -- and the flush turns it into sum(dm * x^) = rstd * (sum(dm * x) - mean * sum(dm)) once per
+          // workgroup; mode 4 (sums only) touches neither x nor the second moment.
+          if (p.bn_mode == 4) {
+            const unsigned mb = e_mv[i][0];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mk[e] = ((e_mv[i][0] >> e) & 1u) ? 1.f : 0.f;
+            for (int e = 0; e < 8; ++e) {
+              v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
+              e_s[e] += v[e];
+            }
           } else {
+            float xf[8];
+            chunk_to_f32<uint16_t>(e_xv[i], xf);
+            if (p.bn_mode == 1) {
+              float mk[8];
+              chunk_to_f32<uint16_t>(e_mv[i], mk);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mk[e] = fmaf(xf[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
-          }
+              for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            } else if (p.bn_mode == 3) {
+              const unsigned mb = e_mv[i][0];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[e] = mk[e] > 0.f ? v[e] : 0.f;
-            e_s[e] += v[e];
-            e_q[e] += v[e] * (xf[e] - bnp[2 * BN + e_cc * 8 + e]) * bnp[3 * BN + e_cc * 8 + e];
+              for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                v[e] = fmaf(xf[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]) > 0.f ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              e_s[e] += v[e];
+              e_q[e] = fmaf(v[e], xf[e], e_q[e]);
+            }
           }
         }
         if (DIAG(16)) continue;
@@ -987,6 +1003,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     if (tid < BN && n0 + tid < p.N && (count > 0 || own_slot)) {
       float s1 = 0.f, s2 = 0.f;
       for (int w = 0; w < RPP; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+      s2 = (s2 - bnp[2 * BN + tid] * s1) * bnp[3 * BN + tid];     // raw moment -> sum(dm * x^)  (mode 4: s2 = 0, mean = rstd = 0)
       float* st = p.stats + (long long)(own_slot ? mslot : mslot % p.nslot) * 2 * p.N;
       if (own_slot) { st[n0 + tid] = s1; st[p.N + n0 + tid] = s2; }
       else { atomicAdd(st + n0 + tid, s1); atomicAdd(st + p.N + n0 + tid, s2); }

@@ -86,7 +86,26 @@ def l2norm_bwd(z, inv, dz):
     return dx
 
 
+_NTXENT_DIMS = (64, 128, 256)       # embedding widths the fused kernels are instantiated for
+
+
+def _ntxent_dim(D):
+    """Kernel width for a `proj_out_dim` of D (a free flag in the reference, tf2/run.py:196): the next instantiated width.
+    Zero columns change neither the dot products nor the norms, so other widths run zero-padded."""
+    for d in _NTXENT_DIMS:
+        if D <= d:
+            return d
+    raise ValueError('NT-Xent kernels support proj_out_dim <= %d (got %d)' % (_NTXENT_DIMS[-1], D))
+
+
+def _ntxent_pad(z):
+    D = z.shape[1]
+    Dk = _ntxent_dim(D)
+    return z if Dk == D else torch.nn.functional.pad(z, (0, Dk - D))
+
+
 def ntxent_workspace(n, N, D, device):
+    D = _ntxent_dim(D)
     nbytes = lib().ntxent_workspace_bytes(n, N, D)
     return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
 
@@ -95,6 +114,8 @@ def ntxent_fwd(z_local, z_all, rank, temperature, ws=None):
     n, D = z_local.shape[0] // 2, z_local.shape[1]
     N = z_all.shape[0] // 2
     assert z_local.dtype == torch.float32 and z_all.dtype == torch.float32
+    z_local, z_all = _ntxent_pad(z_local), _ntxent_pad(z_all)
+    D = z_local.shape[1]
     if ws is None:
         ws = ntxent_workspace(n, N, D, z_local.device)
     out = torch.zeros(4, device=z_local.device, dtype=torch.float32)
@@ -106,18 +127,23 @@ def ntxent_fwd(z_local, z_all, rank, temperature, ws=None):
 
 
 def ntxent_bwd(z_local, z_all, rank, temperature, row_stats, grad_scale, out, ws):
-    n, D = z_local.shape[0] // 2, z_local.shape[1]
+    n, D0 = z_local.shape[0] // 2, z_local.shape[1]
     N = z_all.shape[0] // 2
+    z_local, z_all = _ntxent_pad(z_local), _ntxent_pad(z_all)
+    D = z_local.shape[1]
     dz_local = torch.empty_like(z_local)
     dz_all = torch.empty_like(z_all)
     # bytes: the fused forward+backward I/O of SURVEY 8(d): read h_local + h_all, write dH_local + dH_all
     _launch('ntxent_bwd', 16.0 * n * N * D, 2.0 * (2 * n + 2 * N) * D * 4,
             lambda: lib().ntxent_bwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(row_stats),
                                      float(grad_scale), _p(dz_local), _p(dz_all), _p(out), _p(ws), _s()))
+    if D != D0:
+        dz_local, dz_all = dz_local[:, :D0].contiguous(), dz_all[:, :D0].contiguous()
     return dz_local, dz_all
 
 
 def ntxent_logits_ab(z_local, z_all, temperature):
+    z_local, z_all = _ntxent_pad(z_local), _ntxent_pad(z_all)
     n, D = z_local.shape[0] // 2, z_local.shape[1]
     N = z_all.shape[0] // 2
     out = torch.empty(n, N, device=z_local.device, dtype=torch.float32)

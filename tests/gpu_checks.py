@@ -496,7 +496,8 @@ def check_avgpool2(V, H, C, stride, dtype, seed=0):
 
 
 def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_classes=10, seed=0,
-                     weight_decay=1e-4, lr=0.1, steps=1, randomize_bn=True, sk_ratio=0.0, width_multiplier=1):
+                     weight_decay=1e-4, lr=0.1, steps=1, randomize_bn=True, sk_ratio=0.0, width_multiplier=1,
+                     proj_out_dim=128):
     """Full pretraining steps: HIP path vs the torch-CPU oracle restating tf2/run.py:557-622 on
     identical weights and inputs.
 
@@ -516,14 +517,14 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
 
     CAL = 6.0     # our fp32 kernels vs float64 may deviate a few times more than torch-CPU fp32 does (different fusion / summation order)
     cfg = Config(resnet_depth=depth, image_size=image_size, num_classes=num_classes, weight_decay=weight_decay,
-                 sk_ratio=sk_ratio, width_multiplier=width_multiplier)
+                 sk_ratio=sk_ratio, width_multiplier=width_multiplier, proj_out_dim=proj_out_dim)
     params, state = init_model(cfg, seed=seed, randomize_bn=randomize_bn)
     momenta = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
     g = torch.Generator().manual_seed(seed + 1)
     FLAGS.reset()
     FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype=compute_dtype, use_blur=False,
                  weight_decay=weight_decay, train_batch_size=batch, sk_ratio=sk_ratio,
-                 width_multiplier=width_multiplier)
+                 width_multiplier=width_multiplier, proj_out_dim=proj_out_dim)
     RT.reset()
     RT.device = torch.device(DEV)
     model = model_lib.Model(num_classes)

@@ -31,7 +31,8 @@ def test_ntxent_closed_forms():
 
 
 @pytest.mark.parametrize('n,R,D,rank', [(64, 1, 128, 0), (96, 1, 64, 0), (32, 4, 128, 2), (512, 1, 128, 0),
-                                        (64, 2, 256, 1), (100, 1, 128, 0), (512, 8, 128, 5)])
+                                        (64, 2, 256, 1), (100, 1, 128, 0), (512, 8, 128, 5),
+                                        (64, 1, 96, 0), (48, 2, 200, 1), (40, 1, 16, 0)])   # widths that run zero-padded
 def test_ntxent_vs_oracle(n, R, D, rank):
     from tests import gpu_checks as gc
     _assert(gc.check_ntxent(n, R, D=D, rank=rank))
@@ -441,3 +442,10 @@ def test_bn_statistics_from_gram_matrix(V, H, K, N):
     gates the convolution-epilogue statistics meet."""
     from tests import gpu_checks as gc
     _assert(gc.check_gram_stats(V, H, K, N))
+
+
+def test_train_step_free_proj_out_dim():
+    """`proj_out_dim` is a free flag in the reference (tf2/run.py:196): a width the NT-Xent kernels are not instantiated
+    for runs zero-padded and must give the oracle's step (ResNet-18, 32 px, fp32)."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_train_step(depth=18, image_size=32, batch=16, compute_dtype='f32', proj_out_dim=96))
