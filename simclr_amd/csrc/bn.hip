@@ -72,21 +72,32 @@ __global__ __launch_bounds__(kSlotThreads) void bn_reduce_slots(const float* __r
 //   sum_m c[m][n]^2 = w_n^T (h^T h) w_n = sum_k GW[k][n] W[k][n],   GW = (h^T h) W
 // (h^T h and colsum(h) come from one pass over h, simclr_conv2d_gram -- the same two quantities the folded BatchNorm
 // backward needs, so the forward's statistics pass and the backward's Gram pass are ONE pass).  fp64 accumulation,
-// k ascending: deterministic.  One thread per channel, coalesced rows.
+// fixed summation order: deterministic.
 __global__ __launch_bounds__(256) void bn_sums_from_gram(const float* __restrict__ gw, const float* __restrict__ w,
                                                          const double* __restrict__ cs64, const float* __restrict__ cs32,
                                                          int K, int N, double* __restrict__ sums) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  // 32 channels x 8 k-lanes per workgroup: lane l adds rows l, l+8, ... (ascending), the 8 lane sums are added in lane order
+  __shared__ double sh[2][8][32];
+  const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < K; ++k) {
-    const double wv = (double)w[(long long)k * N + n];
-    a += (cs64 ? cs64[k] : (double)cs32[k]) * wv;
-    b += (double)gw[(long long)k * N + n] * wv;
+  if (n < N) {
+#pragma unroll 4
+    for (int k = kl; k < K; k += 8) {
+      const double wv = (double)w[(long long)k * N + n];
+      a += (cs64 ? cs64[k] : (double)cs32[k]) * wv;
+      b += (double)gw[(long long)k * N + n] * wv;
+    }
   }
-  sums[n] = a;
-  sums[N + n] = b;
+  sh[0][kl][cl] = a;
+  sh[1][kl][cl] = b;
+  __syncthreads();
+  if (kl == 0 && n < N) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) { a += sh[0][l][cl]; b += sh[1][l][cl]; }
+    sums[n] = a;
+    sums[N + n] = b;
+  }
 }
 
 // From global sums -> mean/rstd/scale/shift, moving-stat update.  If `partial` is given (single
@@ -473,7 +484,7 @@ int simclr_bn_sums_from_gram(const float* gw, const float* w_kn, const double* c
                              double* sums, hipStream_t stream) {
   SIMCLR_CHECK_ARG(gw && w_kn && sums && ((cs64 != nullptr) != (cs32 != nullptr)) && K > 0 && N > 0,
                    "bn_sums_from_gram: bad arguments (exactly one of cs64 / cs32)");
-  hipLaunchKernelGGL(bn_sums_from_gram, dim3(ceil_div(N, 256)), dim3(256), 0, stream, gw, w_kn, cs64, cs32, K, N, sums);
+  hipLaunchKernelGGL(bn_sums_from_gram, dim3(ceil_div(N, 32)), dim3(256), 0, stream, gw, w_kn, cs64, cs32, K, N, sums);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

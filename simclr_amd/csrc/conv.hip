@@ -1916,10 +1916,14 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
   T* __restrict__ Y = (T*)p.y;
   const int row_elems = p.KWP * 4;             // elements per kernel row
   const int ksteps = p.KP / KSTEP;
-  // nslot >= gridDim.x: the workgroup keeps its channel sums in registers over all its tiles (ascending order) and
-  // stores them once into its own slot -> deterministic statistics; otherwise per-tile atomics into slot mt % nslot
-  const bool own_slot = STATS && p.nslot >= (int)gridDim.x;
-  float own_s = 0.f, own_ss = 0.f;
+  // The workgroup keeps its channel sums in registers over all its tiles (ascending order) and stores them once into its own
+  // slot (nslot >= gridDim.x: plain stores, deterministic statistics; fewer slots: one set of atomics per workgroup).
+  float st_s[4][4], st_q[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st_s[i][r] = 0.f; st_q[i][r] = 0.f; }
+  float* cst = red + 4 * BN * 2;               // bf16: [128][64] C staging tile (16 KB) behind the reduction scratch
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
     const int mw = mt * 128 + wave * 32;
     long long base[2];
@@ -1953,61 +1957,81 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
         for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = MMA<T>::run(bf, af[mi], acc[ni][mi]);
       }
     }
+    if (STATS) {       // per-lane partial sums over all tiles of this workgroup (tile order = ascending: deterministic)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + ni * 16 + g * 4;
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
+    }
+    if (sizeof(T) == 2) {
+      // bf16: stage the 128 x 64 tile in LDS (8-byte granules, XOR-swizzled by row) and store whole 128-byte rows,
+      // 16 bytes per lane -- the direct register stores were 8 bytes per lane in 32-byte row pieces
+      unsigned char* Cs = (unsigned char*)cst;
+      __syncthreads();                                  // the previous tile's row pass is done with the staging buffer
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const int m = mw + mi * 16 + fl;
-        if (m < p.M && n < p.N) {
-          T* dst = Y + (long long)m * p.N + n;
-          if (sizeof(T) == 4) {
-            *(float4*)dst = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
-          } else {
-            u32x2 pk;
-            pk[0] = pack_bf16x2(acc[ni][mi][0], acc[ni][mi][1]);
-            pk[1] = pack_bf16x2(acc[ni][mi][2], acc[ni][mi][3]);
-            *(u32x2*)dst = pk;
-          }
+        const int ml = wave * 32 + mi * 16 + fl;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int q = ni * 4 + g;                     // 8-byte granule (4 channels) in the row
+          u32x2 pk;
+          pk[0] = pack_bf16x2(acc[ni][mi][0], acc[ni][mi][1]);
+          pk[1] = pack_bf16x2(acc[ni][mi][2], acc[ni][mi][3]);
+          *(u32x2*)(Cs + ml * (BN * 2) + ((q ^ ((ml & 7) << 1)) << 3)) = pk;
         }
       }
-    }
-    if (STATS) {
+      __syncthreads();
+      const int cc = tid & 7;                           // 16-byte chunk (8 channels) of the row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 3) + i * 32;
+        const int m = mt * 128 + r;
+        if (m < p.M && n0 + cc * 8 < p.N)
+          *(u32x4*)((uint16_t*)Y + (long long)m * p.N + n0 + cc * 8) =
+              *(const u32x4*)(Cs + r * (BN * 2) + (((cc * 2) ^ ((r & 7) << 1)) << 3));
+      }
+    } else {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + ni * 16 + g * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s = 0.f, ss = 0.f;
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) { const float v = acc[ni][mi][r]; s += v; ss += v * v; }
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
-          if (fl == 0) {
-            const int nl = ni * 16 + g * 4 + r;
-            red[(wave * BN + nl) * 2] = s;
-            red[(wave * BN + nl) * 2 + 1] = ss;
-          }
+        for (int mi = 0; mi < 2; ++mi) {
+          const int m = mw + mi * 16 + fl;
+          if (m < p.M && n < p.N)
+            *(float4*)(Y + (long long)m * p.N + n) = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
         }
       }
-      __syncthreads();
-      if (tid < BN && n0 + tid < p.N) {
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { s += red[(w * BN + tid) * 2]; ss += red[(w * BN + tid) * 2 + 1]; }
-        if (own_slot) { own_s += s; own_ss += ss; }
-        else {
-          float* st = p.stats + (long long)(mt % p.nslot) * 2 * p.N;
-          atomicAdd(st + n0 + tid, s);
-          atomicAdd(st + p.N + n0 + tid, ss);
-        }
-      }
-      __syncthreads();
     }
   }
-  if (own_slot && tid < BN && n0 + tid < p.N) {
-    float* st = p.stats + (long long)blockIdx.x * 2 * p.N;
-    st[n0 + tid] = own_s;
-    st[p.N + n0 + tid] = own_ss;
+  if (STATS) {
+    // one flush per workgroup: lanes -> 16-lane groups -> waves (LDS) -> this workgroup's slot (or atomics into slot b % nslot)
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s_ = st_s[ni][r], ss = st_q[ni][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s_ += __shfl_xor(s_, o, 64); ss += __shfl_xor(ss, o, 64); }
+        if (fl == 0) {
+          const int nl = ni * 16 + g * 4 + r;
+          red[(wave * BN + nl) * 2] = s_;
+          red[(wave * BN + nl) * 2 + 1] = ss;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float s_ = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s_ += red[(w * BN + tid) * 2]; ss += red[(w * BN + tid) * 2 + 1]; }
+      const bool own_slot = p.nslot >= (int)gridDim.x;
+      float* st = p.stats + (long long)(own_slot ? blockIdx.x : blockIdx.x % p.nslot) * 2 * p.N;
+      if (own_slot) { st[n0 + tid] = s_; st[p.N + n0 + tid] = ss; }
+      else { atomicAdd(st + n0 + tid, s_); atomicAdd(st + p.N + n0 + tid, ss); }
+    }
   }
 }
 
@@ -2716,10 +2740,10 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
   p.stride = stride; p.M = V * OH * OW; p.KP = KHP * KWP * 4;
   SIMCLR_CHECK_ARG(p.KP % (4 * epc) == 0, "stem_conv_fwd: padded K=%d not a multiple of %d", p.KP, 4 * epc);
   SIMCLR_CHECK_ARG((KWP * 4) % epc == 0, "stem_conv_fwd: KWP*4 must be a multiple of %d", epc);
-  SIMCLR_CHECK_ARG(Cout % 4 == 0, "stem_conv_fwd: Cout %% 4 != 0");
+  SIMCLR_CHECK_ARG(Cout % (dtype == SIMCLR_DT_BF16 ? 8 : 4) == 0, "stem_conv_fwd: Cout=%d must be a multiple of %d", Cout, dtype == SIMCLR_DT_BF16 ? 8 : 4);
   p.m_tiles = ceil_div(p.M, 128);
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
-  const size_t lds = 64 * (p.KP * esz + 16) + 4 * 64 * 2 * sizeof(float);
+  const size_t lds = 64 * (p.KP * esz + 16) + 4 * 64 * 2 * sizeof(float) + (esz == 2 ? 128 * 64 * 2 : 0);
   dim3 grid(min(p.m_tiles, 2048), ceil_div(Cout, 64));
   if (dtype == SIMCLR_DT_BF16) {
     if (stats) hipLaunchKernelGGL((stem_conv_fwd<uint16_t, true>), grid, dim3(256), lds, stream, p);
