@@ -135,3 +135,81 @@ def test_two_replica_step_over_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip('needs >= 2 GPUs (the build session reaches one); the driver runs the multi-GPU bench')
     _run(2, 'nccl')
+
+
+def _worker_bf16_fused_tail(rank, world, port, q):
+    """Two replicas (gloo, both on cuda:0) of a ResNet-50 bf16 step -- the configuration the multi-GPU bench runs: fused
+    bottleneck tail with Gram-matrix statistics, folded BatchNorm backward, SyncBN sums all-reduced -- against THIS
+    library's single-replica step on the global batch (R replicas == 1 replica on the global batch)."""
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from simclr_amd import comm
+        from simclr_amd import model as model_lib
+        from simclr_amd.flags import FLAGS
+        from simclr_amd.resnet import RT
+        from simclr_amd.run import make_single_step
+
+        depth, image_size, b, num_classes, lr = 50, 64, 8, 10, 0.1
+        g = torch.Generator().manual_seed(11)
+        images = torch.rand(world * b, image_size, image_size, 6, generator=g)
+        labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (world * b,), generator=g), num_classes).float()
+
+        def run(strategy, feats, labs):
+            FLAGS.reset()
+            FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='bf16', use_blur=False,
+                         train_batch_size=world * b)
+            RT.reset()
+            RT.device = torch.device('cuda', 0)
+            RT.seed = 77                                     # identical initial weights in every run / rank
+            RT.strategy = strategy
+            model = model_lib.Model(num_classes)
+            opt = model_lib.build_optimizer(lr)
+            step = make_single_step(model, opt, strategy)
+            out = step(feats.cuda(), {'labels': labs.cuda()})
+            torch.cuda.synchronize()
+            fused = sum(1 for grp in model.resnet_model.block_groups for blk in grp.layers if getattr(blk, 'fused_tail', False))
+            grads = torch.cat([v.grad.reshape(-1).double().cpu() for v in model._flat_order])
+            return float(out['con_loss'].value.item()), grads, fused
+
+        strategy = comm.Strategy()
+        sl = slice(rank * b, (rank + 1) * b)
+        loss_r, grads_r, fused = run(strategy, images[sl], labels[sl])
+        lt = torch.tensor([loss_r], dtype=torch.float64)
+        dist.all_reduce(lt)
+        res = dict(fused_blocks=fused, stat_collectives=strategy.stat_collectives)
+        dist.barrier()
+        if rank == 0:
+            loss_1, grads_1, _ = run(None, images, labels)
+            res['loss_rel'] = abs(float(lt) / world - loss_1) / abs(loss_1)
+            res['grad_one_minus_cos'] = 1.0 - float(torch.dot(grads_r, grads_1) / (grads_r.norm() * grads_1.norm()))
+            res['grad_rel_l2'] = float((grads_r - grads_1).norm() / grads_1.norm())
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok', res))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, 'FAIL', traceback.format_exc()))
+
+
+def test_two_replica_bf16_resnet50_fused_tail_equals_single_replica():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16_fused_tail, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in res), res
+    for rank, _, m in res:
+        assert m['fused_blocks'] == 11, m                # the identity blocks of ResNet-50 minus the network's last block
+        if rank == 0:
+            # same arithmetic up to the summation order of the statistics (fp64 all-reduce of per-replica sums); bf16 storage
+            # rounding turns that into small, not bitwise-zero, differences
+            assert m['loss_rel'] < 2e-3, m
+            assert m['grad_one_minus_cos'] < 2e-3, m
+            assert m['grad_rel_l2'] < 6e-2, m
