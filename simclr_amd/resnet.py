@@ -346,11 +346,12 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
 
 
 def _conv3_fused_level():
-    """SIMCLR_CONV3_FUSED: 0 = every bottleneck tail runs as conv3 -> HBM -> bn_apply; 1 (default) = identity blocks use the
-    fused forward; 2 = projection blocks too (no consistent gain: -0.2 ms in one run, +0.7 ms in another, profiles/r02_notes.md)."""
+    """SIMCLR_CONV3_FUSED: 0 = every bottleneck tail runs as conv3 -> HBM -> bn_apply; 1 = identity blocks use the fused
+    forward; 2 (default) = projection blocks too (the shortcut's own BatchNorm is applied in the same epilogue): with the
+    Gram-matrix statistics 0.5-0.7 ms/step faster than 1 in three interleaved pairs (profiles/r02_notes.md)."""
     import os
-    v = os.environ.get('SIMCLR_CONV3_FUSED', '1')
-    return int(v) if v.isdigit() else 1
+    v = os.environ.get('SIMCLR_CONV3_FUSED', '2')
+    return int(v) if v.isdigit() else 2
 
 
 def _conv3_stats_from_gram():
@@ -435,7 +436,9 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         if stem_geo is not None:
             self.w_s = ops.prep_weights(w, 2, RT.dtype, stem_geo['KHP'], stem_geo['KWP'], cout_p=self.cout_p)
         else:
-            if _PREP_PER_LAYER or not any(r() is self for r in RT.convs):   # (built under an earlier RT.reset())
+            # first refresh of a layer (lazy build during the first forward) or a layer outside the registry (built under
+            # an earlier RT.reset()): its own launch; afterwards every version bump refreshes ALL layers with one launch
+            if _PREP_PER_LAYER or self._version < 0 or not any(r() is self for r in RT.convs):
                 self.w_t, self.w_d = ops.prep_weights_pair(w, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
             else:
                 RT.refresh_conv_weights()
