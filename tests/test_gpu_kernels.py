@@ -449,3 +449,19 @@ def test_train_step_free_proj_out_dim():
     for runs zero-padded and must give the oracle's step (ResNet-18, 32 px, fp32)."""
     from tests import gpu_checks as gc
     _assert(gc.check_train_step(depth=18, image_size=32, batch=16, compute_dtype='f32', proj_out_dim=96))
+
+
+def test_hand_derived_ntxent_swapped_views_on_device():
+    """The same paper-and-pencil case through the fused kernels (loss, contrast accuracy, contrast entropy)."""
+    import math
+    from simclr_amd import ops
+    n, D = 64, 64
+    e = torch.eye(n, D, device='cuda')
+    h = torch.cat([e, e[torch.arange(n, device='cuda') ^ 1]], 0).contiguous()
+    z, _ = ops.l2norm_fwd(h)
+    out, rs, ws = ops.ntxent_fwd(z, z, 0, 1.0)
+    ops.ntxent_bwd(z, z, 0, 1.0, rs, 1.0, out, ws)          # the entropy is accumulated in the backward sweep
+    o = out.cpu().double()
+    assert abs(float(o[0]) - 2 * math.log(2 * n - 2 + math.e)) < 1e-4
+    assert float(o[1]) == 0.0
+    assert abs(float(o[2]) - (math.log(n - 1 + math.e) - math.e / (n - 1 + math.e))) < 1e-4

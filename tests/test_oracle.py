@@ -280,3 +280,17 @@ def test_oracle_matches_tensorflow_reference():
         pytest.skip('tensorflow / absl / reference checkout not available here: oracle stays unpinned (DESIGN.md section 5)')
     ok, res = chk.run_all()
     assert ok, res
+
+
+def test_hand_derived_ntxent_swapped_views():
+    """tests/golden/HAND_DERIVED.md, last section: loss 2 log(2n-2+e), accuracy 0, entropy log(n-1+e) - e/(n-1+e)."""
+    import math
+    from oracle import ntxent as ont
+    n = 64
+    e = np.eye(n)
+    h = np.concatenate([e, e[np.arange(n) ^ 1]], 0)
+    loss, logits_ab, labels = ont.add_contrastive_loss(h, True, 1.0)
+    acc, ent = ont.contrastive_metrics(logits_ab, labels)
+    assert abs(float(loss) - 2 * math.log(2 * n - 2 + math.e)) < 1e-9
+    assert acc == 0.0
+    assert abs(ent - (math.log(n - 1 + math.e) - math.e / (n - 1 + math.e))) < 1e-6
