@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SIMCLR_HIP_LIB') or os.path.join(_HERE, 'libsimclr_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'simclr_hip.h')
 
+# bumped whenever an entry point's buffer-size contract or argument list changes (csrc/runtime.hip)
+ABI_VERSION = 3
+
 DT_F32 = 0
 DT_BF16 = 1
 
@@ -72,6 +75,10 @@ class _Lib:
             fn = getattr(self._dll, name)   # AttributeError if the symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
+        got = self._dll.simclr_abi_version()
+        if got != ABI_VERSION:
+            raise SimclrHipError('%s has ABI version %d, this package expects %d -- rebuild it (simclr_amd/csrc/build.sh)'
+                                 % (LIB_PATH, got, ABI_VERSION))
         self._int_fns = {n for n, (r, _) in self.signatures.items() if r is ctypes.c_int}
         self._no_check = {'simclr_abi_version', 'simclr_lars_chunk_elems', 'simclr_conv2d_stats_slots',
                           'simclr_stem_stats_slots', 'simclr_bn_bwd_reduce_slots', 'simclr_bn_bwd_pool_slots',

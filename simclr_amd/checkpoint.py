@@ -11,8 +11,10 @@ through a `tf.train.CheckpointManager(directory=FLAGS.model_dir, max_to_keep=FLA
 keyed by the Keras-style variable names (`Variable.name`), so the content is layout-independent: the
 compute copies (bf16 / transposed weights) are rebuilt from the fp32 masters after a restore.
 Variables are created lazily at the first forward pass (like Keras layers), so a model must have been
-called once before `restore` (run.main restores right after the first step; perform_evaluation after the
-first eval batch).  `expect_partial` semantics: names that are absent on either side are reported in the
+called once before `restore`: run.main builds the variables with one inference-mode forward (no statistics or
+weights change) and restores BEFORE step 0, so a resumed run repeats no step; perform_evaluation restores after
+the first eval batch.  Under several replicas every rank restores, only replica 0 writes (`save(..., write=False)`
+on the others keeps their bookkeeping in step without touching the directory).  `expect_partial` semantics: names that are absent on either side are reported in the
 returned status, not fatal, unless `assert_consumed()` is asked for; a shape mismatch is always an error.
 """
 import json

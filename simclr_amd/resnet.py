@@ -227,8 +227,9 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         return prepare_many([(self, inputs)], training)[0]
 
     def _prepare_with(self, inputs, training, sums):
-        """sums: the cross-replica [2,C] fp64 sums (SyncBatchNormalization, :50-60) or None (one replica /
-        global_bn off: the slot reduction is fused into the finalize kernel)."""
+        """sums: [2,C] fp64 sums -- cross-replica ones under SyncBatchNormalization (:50-60, prepare_many all-reduced
+        them), this replica's own otherwise (Gram-matrix statistics of a fused tail) -- or None (the slot reduction is fused
+        into the finalize kernel).  The divisor follows the same rule: global rows only when the sums are global."""
         x = inputs.t
         C = inputs.shape[-1]
         if self.moving_mean is None:
@@ -239,7 +240,7 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
             if inputs.stats is None and sums is None:
                 raise NotImplementedError('BatchNormRelu input must come from a conv/dense epilogue')
             if sums is not None:
-                count = rows * num_replicas(RT.strategy)
+                count = rows * (num_replicas(RT.strategy) if _sync_bn() else 1)
                 mean, rstd, scale, shift = ops.bn_finalize(sums, count, g, b, self._pmm, self._pmv,
                                                            FLAGS.batch_norm_decay, BATCH_NORM_EPSILON)
             else:

@@ -144,7 +144,8 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
         if sup_loss is not None:
             total = total + sup_loss.value
         m['train/total_loss'].update_state(total)
-        return dict(con_loss=con_loss, sup_loss=sup_loss, weight_decay=weight_decay, total_loss=total)
+        return dict(con_loss=con_loss, sup_loss=sup_loss, weight_decay=weight_decay, total_loss=total,
+                    logits_con=logits_con if con_loss is not None else None)
 
     single_step.metrics = m
     return single_step

@@ -465,3 +465,47 @@ def test_hand_derived_ntxent_swapped_views_on_device():
     assert abs(float(o[0]) - 2 * math.log(2 * n - 2 + math.e)) < 1e-4
     assert float(o[1]) == 0.0
     assert abs(float(o[2]) - (math.log(n - 1 + math.e) - math.e / (n - 1 + math.e))) < 1e-4
+
+
+@pytest.mark.parametrize('compute_dtype', ['f32', 'bf16'])
+def test_train_step_resnet50_randomized_bn_batch64_fixed_gates(compute_dtype):
+    """ResNet-50, 96 px, batch 64 (128 views), EVERY BatchNorm with gamma in [0.5, 1.5) (block
+    tails included, so no residual branch is zero) and random beta -- bf16 speed mode vs the float64 oracle with FIXED
+    gates (gradient 1-cos <= 2e-3, relative L2 <= 5e-2, embeddings <= 5e-3, loss <= 1e-2 rel), and the fp32 parity mode on
+    the same step at the north_star tolerances.  The single-step-from-initialisation cases above are the worst-conditioned
+    point of training (zero-gamma tails, near-identical rows); this one is not."""
+    from tests import gpu_checks as gc
+    gates = None
+    if compute_dtype == 'bf16':
+        gates = {'fixed_grad_1-cos': 2e-3, 'fixed_grad_relnorm': 5e-2, 'fixed_embeddings_abs': 5e-3,
+                 'fixed_grad_tensor_vs_global_norm': 5e-2, 'fixed_update_relnorm': 0.25}
+    res = gc.check_train_step_fixed(depth=50, image_size=96, batch=64, compute_dtype=compute_dtype, randomize_bn=True,
+                                    gates=gates)
+    for r in res:
+        print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
+    _assert(res)
+
+
+def test_bf16_training_trajectory_matches_f32_over_100_steps():
+    """100 optimizer steps of BASELINE configs[0]'s shape (ResNet-18, 32 px, batch 256) in bf16 and in
+    fp32 from the same weights and batches: contrastive loss within 1 % and contrastive accuracy within 0.02 in every
+    10-step window after step 20 (tf2/run.py:557-622, tf2/metrics.py:23-36)."""
+    import json
+    from tests import gpu_checks as gc
+    res = gc.check_bf16_trajectory()
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        json.dump(res, open(os.path.join(out, 'bf16_trajectory.json'), 'w'))
+    for r in res:
+        print('%-70s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']), {k: v for k, v in r.items() if k in ('f32_last', 'bf16_last', 'first', 'last')})
+    _assert(res)
+
+
+def test_train_step_resnet152_3x_sk_f32():
+    """BASELINE configs[4]'s architecture (ResNet-152, width 3, selective kernels + ResNet-D stem / shortcuts,
+    tf2/resnet.py:217-277, 702-747) at a small size: one full step in the fp32 parity mode vs the float64 oracle; variable
+    names and the parameter count of the encoder (SimCLRv2's largest model) are asserted too."""
+    from tests import gpu_checks as gc
+    res = gc.check_train_step(depth=152, image_size=32, batch=4, compute_dtype='f32', num_classes=10, randomize_bn=True,
+                              sk_ratio=0.0625, width_multiplier=3)
+    _assert(res)
