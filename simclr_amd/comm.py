@@ -10,6 +10,8 @@ Stands in for the `tf.distribute` strategy object the reference threads through
 Everything here is device-agnostic torch (works on CPU tensors with gloo), which is how the
 multi-replica semantics are tested without GPUs (tests/test_distributed_gloo.py).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -31,7 +33,11 @@ class Strategy:
         self.num_replicas_in_sync = dist.get_world_size(group)
         self.replica_id_in_sync_group = dist.get_rank(group)
         self.stat_group = self.grad_group = group
-        if separate_groups and self.num_replicas_in_sync > 1:
+        # SIMCLR_FORCE_COLLECTIVES=1: issue every collective even with ONE replica (each is then the identity) -- the way
+        # the RCCL code paths (all_gather_into_tensor, reduce_scatter_tensor, the three communicators, async works) are
+        # executed on a single-GPU box: tests/test_gpu_distributed.py::test_rccl_collectives_with_one_rank
+        self.force = os.environ.get('SIMCLR_FORCE_COLLECTIVES') == '1'
+        if separate_groups and (self.num_replicas_in_sync > 1 or self.force):
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
             self.stat_group = dist.new_group(ranks)        # collective: every replica constructs its Strategy
             self.grad_group = dist.new_group(ranks)
@@ -93,6 +99,11 @@ def num_replicas(strategy):
     return 1 if strategy is None else strategy.num_replicas_in_sync
 
 
+def collectives_on(strategy):
+    """True when the cross-replica collectives must be issued: several replicas, or one with SIMCLR_FORCE_COLLECTIVES."""
+    return strategy is not None and (strategy.num_replicas_in_sync > 1 or getattr(strategy, 'force', False))
+
+
 def replica_id(strategy):
     return 0 if strategy is None else strategy.replica_id_in_sync_group
 
@@ -102,7 +113,7 @@ def gather_hidden(z_local, strategy, async_op=False):
     block (both views together), then a re-layout from replica-major to view-major order.
     async_op: returns a zero-argument function that waits for the transfer and returns the gathered block."""
     R = num_replicas(strategy)
-    if R <= 1:                               # tf2/objective.py:103-104
+    if not collectives_on(strategy):         # tf2/objective.py:103-104
         return (lambda: z_local) if async_op else z_local
     n = z_local.shape[0] // 2
 
@@ -123,7 +134,7 @@ def scatter_hidden_grad(dz_all, strategy, async_op=False):
     """Transpose of gather_hidden: [2N,D] key-side gradient -> SUM over replicas of the rows that
     belong to this replica, as [2n,D] (= [dz1_slot; dz2_slot]).  async_op: returns a wait-and-get function."""
     R = num_replicas(strategy)
-    if R <= 1:
+    if not collectives_on(strategy):
         return (lambda: dz_all) if async_op else dz_all
     n = dz_all.shape[0] // (2 * R)
     g = dz_all.view(2, R, n, -1).transpose(0, 1).reshape(R * 2 * n, -1).contiguous()

@@ -446,11 +446,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
                    : (float*)(As + STAGES * STG);  // BNEPI: [4][BN] = scale, shift, mean, rstd of this N-tile (+ [BN] bias if EXT)
   long long* rowoff = (long long*)(bnp + (4 + (EXT ? 1 : 0)) * BN); // [BM] output offsets of the tile rows (LDS epilogue)
   const int zrow = WIN ? (int)(((unsigned char*)(rowoff + BM) - smem) >> 7) : 0;   // WIN: index of a 128-byte row of zeros
+  // WSUM (256-wide tile): the row-pass sums are folded after every half tile into a per-WAVE LDS slot [NW][BN][2] (plain
+  // read-modify-write, the slot belongs to one wave: deterministic) instead of living in 16 registers across the k-loop,
+  // where the 128 accumulator registers leave no room for them
+  constexpr bool WSUM = BM == 256;
+  float2* wred = (float2*)(rowoff + BM);
   constexpr bool LDS_EPI = sizeof(T) == 2;        // bf16: coalesced row-wise epilogue through LDS
   constexpr int NTH = NW * 64;
   constexpr int CPR = BN / 8;                     // 16-byte chunks (8 channels) per C row
   constexpr int RPP = NTH / CPR;                  // rows per pass of the row-wise epilogue
-  static_assert(!LDS_EPI || (BM * BN * 2 <= STG * 16), "C tile must fit in one stage");
+  // A C tile larger than one stage (256 x 256) goes through the row-wise epilogue in EH halves of BMH rows: the waves of
+  // M-half h stage their accumulators, every thread takes part in the row pass, then the other half follows.
+  // ROWSTATS: the per-channel sums are taken in the row-wise epilogue pass (16 registers per thread, of the bf16-rounded
+  // values -- the tensor the reference's moments see, tf2/resnet.py:50-60) instead of from the accumulators (32 registers
+  // held across the whole k-loop): the fused BN-backward reduce always, the forward statistics on the 256-wide tile.
+  constexpr bool ROWSTATS = STATS && LDS_EPI && (BNEPI || BM == 256);
+  constexpr int EH = (LDS_EPI && BM * BN * 2 > STG * 16) ? 2 : 1;
+  constexpr int BMH = BM / EH;
+  static_assert(!LDS_EPI || (BMH * BN * 2 <= STG * 16), "C (half) tile must fit in one stage");
+  static_assert(EH == 1 || (WM % EH == 0 && !WIN), "half-tile epilogue: whole waves per half");
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -575,6 +589,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       if (EXT) bnp[4 * BN + i] = (ok && p.bias) ? p.bias[n] : 0.f;
     }
     // visibility: the first barrier of the k-loop (or the explicit one before the flush) orders these writes
+  }
+  if (WSUM && STATS && LDS_EPI) {
+    for (int i = lane; i < BN; i += 64) wred[wave * BN + i] = make_float2(0.f, 0.f);     // own slot: ordered by program order
   }
   // row-wise epilogue state: this thread's fixed 8-channel chunk and its partial sums
   const int e_cc = tid % CPR;
@@ -724,21 +741,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       if (!DIAG(1))
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        u32x4 af[MI], bf[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int r = wm * (MI * 16) + i * 16 + fl;
-          af[i] = As[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))];
-        }
+        constexpr int MH = MI > 4 ? 4 : MI;          // m-fragments in flight (8-fragment waves: two groups of four)
+        u32x4 bf[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int r = wn * 64 + i * 16 + fl;
           bf[i] = Bs[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))];
         }
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int mh = 0; mh < MI; mh += MH) {
+          u32x4 af[MH];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MMA<T>::run(bf[ni], af[mi], acc[ni][mi]);
+          for (int i = 0; i < MH; ++i) {
+            const int r = wm * (MI * 16) + (mh + i) * 16 + fl;
+            af[i] = As[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))];
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MH; ++mi) acc[ni][mh + mi] = MMA<T>::run(bf[ni], af[mi], acc[ni][mh + mi]);
+        }
       }
       buf = (buf + 1 == STAGES) ? 0 : buf + 1;
       ++consumed;
@@ -763,14 +785,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       // mask / previous value, ReLU mask, per-channel sums, 16-byte coalesced stores.
       const int cst = (buf == 0) ? STAGES - 1 : buf - 1;
       unsigned char* Cs = WIN ? smem : (unsigned char*)(As + cst * STG);
+#pragma unroll
+      for (int eh = 0; eh < EH; ++eh) {
       __syncthreads();
-      if (tid < BM) rowoff[tid] = row_off(m0 + tid);
+      if (eh == 0 && tid < BM) rowoff[tid] = row_off(m0 + tid);
+      if (EH == 1 || wm / (WM / EH) == eh)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int ml = wm * (MI * 16) + mi * 16 + fl;
+        const int ml = wm * (MI * 16) + mi * 16 + fl - eh * BMH;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          if (STATS && !BNEPI) {
+          if (STATS && !ROWSTATS) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
           }
@@ -785,13 +810,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       // All global operands of this thread's ER rows (previous value / BN input / mask) are requested
       // back to back with branch-free addresses, so the row pass pays ONE memory round trip per tile
       // instead of one per row pair.
-      constexpr int ER = BM / RPP;
+      // (256-wide tile: the waves of the other half still hold 128 accumulator registers, so the rows go in batches of 4)
+      constexpr int ERT = BMH / RPP;
+      constexpr int ER = (BM == 256 && ERT > 4) ? 4 : ERT;
       const int ncol = n0 + e_cc * 8;
+#pragma unroll 1
+      for (int eb = 0; eb < ERT; eb += ER) {
       long long eoff[ER];
       bool erok[ER];
 #pragma unroll
       for (int i = 0; i < ER; ++i) {
-        const long long off = rowoff[tid / CPR + i * RPP];
+        const long long off = rowoff[eh * BMH + tid / CPR + (eb + i) * RPP];
         erok[i] = off >= 0 && ncol < p.N && Y != nullptr;     // y == NULL: statistics-only pass, nothing is stored
         eoff[i] = erok[i] ? off + ncol : 0;       // masked rows read (and ignore) element 0
       }
@@ -825,12 +854,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       }
 #pragma unroll
       for (int i = 0; i < ER; ++i) {
-        if (!erok[i]) continue;
-        const int r = tid / CPR + i * RPP;
+        if (!(ROWSTATS && !BNEPI) && !erok[i]) continue;
+        const int r = tid / CPR + (eb + i) * RPP;
         const u32x4 cv = *(const u32x4*)(Cs + r * (BN * 2) + (((e_cc * 2) ^ ((r & 7) << 1)) << 3));
         uint16_t* dst = (uint16_t*)Y + eoff[i];
         float v[8];
         chunk_to_f32<uint16_t>(cv, v);
+        if (ROWSTATS && !BNEPI) {          // rows >= M and columns >= N hold exact zeros: no masking needed
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { e_s[e] += v[e]; e_q[e] = fmaf(v[e], v[e], e_q[e]); }
+          if (!erok[i]) continue;
+        }
         if (FAPPLY) {
           // the arithmetic of bn_apply<RES = 0 | 1> on the bf16-rounded convolution result: bitwise the same output as
           // conv -> HBM -> bn_apply
@@ -903,6 +937,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         if (p.accumulate || BNEPI || EXT) *(u32x4*)dst = f32_to_chunk<uint16_t>(v);
         else *(u32x4*)dst = cv;
       }
+      }   // eb
+      if (WSUM && ROWSTATS) {
+        static_assert(!WSUM || CPR == 32, "lanes l and l + 32 of a wave own the same channel chunk");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float s1 = e_s[e] + __shfl_xor(e_s[e], 32, 64), s2 = e_q[e] + __shfl_xor(e_q[e], 32, 64);
+          if (lane < 32) {
+            float2 o = wred[wave * BN + e_cc * 8 + e];
+            o.x += s1; o.y += s2;
+            wred[wave * BN + e_cc * 8 + e] = o;
+          }
+          e_s[e] = 0.f; e_q[e] = 0.f;
+        }
+      }
+      }   // eh
     } else {
     // ---- fp32 parity mode: registers -> NHWC (4 consecutive channels per lane), no LDS, no barrier
 #pragma unroll
@@ -986,24 +1035,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     }
     }
   }
-  if (STATS && BNEPI && LDS_EPI) {
+  if (ROWSTATS) {
     // flush of the row-wise sums: NTH threads = RPP row-lanes x CPR channel chunks -> LDS -> atomics
     __syncthreads();
-    float* red = (float*)smem;  // [RPP][BN][2]
+    float* red = WSUM ? (float*)wred : (float*)smem;  // [RPP | NW][BN][2]
+    constexpr int NRED = WSUM ? NW : RPP;
+    if (!WSUM) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[((tid / CPR) * BN + e_cc * 8 + e) * 2] = e_s[e];
-      red[((tid / CPR) * BN + e_cc * 8 + e) * 2 + 1] = e_q[e];
+      for (int e = 0; e < 8; ++e) {
+        red[((tid / CPR) * BN + e_cc * 8 + e) * 2] = e_s[e];
+        red[((tid / CPR) * BN + e_cc * 8 + e) * 2 + 1] = e_q[e];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // nslot >= mslots (what simclr_conv2d_stats_slots returns): every workgroup owns slot `mslot` of its channels and
     // stores its sums there -- no float atomics, so the statistics are bit-identical from run to run (idle
     // workgroups store zeros).  Fewer slots: atomics into slot mslot % nslot (order-dependent rounding).
     const bool own_slot = p.nslot >= mslots;
     if (tid < BN && n0 + tid < p.N && (count > 0 || own_slot)) {
       float s1 = 0.f, s2 = 0.f;
-      for (int w = 0; w < RPP; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
-      s2 = (s2 - bnp[2 * BN + tid] * s1) * bnp[3 * BN + tid];     // raw moment -> sum(dm * x^)  (mode 4: s2 = 0, mean = rstd = 0)
+      for (int w = 0; w < NRED; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+      if (BNEPI) s2 = (s2 - bnp[2 * BN + tid] * s1) * bnp[3 * BN + tid];     // raw moment -> sum(dm * x^)  (mode 4: s2 = 0, mean = rstd = 0)
       float* st = p.stats + (long long)(own_slot ? mslot : mslot % p.nslot) * 2 * p.N;
       if (own_slot) { st[n0 + tid] = s1; st[p.N + n0 + tid] = s2; }
       else { atomicAdd(st + n0 + tid, s1); atomicAdd(st + p.N + n0 + tid, s2); }
@@ -1569,14 +1621,17 @@ void conv_wgrad_dma(const WgradP p) {
 }
 
 // ------------------------------------------------------------------------------------
-// Multi-tap wgrad for stride-1 3x3 "same" convolutions in bf16 (opt-in: SIMCLR_WGRAD_3X3=1/2; parity-tested with
-// the switch forced on).  The per-tap kernels above re-read the activation and the
-// gradient slab once per tap (9x through L2); here a workgroup owns a (64 input channels x 64 output
-// channels) tile of ALL nine taps: per 64-pixel chunk it loads the gradient rows once and ONE activation
-// window with a halo of W+1 pixels on either side ([64 + 2W + 2] pixel rows), and forms tap (dy,dx) from the
-// window shifted by dy*W + dx.  Pixel pairs that the shift carries across an image border are removed by
-// masking the gradient fragment (per-lane 8-pixel edge masks).  ~150-230 FLOP per L2->LDS byte instead of
-// 32-64.  Index / mask logic checked against autograd in numpy.
+// Nine-tap weight gradient of the stride-1 3x3 "same" convolutions in bf16 (tf2/resnet.py:183-208 under tape.gradient).
+// The per-tap kernels above re-read the activation and the gradient once per tap (9x through L2 and LDS); here a
+// workgroup owns a (64 input channels x 64 output channels) tile of ALL nine taps: per 64-pixel chunk it loads the
+// gradient rows once and ONE activation window with a halo of W+1 pixels on either side ([64 + 2W + 2] pixel rows), and
+// forms tap (dy,dx) from the window shifted by dy*W + dx.  Wave w owns input channels [16w, 16w+16) x all 64 output
+// channels x nine taps (144 accumulator registers): per 32-pixel k-step it reads 4 gradient fragments (shared by the nine
+// taps) and 9 activation fragments for 36 MFMAs -- 0.36 KB of LDS reads per MFMA against 0.5 of the per-tap 64x64 wave
+// tile.  Pixel pairs that the shift carries across an image border are removed by masking the ACTIVATION fragment
+// (one fragment per tap: 4 ANDs) with per-lane 8-pixel edge masks.  The 32-byte channel blocks of an LDS row are
+// XOR-permuted by key(row) = bit1 | bit3 << 1 of the row: the 8 rows {R..R+3, R+8..R+11} one half-wave transposing read
+// touches then fall into 8 different bank groups for EVERY window shift R.
 // ------------------------------------------------------------------------------------
 struct Wgrad3P {
   const void* x;      // [V, H, W, pixpitch...] bf16
@@ -1588,6 +1643,8 @@ struct Wgrad3P {
   int hpp;            // halo window rows, rounded up to 8
 };
 
+__device__ __forceinline__ int w3_key(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
   constexpr int BR = 64, RB = 128;                 // pixels per chunk, bytes per LDS row (64 bf16 channels)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1596,7 +1653,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, fl = lane & 15;
-  const int wk = wave >> 1, wn = wave & 1;
   const int tiles = p.ci_tiles * p.co_tiles;
   const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
   const int tile = bidx % tiles, split = (bidx / tiles) * 8 + xcd;
@@ -1607,13 +1663,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
   const int W1 = p.W + 1;
   const int stage_bytes = (p.hpp + BR) * RB;
 
-  f32x4 acc[9][2][2];
+  f32x4 acc[9][4];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = (p.M + BR - 1) / BR;
   const int c_begin = split * p.chunks_per_split;
@@ -1628,7 +1682,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
     const int nxi = p.hpp >> 3;
     for (int q = wave; q < nxi; q += 4) {
       const int r = q * 8 + lrow;
-      const int lc = (((lpc >> 1) ^ (r & 3)) << 1) | (lpc & 1);        // logical chunk held by this LDS slot
+      const int lc = (((lpc >> 1) ^ w3_key(r)) << 1) | (lpc & 1);        // logical chunk held by this LDS slot
       const int gp = mc + r - W1;
       const void* src = (gp >= 0 && gp < p.M) ? (const void*)(X + (long long)gp * p.pixpitch + ci0 + lc * 8) : p.zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + q * 1024), 16, 0, 0);
@@ -1637,28 +1691,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
     for (int j = 0; j < 2; ++j) {
       const int q = wave * 2 + j;
       const int r = q * 8 + lrow;
-      const int lc = (((lpc >> 1) ^ (r & 3)) << 1) | (lpc & 1);
+      const int lc = (((lpc >> 1) ^ w3_key(r)) << 1) | (lpc & 1);
       const int m = mc + r;
       const void* src = (m < p.M) ? (const void*)(DY + (long long)m * p.N + n0 + lc * 8) : p.zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + q * 1024), 16, 0, 0);
     }
   };
 
-  // ---- per-lane constants of the fragment reads (row & 3 of every read is fixed per lane and tap)
-  // byte offset of (row, 4-channel group) in a [rows][128 B] tile whose 32-byte blocks are XOR-permuted by row & 3
-  auto off_of = [&](int row, int byte) -> int { return row * RB + ((((byte >> 5) ^ (row & 3)) & 3) << 5) + (byte & 31); };
+  // ---- per-lane constants of the fragment reads: byte offset of (row, channel byte) in a [rows][128 B] tile
+  auto off_of = [&](int row, int byte) -> int { return row * RB + ((((byte >> 5) ^ w3_key(row)) & 3) << 5) + (byte & 31); };
   const int px_lane = g * 8 + (fl >> 2);                     // this lane's pixel row inside a 32-pixel k-step
-  int a_off[9][2];                                           // window read offsets for k-step 0 (k-step 1: +32 rows)
+  // window read offsets of k-step 0, rows r and r + 4 (k-step 1: + 32 rows = + 4096 bytes, key(row + 32) == key(row))
+  int a_lo[9], a_hi[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const int delta = (t / 3 - 1) * p.W + (t % 3 - 1);
-#pragma unroll
-    for (int ki = 0; ki < 2; ++ki)
-      a_off[t][ki] = off_of(px_lane + W1 + delta, (wk * 32 + ki * 16 + (fl & 3) * 4) * 2);
+    const int r = px_lane + W1 + (t / 3 - 1) * p.W + (t % 3 - 1);
+    a_lo[t] = off_of(r, (wave * 16 + (fl & 3) * 4) * 2);
+    a_hi[t] = off_of(r + 4, (wave * 16 + (fl & 3) * 4) * 2);
   }
-  int b_off[2];
+  int b_lo[4], b_hi[4];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) b_off[ni] = off_of(px_lane, (wn * 32 + ni * 16 + (fl & 3) * 4) * 2);
+  for (int ni = 0; ni < 4; ++ni) {
+    b_lo[ni] = off_of(px_lane, (ni * 16 + (fl & 3) * 4) * 2);
+    b_hi[ni] = off_of(px_lane + 4, (ni * 16 + (fl & 3) * 4) * 2);
+  }
 
   // ---- (row, column) of the first pixel of this lane's two 8-pixel groups (k-steps 0 and 1), advanced per chunk
   const int hw = p.H * p.W;
@@ -1677,16 +1733,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // gradient fragments (shared by the nine taps)
-      u32x4 bf[2];
+      u32x4 bf[4];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const unsigned char* b = ds + ks * 32 * RB + b_off[ni];
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(b));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(b + 4 * RB));
+      for (int ni = 0; ni < 4; ++ni) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ds + ks * 32 * RB + b_lo[ni]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ds + ks * 32 * RB + b_hi[ni]));
         const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
         bf[ni] = (u32x4){l2[0], l2[1], h2[0], h2[1]};
       }
-      // edge masks of this lane's 8 pixels (bit j set = the neighbour in that direction exists).  W >= 8, so the
+      // edge masks of this lane's 8 pixels (bit j set = the neighbour in that direction exists).  W >= 7, so the
       // 8 consecutive pixels cross at most one row end: at position jw = W - gx (>= 8: no crossing).
       const int jw = p.W - gx[ks];
       const unsigned lowm = jw >= 8 ? 0xffu : ((1u << jw) - 1u);          // pixels still in row gy
@@ -1695,7 +1750,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
       const unsigned dn = (gy[ks] < p.H - 1 ? lowm : 0u) | (y1 < p.H - 1 ? (0xffu & ~lowm) : 0u);
       const unsigned lf = 0xffu & ~((gx[ks] == 0 ? 1u : 0u) | (jw < 8 ? (1u << jw) : 0u));          // x == 0 at j = 0 / jw
       const unsigned rt = 0xffu & ~((jw - 1 < 8 ? (1u << (jw - 1)) : 0u));                            // x == W-1 at j = jw-1
-      // 16-bit lane masks -> dword masks (dword d holds pixels 2d, 2d+1), once per direction
+      // 8-bit lane masks -> dword masks (dword d holds pixels 2d, 2d+1), once per direction
       u32x4 wup, wdn, wlf, wrt;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -1707,27 +1762,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ty = t / 3, tx = t % 3;
-        u32x4 mb[2];
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xs + ks * 32 * RB + a_lo[t]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(xs + ks * 32 * RB + a_hi[t]));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        u32x4 af = (u32x4){l2[0], l2[1], h2[0], h2[1]};
+        if (t != 4) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          unsigned w = 0xffffffffu;
-          if (ty == 0) w &= wup[d]; else if (ty == 2) w &= wdn[d];
-          if (tx == 0) w &= wlf[d]; else if (tx == 2) w &= wrt[d];
-          mb[0][d] = (t == 4) ? bf[0][d] : (bf[0][d] & w);
-          mb[1][d] = (t == 4) ? bf[1][d] : (bf[1][d] & w);
+          for (int d = 0; d < 4; ++d) {
+            unsigned w = 0xffffffffu;
+            if (ty == 0) w &= wup[d]; else if (ty == 2) w &= wdn[d];
+            if (tx == 0) w &= wlf[d]; else if (tx == 2) w &= wrt[d];
+            af[d] &= w;
+          }
         }
 #pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
-          const unsigned char* a = xs + ks * 32 * RB + a_off[t][ki];
-          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a));
-          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a + 4 * RB));
-          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          const u32x4 af = (u32x4){l2[0], l2[1], h2[0], h2[1]};
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[t][ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, mb[ni]), __builtin_bit_cast(bf16x8, af), acc[t][ki][ni], 0, 0, 0);
-        }
+        for (int ni = 0; ni < 4; ++ni)
+          acc[t][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, bf[ni]), __builtin_bit_cast(bf16x8, af), acc[t][ni], 0, 0, 0);
       }
       // advance this group's pixel coordinates by one chunk
       gx[ks] += dcol;
@@ -1745,19 +1796,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
     if (c + 1 < c_end) issue(c + 1, s ^ 1);
     compute(s);
   }
+  // D[n = g*4+reg][ci = fl]  ->  slab[split][tap*IC + ci][n .. n+3]
   float* slab = p.dw + (long long)split * 9 * p.IC * p.N;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 9; ++t) {
+    const int kk = t * p.IC + ci0 + wave * 16 + fl;
 #pragma unroll
-    for (int ki = 0; ki < 2; ++ki) {
-      const int kk = t * p.IC + ci0 + wk * 32 + ki * 16 + fl;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 32 + ni * 16 + g * 4;
-        *(float4*)(slab + (long long)kk * p.N + n) =
-            make_float4(acc[t][ki][ni][0], acc[t][ki][ni][1], acc[t][ki][ni][2], acc[t][ki][ni][3]);
-      }
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + ni * 16 + g * 4;
+      *(float4*)(slab + (long long)kk * p.N + n) = make_float4(acc[t][ni][0], acc[t][ni][1], acc[t][ni][2], acc[t][ni][3]);
     }
+  }
 }
 
 // C[m][n] = sum_k A[m][k] * B[n][k]   (fp32, row-major, K contiguous in both; m, n multiples of 16, k of 32).
@@ -2158,6 +2207,15 @@ static void igemm_persistent_grid(long long M, int N, int* bn, int* n_tiles, int
   *bn = BN; *n_tiles = nt; *grid = pg;
 }
 
+// Tile choice of the bf16 forward / dgrad launches: true = 256 x 256 (8 waves), false = 128 x (64 | 128) (4 waves).
+static bool igemm_use_256(const ConvP& p) {
+  if (p.N % 256 != 0 || p.ntaps <= 0 || p.N / 256 > 32) return false;
+  const char* e = getenv("SIMCLR_IGEMM_TILE");
+  const int mode = e ? atoi(e) : 0;
+  if (mode == 256) return true;
+  return false;
+}
+
 template <typename T, int MODE>
 void launch_igemm_one(ConvP p, hipStream_t stream) {
   const int BN = (p.N <= 64) ? 64 : 128;
@@ -2182,6 +2240,31 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     int bn_, nt_, pg;
     igemm_persistent_grid(p.M, p.N, &bn_, &nt_, &pg);
     const size_t plds = 2 * (128 + BN) * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long);
+    // 256 x 256 tile, 8 waves of 128 x 64 (one workgroup per CU): half the L2->LDS bytes per FLOP of the 128 x 128 tile
+    // (which needs 64 B/clk/CU from L2 at the MFMA peak -- more than an XCD's L2 delivers) and 0.375 instead of 0.5 KB
+    // of LDS fragment reads per MFMA.  SIMCLR_IGEMM_TILE: 128 / 256 force a tile, unset = igemm_use_256 (measured per
+    // layer class, profiles/r03_notes.md).  The statistics slots of the 128-wide geometry (simclr_conv2d_stats_slots)
+    // are never fewer than this grid's M-slots.
+    if constexpr (sizeof(T) == 2) {
+      if (igemm_use_256(p)) {
+        p.m_tiles = ceil_div(p.M, 256);
+        p.n_tiles = p.N / 256;
+        const int unit = 8 * p.n_tiles;
+        int pg2 = max(unit, (256 / unit) * unit);
+        pg2 = min(pg2, ceil_div(p.m_tiles, 8) * unit);
+        const size_t lds2 = 2 * (256 + 256) * 128 + 5 * 256 * sizeof(float) + 256 * sizeof(long long) + 8 * 256 * 2 * sizeof(float);
+#define L2(STv, BEv, EXv, FAv) \
+        hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv>), dim3(pg2), dim3(512), lds2, stream, p)
+        if (p.fapply) { if constexpr (MODE == MODE_FWD) L2(false, false, false, true); }
+        else if (p.x2 && p.bn_mode) L2(true, true, true, false);
+        else if (p.x2) L2(false, false, true, false);
+        else if (p.bn_mode) L2(true, true, false, false);
+        else if (st) L2(true, false, false, false);
+        else L2(false, false, false, false);
+#undef L2
+        return;
+      }
+    }
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
     if (p.fapply) {
@@ -2508,7 +2591,7 @@ static bool wgrad_use_3x3(int dtype, long long M, int Cin, int Cout, int KH, int
   if (mode <= 0) return false;
   if (mode == 2 && M < 500000) return false;
   return dtype == SIMCLR_DT_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && IH == OH && IW == OW &&
-         Cin % 64 == 0 && Cout % 64 == 0 && (pixpitch * 2) % 16 == 0 && IW >= 8 && (64 + 2 * IW + 2 + 7) / 8 * 8 * 128 * 2 + 2 * 64 * 128 <= 160 * 1024;
+         Cin % 64 == 0 && Cout % 64 == 0 && (pixpitch * 2) % 16 == 0 && IW >= 7 && (64 + 2 * IW + 2 + 7) / 8 * 8 * 128 * 2 + 2 * 64 * 128 <= 160 * 1024;
 }
 static bool wgrad_use_256() {
 #ifdef SIMCLR_DIAG

@@ -11,7 +11,7 @@ fused contrast accuracy / entropy (tf2/metrics.py:28-35); call `.dense()` for re
 import torch
 
 from . import ops
-from .comm import gather_hidden, num_replicas, replica_id, scatter_hidden_grad
+from .comm import collectives_on, gather_hidden, num_replicas, replica_id, scatter_hidden_grad
 from .resnet import RT
 
 LARGE_NUM = 1e9  # tf2/objective.py:24 (kept for reference; the kernel skips the masked column)
@@ -85,7 +85,7 @@ class LazyLabels:
 def tpu_cross_replica_concat(tensor, strategy=None):
     """Reduce a concatenation of the `tensor` across replicas (tf2/objective.py:92-127).
     The reference builds it from scatter_nd + all_reduce(SUM); over RCCL it is an all_gather."""
-    if strategy is None or strategy.num_replicas_in_sync <= 1:
+    if not collectives_on(strategy):
         return tensor
     return strategy.all_gather_concat(tensor)
 

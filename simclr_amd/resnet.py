@@ -26,7 +26,7 @@ import weakref
 import torch
 
 from . import ops
-from .comm import num_replicas
+from .comm import collectives_on, num_replicas
 from .flags import FLAGS
 from .lars_optimizer import Variable
 
@@ -363,7 +363,7 @@ def _conv3_stats_from_gram():
 
 
 def _sync_bn():
-    return FLAGS.global_bn and num_replicas(RT.strategy) > 1
+    return FLAGS.global_bn and collectives_on(RT.strategy)
 
 
 def prepare_many(items, training):

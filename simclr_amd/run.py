@@ -19,7 +19,7 @@ import torch.distributed as dist
 from . import metrics, ops
 from . import model as model_lib
 from . import objective as obj_lib
-from .comm import Strategy, num_replicas
+from .comm import Strategy, collectives_on, num_replicas
 from .flags import FLAGS
 from .resnet import RT, join_wgrad_stream
 
@@ -61,7 +61,7 @@ class GradSync:
 
     def on_stage(self, stage):
         """Called by the backward pass after block group `stage` (4..1) is done; 0 = stem done."""
-        if self.strategy is None or self.strategy.num_replicas_in_sync <= 1:
+        if not collectives_on(self.strategy):
             return
         join_wgrad_stream()          # this bucket's weight gradients may still be running on the side stream
         if stage == 0:
@@ -164,15 +164,29 @@ def synthetic_batches(batch, image_size, num_classes, device, seed=0, pool=2):
 
 
 def init_distributed():
-    """One process per GPU (torchrun): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
+    """One process per GPU (torchrun): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env.
+    SIMCLR_DIST_BACKEND=gloo: the ranks talk over gloo and, with SIMCLR_SHARE_GPU=1, all sit on cuda:0 -- the way the
+    multi-rank launch path is exercised on a single-GPU box (RCCL refuses two ranks on one device).
+    SIMCLR_FORCE_COLLECTIVES=1 with WORLD_SIZE=1: a one-rank RCCL communicator whose collectives are all issued."""
     import os
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    force = os.environ.get('SIMCLR_FORCE_COLLECTIVES') == '1'
+    if world <= 1 and not force:
         return None
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('SIMCLR_DIST_BACKEND', 'nccl')
+    share = os.environ.get('SIMCLR_SHARE_GPU') == '1'
+    local = 0 if share else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     if not dist.is_initialized():
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if world <= 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     return Strategy()
 
 

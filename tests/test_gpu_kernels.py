@@ -121,6 +121,35 @@ def test_conv_bench_path_shapes(V, H, Cin, Cout, k, s, bn_case, dtype):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s,bn_case', [c for c in BENCH_PATH_CASES if c[2] % 256 == 0 or c[3] % 256 == 0]
+                         + [(300, 14, 1024, 256, 1, 1, (3, 1)), (37, 28, 512, 256, 1, 1, (4, 0))])
+def test_conv_256_tile_paths(V, H, Cin, Cout, k, s, bn_case):
+    """The 256 x 256 / 8-wave forward and dgrad instantiations (half-tile row-wise epilogue) forced on for every layer
+    whose output width allows them: same full-tensor float64 bar as the 128-wide tiles (tf2/resnet.py:183-208)."""
+    import os
+    from tests import gpu_checks as gc
+    os.environ['SIMCLR_IGEMM_TILE'] = '256'
+    try:
+        _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, BF, bn_case=bn_case))
+        if k == 1 and Cout % 256 == 0:      # the fused conv3 + bn3 + residual + ReLU epilogue on the wide tile: bitwise
+            _assert(gc.check_conv_fwd_bn_apply(min(V, 64), H, Cin, Cout, 1, s, True, True, res_bn=(s == 2)))
+    finally:
+        os.environ.pop('SIMCLR_IGEMM_TILE')
+    torch.cuda.empty_cache()
+
+
+def test_train_step_bf16_with_256_tiles():
+    """ResNet-50 bf16 step vs the oracle with the 256-wide tiles forced on wherever the output width allows (the K-extended
+    dgrad of the folded BatchNorm backward and the fused block tails included)."""
+    import os
+    from tests import gpu_checks as gc
+    os.environ['SIMCLR_IGEMM_TILE'] = '256'
+    try:
+        _assert(gc.check_train_step(depth=50, image_size=64, batch=8, compute_dtype='bf16', num_classes=1000, randomize_bn=False))
+    finally:
+        os.environ.pop('SIMCLR_IGEMM_TILE')
+
+
 @pytest.mark.parametrize('compute_dtype', ['f32', 'bf16'])
 def test_train_step_resnet50_224_batch32_fixed_thresholds(compute_dtype):
     """ResNet-50 / 224 px / batch 32 step vs the float64 oracle with FIXED gates
@@ -468,19 +497,20 @@ def test_hand_derived_ntxent_swapped_views_on_device():
 
 
 @pytest.mark.parametrize('compute_dtype', ['f32', 'bf16'])
-def test_train_step_resnet50_randomized_bn_batch64_fixed_gates(compute_dtype):
-    """ResNet-50, 96 px, batch 64 (128 views), EVERY BatchNorm with gamma in [0.5, 1.5) (block
-    tails included, so no residual branch is zero) and random beta -- bf16 speed mode vs the float64 oracle with FIXED
-    gates (gradient 1-cos <= 2e-3, relative L2 <= 5e-2, embeddings <= 5e-3, loss <= 1e-2 rel), and the fp32 parity mode on
-    the same step at the north_star tolerances.  The single-step-from-initialisation cases above are the worst-conditioned
-    point of training (zero-gamma tails, near-identical rows); this one is not."""
+def test_train_step_resnet50_from_trained_point_fixed_gates(compute_dtype):
+    """one step of ResNet-50 (64 px, batch 64 = 128 views) from a TRAINED point -- 60 steps of
+    pretraining on the device first, so the features differ from image to image and every block tail has gamma != 0 --
+    against the float64 oracle started from the exported weights, with FIXED gates: bf16 speed mode gradient 1-cos <= 2e-3,
+    relative L2 <= 5e-2, embeddings <= 5e-3, loss <= 1e-2 rel; fp32 parity mode on the same step at north_star's
+    tolerances.  The single-step-from-initialisation cases above are the worst-conditioned point of training
+    (zero-gamma tails, near-identical feature rows); this one is not."""
     from tests import gpu_checks as gc
     gates = None
     if compute_dtype == 'bf16':
         gates = {'fixed_grad_1-cos': 2e-3, 'fixed_grad_relnorm': 5e-2, 'fixed_embeddings_abs': 5e-3,
                  'fixed_grad_tensor_vs_global_norm': 5e-2, 'fixed_update_relnorm': 0.25}
-    res = gc.check_train_step_fixed(depth=50, image_size=96, batch=64, compute_dtype=compute_dtype, randomize_bn=True,
-                                    gates=gates)
+    res = gc.check_train_step_fixed(depth=50, image_size=64, batch=64, compute_dtype=compute_dtype, gates=gates,
+                                    pretrain_steps=60)
     for r in res:
         print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
     _assert(res)
@@ -503,9 +533,23 @@ def test_bf16_training_trajectory_matches_f32_over_100_steps():
 
 def test_train_step_resnet152_3x_sk_f32():
     """BASELINE configs[4]'s architecture (ResNet-152, width 3, selective kernels + ResNet-D stem / shortcuts,
-    tf2/resnet.py:217-277, 702-747) at a small size: one full step in the fp32 parity mode vs the float64 oracle; variable
-    names and the parameter count of the encoder (SimCLRv2's largest model) are asserted too."""
+    tf2/resnet.py:217-277, 702-747) at a small size: one full step in the fp32 parity mode vs the float64 oracle (variable
+    names included: the comparison is by name), and the parameter count of the encoder against the reference's model zoo."""
     from tests import gpu_checks as gc
-    res = gc.check_train_step(depth=152, image_size=32, batch=4, compute_dtype='f32', num_classes=10, randomize_bn=True,
+    res = gc.check_train_step(depth=152, image_size=32, batch=8, compute_dtype='f32', num_classes=10, randomize_bn=False,
                               sk_ratio=0.0625, width_multiplier=3)
     _assert(res)
+    # README.md:33 model-zoo "Param (M)" of R152 3x + SK: 795 (encoder, trainable + BatchNorm moving statistics)
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    FLAGS.reset(); FLAGS.update(resnet_depth=152, width_multiplier=3, sk_ratio=0.0625, image_size=32, use_blur=False, compute_dtype='bf16')
+    RT.reset(); RT.device = torch.device('cuda')
+    m = model_lib.Model(10)
+    with torch.no_grad():
+        m(torch.rand(2, 32, 32, 6, device='cuda'), training=False)
+    n = sum(v.numel() for v in m.resnet_model.variables)
+    FLAGS.reset(); RT.reset()
+    del m
+    torch.cuda.empty_cache()
+    assert round(n / 1e6) == 795, n

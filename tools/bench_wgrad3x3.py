@@ -8,7 +8,7 @@ from tools.microbench import timeit
 
 def main():
     dev, dt, V = 'cuda', torch.bfloat16, 1024
-    for (H, C, cnt) in [(56, 64, 3), (28, 128, 3), (14, 256, 5), (7, 512, 2)]:
+    for (H, C, cnt) in [(56, 64, 3), (28, 128, 3), (14, 256, 5), (7, 512, 2)] + ([(56, 128, 0), (28, 256, 0), (14, 512, 0)] if '--wide' in sys.argv else []):
         x = torch.randn(V, H, H, C, device=dev).to(dt)
         dy = torch.randn(V, H, H, C, device=dev).to(dt)
         res = {}

@@ -92,6 +92,41 @@ def main():
             del x, dy, y, dx
         print('per-step totals (ms): fwd %.2f (no stats %.2f)  dgrad %.2f  wgrad %.2f' % (
             tot['fwd'] / 1e3, tot['fwd_nostats'] / 1e3, tot['dgrad'] / 1e3, tot['wgrad'] / 1e3), flush=True)
+    if 'tile' in what:
+        # A/B of the forward / dgrad tile: default (128-wide) vs SIMCLR_IGEMM_TILE=256 on every layer whose width allows it
+        print('%-26s | fwd+stats 128 / 256 | fwd 128 / 256 | dgrad 128 / 256 | dgrad_bn 128 / 256  (us)' % 'layer')
+        tot = [0.0] * 8
+        for (H, Cin, Cout, k, s, cnt) in R50:
+            if Cout % 256 and Cin % 256:
+                continue
+            pad = (k - 1) // 2
+            OH = (H + (k - 1) - k) // s + 1
+            x = torch.randn(V, H, H, Cin, device=dev).to(dt)
+            w = (torch.randn(k, k, Cin, Cout, device=dev) * (k * k * Cin) ** -0.5)
+            dy = torch.randn(V, OH, OH, Cout, device=dev).to(dt)
+            w_t = ops.prep_weights(w, 0, dt); w_d = ops.prep_weights(w, 1, dt)
+            y = torch.empty(V, OH, OH, Cout, device=dev, dtype=dt)
+            dx = torch.empty(V, H, H, Cin, device=dev, dtype=dt)
+            stats = ops.conv_stats(V * OH * OH, Cout, dev)
+            bn = dict(x=x, mask=None, scale=torch.rand(Cin, device=dev) - 0.4, shift=torch.randn(Cin, device=dev) * 0.3,
+                      mean=torch.randn(Cin, device=dev) * 0.2, rstd=torch.rand(Cin, device=dev) + 0.5, mode=2)
+            ts = []
+            for tile in ('128', '256'):
+                os.environ['SIMCLR_IGEMM_TILE'] = tile
+                ts.append(timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=stats, out=y), args.iters))
+                ts.append(timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=None, out=y), args.iters))
+                ts.append(timeit(lambda: ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H, out=dx), args.iters))
+                ts.append(timeit(lambda: ops.conv2d_dgrad_bn(dy, w_d, k, k, pad, H, H, bn, out=dx), args.iters) if s == 1 else 0.0)
+            os.environ.pop('SIMCLR_IGEMM_TILE')
+            name = '%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt)
+            print('%-26s | %6.0f %6.0f | %6.0f %6.0f | %6.0f %6.0f | %6.0f %6.0f' % (
+                name, ts[0], ts[4], ts[1], ts[5], ts[2], ts[6], ts[3], ts[7]), flush=True)
+            res.append(dict(layer='tile ' + name, t128=ts[:4], t256=ts[4:], count=cnt))
+            for i in range(8):
+                tot[i] += cnt * ts[i]
+            del x, dy, y, dx
+        print('weighted totals (ms): fwd+stats %.2f / %.2f  fwd %.2f / %.2f  dgrad %.2f / %.2f  dgrad_bn %.2f / %.2f' % (
+            tot[0] / 1e3, tot[4] / 1e3, tot[1] / 1e3, tot[5] / 1e3, tot[2] / 1e3, tot[6] / 1e3, tot[3] / 1e3, tot[7] / 1e3), flush=True)
     if 'bn' in what:
         print('%-22s %9s %9s %9s %9s | GB/s apply resid bwd_red bwd_app' % ('tensor', 'apply_us', 'resid_us', 'bwdred_us', 'bwdapp_us'))
         shapes = [(56, 64, 7), (56, 256, 4), (28, 128, 8), (28, 512, 5), (14, 256, 12), (14, 1024, 7), (7, 512, 6), (7, 2048, 4)]
