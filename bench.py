@@ -50,6 +50,8 @@ PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 FLOP_PER_IMAGE = 49.15e9    # 2 views x (fwd+dgrad+wgrad), encoder + head
+# (depth, width, SK) -> FLOP per image at 224 px (SURVEY 8(d) / BASELINE.md section 3: cfg2/3, cfg4, cfg5)
+FLOP_PER_IMAGE_BY_MODEL = {(50, 1, False): 49.15e9, (50, 2, True): 296.6e9, (152, 3, True): 1893.6e9}
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -134,7 +136,11 @@ def make_roofline(kernel, flops, min_bytes, impl_bytes, total_ms, launches, step
         d.update(achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit='GB/s', frac=round(gbps / PEAK_HBM_GBPS, 4))
     else:
         d.update(achieved=round(tflops, 2), peak=mfma_peak_tflops, unit='TFLOP/s', frac=round(tflops / mfma_peak_tflops, 4))
-    d.update(traffic=None, traffic_source=None,
+    # strict_frac: SURVEY 8(d) bytes only (= frac when HBM-bound); fused_operands_frac: the same time against the bytes
+    # the launches move by design (residual / BN input / mask operands of the fused epilogues included)
+    d.update(strict_frac=round((gbps / PEAK_HBM_GBPS) if hbm else (tflops / mfma_peak_tflops), 4),
+             fused_operands_frac=round(impl_bytes / sec / 1e9 / PEAK_HBM_GBPS, 4) if hbm else None,
+             traffic=None, traffic_source=None, traffic_measured_in_run=False,
              bytes_rule='SURVEY 8(d) minimum: (input + output + weights) * elt per launch, each read / written once',
              algorithmic_bytes_per_launch=round(min_bytes / max(launches, 1)),
              flops_per_launch_avg=flops / max(launches, 1),
@@ -238,7 +244,14 @@ def main():
     ap.add_argument('--no_kernel_events', action='store_true', help='skip the instrumented steps (rocprof runs)')
     ap.add_argument('--no_f32', action='store_true', help='skip the fp32 parity-mode measurement')
     ap.add_argument('--prof_steps', type=int, default=3)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo: the ranks talk over gloo and share cuda:0 when the box has fewer GPUs than ranks (exercises '
+                         'the N > 1 launch path on a single-GPU box; RCCL refuses two ranks on one device)')
     args = ap.parse_args()
+    if args.backend == 'gloo':
+        os.environ['SIMCLR_DIST_BACKEND'] = 'gloo'
+        if torch.cuda.device_count() < args.gpus:
+            os.environ['SIMCLR_SHARE_GPU'] = '1'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(relaunch_multi_gpu(args))
@@ -263,6 +276,8 @@ def main():
         step_fn(f, l)
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    torch.cuda.reset_peak_memory_stats()
+    coll0 = (strategy.stat_collectives, strategy.hidden_collectives) if strategy is not None else (0, 0)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -278,6 +293,11 @@ def main():
         elapsed = float(t.item())
     value = global_batch * args.steps / elapsed
     metrics = {k: v.result() for k, v in step_fn.metrics.items()}
+    peak_hbm_gb = torch.cuda.max_memory_allocated() / 1e9          # every device buffer of the step is a torch allocation
+    coll_counts = None
+    if strategy is not None:
+        coll_counts = dict(stat_collectives_per_step=(strategy.stat_collectives - coll0[0]) / args.steps,
+                           hidden_collectives_per_step=(strategy.hidden_collectives - coll0[1]) / args.steps)
 
     # ---- instrumented steps (per-launch HIP events), outside the headline region
     prof = None
@@ -293,12 +313,14 @@ def main():
     coll = None
     if strategy is not None:
         coll = collective_bench(strategy, args.per_gpu_batch, dev, int(model._flat_grads.numel()))
+        coll.update(coll_counts, backend=dist.get_backend())
     if rank != 0:
         return
 
     peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
     default_cfg = (args.resnet_depth == 50 and args.image_size == 224 and args.width_multiplier == 1 and
                    args.sk_ratio == 0 and args.per_gpu_batch == 512)
+    flop_img = FLOP_PER_IMAGE_BY_MODEL.get((args.resnet_depth, args.width_multiplier, args.sk_ratio > 0)) if args.image_size == 224 else None
     roofline, kernels, ntx = None, {}, None
     if prof is not None:
         summ = prof.summary()
@@ -357,18 +379,19 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         s32, d32, _, m32 = build_step(args, 'f32', None, 1, 0, dev)
-        for _ in range(2):
+        w32 = 3
+        for _ in range(w32):
             f, l = next(d32); s32(f, l)
         torch.cuda.synchronize()
-        k32 = 4
+        k32 = 10
         t1 = time.perf_counter()
         for _ in range(k32):
             f, l = next(d32); s32(f, l)
         torch.cuda.synchronize()
         e32 = time.perf_counter() - t1
         f32_mode = dict(value=round(global_batch * k32 / e32, 2), unit='images/s', ms_per_step=round(e32 / k32 * 1e3, 2),
-                        steps=k32, warmup=2, dtype='f32',
-                        step_mfma_frac=round(global_batch * k32 / e32 * FLOP_PER_IMAGE / (PEAK_F32_TFLOPS * 1e12), 4) if default_cfg else None)
+                        steps=k32, warmup=w32, dtype='f32',
+                        step_mfma_frac=round(global_batch * k32 / e32 * flop_img / (PEAK_F32_TFLOPS * 1e12), 4) if flop_img else None)
         del s32, d32, m32
         gc.collect()
         torch.cuda.empty_cache()
@@ -416,7 +439,8 @@ def main():
                                   global_batch, ', on-device blur' if args.use_blur else '', world),
                    'global_batch': global_batch, 'parallelism': 'dp%d' % world},
         'step_ms': percentiles(step_ms),
-        'step_mfma_frac': round(value * FLOP_PER_IMAGE / (world * peak * 1e12), 4) if default_cfg else None,
+        'step_mfma_frac': round(value * flop_img / (world * peak * 1e12), 4) if flop_img else None,
+        'flop_per_image': flop_img, 'peak_hbm_gb': round(peak_hbm_gb, 2),
         'per_layer_bound_frac': round(value / (world * 22100.0), 4) if default_cfg and args.dtype == 'bf16' else None,
         'roofline': roofline,
         'ntxent': ntx,

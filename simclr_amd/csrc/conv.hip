@@ -1749,7 +1749,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
       const unsigned up = (gy[ks] > 0 ? lowm : 0u) | (y1 > 0 ? (0xffu & ~lowm) : 0u);
       const unsigned dn = (gy[ks] < p.H - 1 ? lowm : 0u) | (y1 < p.H - 1 ? (0xffu & ~lowm) : 0u);
       const unsigned lf = 0xffu & ~((gx[ks] == 0 ? 1u : 0u) | (jw < 8 ? (1u << jw) : 0u));          // x == 0 at j = 0 / jw
-      const unsigned rt = 0xffu & ~((jw - 1 < 8 ? (1u << (jw - 1)) : 0u));                            // x == W-1 at j = jw-1
+      const unsigned rt = 0xffu & ~((jw - 1 < 8 ? (1u << (jw - 1)) : 0u) |                            // x == W-1 at j = jw-1
+                                    (jw - 1 + p.W < 8 ? (1u << (jw - 1 + p.W)) : 0u));                // and once more when W = 7
       // 8-bit lane masks -> dword masks (dword d holds pixels 2d, 2d+1), once per direction
       u32x4 wup, wdn, wlf, wrt;
 #pragma unroll
@@ -2208,12 +2209,22 @@ static void igemm_persistent_grid(long long M, int N, int* bn, int* n_tiles, int
 }
 
 // Tile choice of the bf16 forward / dgrad launches: true = 256 x 256 (8 waves), false = 128 x (64 | 128) (4 waves).
-static bool igemm_use_256(const ConvP& p) {
+// Measured per ResNet-50 layer class at 1024 views (profiles/r03_notes.md, tools/microbench.py --what tile): the wide tile
+// wins on the 1x1 convolutions with >= 256 output channels and >= 150 k rows (-5...-18 %: forward with statistics, forward
+// with the fused BatchNorm-apply epilogue, plain and K-extended dgrad), ties at 7^2 (196 M-tiles leave the last round of
+// 256 workgroups 3/4 empty) and LOSES wherever the row-wise epilogue carries the fused BN-backward reduce (one workgroup
+// per CU cannot hide that pass behind another workgroup's MFMAs: +5...+18 %) and on the 3x3 layers (the 128-wide
+// halo-window path moves fewer L2->LDS bytes than the 256-wide gather).
+static bool igemm_use_256(const ConvP& p, bool fwd) {
   if (p.N % 256 != 0 || p.ntaps <= 0 || p.N / 256 > 32) return false;
   const char* e = getenv("SIMCLR_IGEMM_TILE");
   const int mode = e ? atoi(e) : 0;
   if (mode == 256) return true;
-  return false;
+  if (mode == 128) return false;
+  if (p.KH != 1 || p.KW != 1 || p.M < 150000) return false;
+  if (p.bn_mode && !p.fapply) return false;          // fused BN-backward reduce epilogue
+  if (fwd && !p.fapply && p.stats && p.K < 128) return false;
+  return true;
 }
 
 template <typename T, int MODE>
@@ -2246,7 +2257,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     // layer class, profiles/r03_notes.md).  The statistics slots of the 128-wide geometry (simclr_conv2d_stats_slots)
     // are never fewer than this grid's M-slots.
     if constexpr (sizeof(T) == 2) {
-      if (igemm_use_256(p)) {
+      if (igemm_use_256(p, MODE == MODE_FWD)) {
         p.m_tiles = ceil_div(p.M, 256);
         p.n_tiles = p.N / 256;
         const int unit = 8 * p.n_tiles;
@@ -2579,17 +2590,13 @@ static int wgrad_splits(long long M, int K, int N, int bkw, int bnw, int br, int
   }
   return eff;
 }
-// experimental multi-tap 3x3 kernel (default off); read per call so that a test can switch it on in-process
+// nine-tap 3x3 kernel: default for every eligible layer (bf16, stride 1, 7 <= W, whole 64-channel blocks); measured
+// against the per-tap kernels at 1024 views (profiles/r03_notes.md): 56^2 645 -> 516 us, 28^2 463 -> 381, 14^2 387 -> 367,
+// 7^2 360 -> 349; SIMCLR_WGRAD_3X3=0 switches back (read per call so that a test can compare both in-process)
 static bool wgrad_use_3x3(int dtype, long long M, int Cin, int Cout, int KH, int KW, int stride, int pad, int IH, int IW,
                           int OH, int OW, int pixpitch) {
-  // SIMCLR_WGRAD_3X3: unset / 0 = off, 1 = every eligible layer (the parity test forces this), 2 = only layers with
-  // >= 500 K output pixels.  Stand-alone it is faster on the 56x56 / 28x28 layers (540 vs 653 us, 407 vs 460 us) and
-  // equal at 14x14, but the whole-step bench showed no gain (82.7 vs 81.5 ms, within noise) -> opt-in until the
-  // mask / LDS-read cost is cut further (profiles/r01_notes.md).
   const char* e = getenv("SIMCLR_WGRAD_3X3");
-  const int mode = e ? atoi(e) : 0;
-  if (mode <= 0) return false;
-  if (mode == 2 && M < 500000) return false;
+  if (e && atoi(e) <= 0) return false;
   return dtype == SIMCLR_DT_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && IH == OH && IW == OW &&
          Cin % 64 == 0 && Cout % 64 == 0 && (pixpitch * 2) % 16 == 0 && IW >= 7 && (64 + 2 * IW + 2 + 7) / 8 * 8 * 128 * 2 + 2 * 64 * 128 <= 160 * 1024;
 }
@@ -2620,8 +2627,8 @@ size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int C
   // the bf16 kernel variants reduce in chunks of 64 or 32 pixels: size for whichever needs more slabs
   int splits = wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps);
   splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, 32, &cps));
-  if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0)      // experimental multi-tap kernel: 64x64 tiles of all taps
-    splits = max(splits, wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 64, &cps));
+  if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0)      // nine-tap kernel: 64x64 tiles of all taps, up to 1024 ranges
+    splits = max(splits, wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 64, &cps, 1024, 2048));
   if (Cin == 32 && KH * KW * Cin <= 256 && Cout <= 64)            // stem: one 256-row k-tile, up to 1024 pixel ranges
     splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, 256, 64, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps, 1024, 1024));
   return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
@@ -2647,7 +2654,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     SIMCLR_CHECK_ARG(q.zero != nullptr, "conv2d_wgrad: zero page symbol not found");
     q.V = V; q.H = IH; q.W = IW; q.IC = Cin; q.N = Cout; q.pixpitch = pixpitch; q.M = p.M;
     q.ci_tiles = Cin / 64; q.co_tiles = Cout / 64;
-    q.splits = wgrad_splits(p.M, Cin, Cout, 64, 64, 64, &q.chunks_per_split);
+    // pixel ranges: ~1024 workgroups in total (2 resident per CU; SIMCLR_WGRAD3_BLOCKS overrides), at most 1024 ranges
+    const int want3 = getenv("SIMCLR_WGRAD3_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD3_BLOCKS")) : 1024;
+    q.splits = wgrad_splits(p.M, Cin, Cout, 64, 64, 64, &q.chunks_per_split, 1024, want3);
     q.hpp = (64 + 2 * IW + 2 + 7) / 8 * 8;
     const int tiles = q.ci_tiles * q.co_tiles;
     const int grid3 = tiles * ceil_div(q.splits, 8) * 8;

@@ -240,9 +240,12 @@ def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=N
     y = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
     M, K = V * OH * OW, KH * KW * Cin
     bits = torch.empty(M, Cout // 8, device=x.device, dtype=torch.uint8) if want_bits else None
-    nb = 2 * (V * IH * IW * Cin + M * Cout * (2 if res is not None else 1) + K * Cout) + (M * Cout // 8 if want_bits else 0)
+    # algorithmic bytes = SURVEY 8(d)'s strict count (input + output + weights); the residual read and the mask write of
+    # the fused epilogue (bn3's own traffic) are counted under impl_bytes only
+    nb = 2 * (V * IH * IW * Cin + M * Cout + K * Cout)
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, nb,
-            lambda: lib().conv2d_fwd_bn_apply(_p(x), _p(w_t), _p(y), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift),
+            impl_bytes=nb + (2 * M * Cout if res is not None else 0) + (M * Cout // 8 if want_bits else 0),
+            fn=lambda: lib().conv2d_fwd_bn_apply(_p(x), _p(w_t), _p(y), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift),
                                               int(relu), _p(bits), V,
                                               IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
     return (y, bits) if want_bits else y

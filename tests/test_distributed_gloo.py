@@ -95,3 +95,43 @@ def test_multi_replica_semantics_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == 'ok' for r in res), res
+
+
+def _worker_forced(q, port):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', SIMCLR_FORCE_COLLECTIVES='1')
+        dist.init_process_group('gloo', rank=0, world_size=1)
+        from simclr_amd import comm
+        st = comm.Strategy()
+        # one replica, collectives forced on: three distinct communicators, every collective legal and the identity
+        assert st.force and comm.collectives_on(st) and st.num_replicas_in_sync == 1
+        assert st.stat_group is not st.grad_group and st.stat_group is not st.group
+        z = torch.randn(12, 16)
+        assert torch.equal(comm.gather_hidden(z, st), z)
+        fin = comm.gather_hidden(z, st, async_op=True)
+        assert torch.equal(fin(), z)
+        assert torch.equal(comm.scatter_hidden_grad(z.clone(), st), z)
+        assert torch.equal(comm.scatter_hidden_grad(z.clone(), st, async_op=True)(), z)
+        s2 = torch.ones(2, 7, dtype=torch.float64)
+        a, b = st.all_reduce_sum_many([s2.clone(), 2 * s2])
+        assert torch.equal(a, s2) and torch.equal(b, 2 * s2)
+        assert st.hidden_collectives == 4 and st.stat_collectives == 1
+        os.environ.pop('SIMCLR_FORCE_COLLECTIVES')
+        assert not comm.collectives_on(None)
+        dist.destroy_process_group()
+        q.put('ok')
+    except Exception:  # noqa
+        import traceback
+        q.put('FAIL: ' + traceback.format_exc())
+
+
+def test_forced_collectives_with_one_replica():
+    """SIMCLR_FORCE_COLLECTIVES=1 (the switch the one-rank RCCL GPU test uses): the Strategy builds its three communicators
+    and issues every collective with a single replica; shapes and results are those of the identity."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_forced, args=(q, _free_port()))
+    p.start()
+    r = q.get(timeout=300)
+    p.join(timeout=60)
+    assert r == 'ok', r

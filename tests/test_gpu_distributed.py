@@ -213,3 +213,160 @@ def test_two_replica_bf16_resnet50_fused_tail_equals_single_replica():
             assert m['loss_rel'] < 2e-3, m
             assert m['grad_one_minus_cos'] < 2e-3, m
             assert m['grad_rel_l2'] < 6e-2, m
+
+
+def _worker_one_rank_rccl(q, port):
+    """ONE rank on the 'nccl' backend (= RCCL) with every collective forced on: all_gather_into_tensor and
+    reduce_scatter_tensor of the hidden block, the SyncBN all-reduces on their own communicator, the bucketed
+    asynchronous gradient all-reduce -- each is the identity with one rank, so the step must equal the strategy-free
+    step; what this buys is that none of those calls meets RCCL for the first time inside the multi-GPU bench."""
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                          SIMCLR_FORCE_COLLECTIVES='1')
+        from simclr_amd import model as model_lib
+        from simclr_amd.flags import FLAGS
+        from simclr_amd.resnet import RT
+        from simclr_amd.run import init_distributed, make_single_step
+        strategy = init_distributed()
+        assert strategy is not None and strategy.force and dist.get_backend() == 'nccl'
+        assert strategy.stat_group is not strategy.grad_group and strategy.stat_group is not strategy.group
+        depth, image_size, b, num_classes, lr = 18, 32, 16, 10, 0.1
+        g = torch.Generator().manual_seed(3)
+        images = torch.rand(b, image_size, image_size, 6, generator=g).cuda()
+        labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (b,), generator=g), num_classes).float().cuda()
+
+        def run(st):
+            FLAGS.reset()
+            FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='f32', use_blur=False, train_batch_size=b)
+            RT.reset()
+            RT.device = torch.device('cuda', 0)
+            RT.seed = 9
+            RT.strategy = st
+            model = model_lib.Model(num_classes)
+            step = make_single_step(model, model_lib.build_optimizer(lr), st)
+            out = step(images, {'labels': labels})
+            torch.cuda.synchronize()
+            return float(out['con_loss'].value.item()), torch.cat([v.grad.reshape(-1).double().cpu() for v in model._flat_order])
+        l_c, g_c = run(strategy)
+        res = dict(stat_collectives=strategy.stat_collectives, hidden_collectives=strategy.hidden_collectives)
+        # the raw collectives, shapes as the step issues them ([2n, 128] fp32 hidden block)
+        z = torch.randn(2 * b, 128, device='cuda')
+        ga = strategy.all_gather_concat(z)
+        rs, work = strategy.reduce_scatter_sum(z.clone(), async_op=True)
+        work.wait()
+        torch.cuda.synchronize()
+        res['gather_exact'] = bool(torch.equal(ga, z)) and bool(torch.equal(rs, z))
+        l_1, g_1 = run(None)
+        res['loss_rel'] = abs(l_c - l_1) / abs(l_1)
+        res['grad_rel_l2'] = float((g_c - g_1).norm() / g_1.norm())
+        dist.destroy_process_group()
+        q.put((0, 'ok', res))
+    except Exception:  # noqa
+        import traceback
+        q.put((0, 'FAIL', traceback.format_exc()))
+
+
+def test_rccl_collectives_with_one_rank():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one_rank_rccl, args=(q, _free_port()))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert res[1] == 'ok', res
+    m = res[2]
+    assert m['gather_exact'], m
+    assert m['hidden_collectives'] == 2 and m['stat_collectives'] > 20, m
+    # SyncBN sums go through fp64 [2, C] tensors instead of the fused slot reduction: same values up to fp32 rounding
+    assert m['loss_rel'] < 1e-5 and m['grad_rel_l2'] < 1e-3, m
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    """`python bench.py --gpus 2 --backend gloo`: the self-launch path (torch.distributed.run, one rank per process), the
+    N > 1 JSON line and the collective micro-benchmark, with both ranks on cuda:0 over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+           '--per_gpu_batch', '16', '--image_size', '64', '--no_cpu_baseline', '--no_f32', '--prof_steps', '1']
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 32
+    assert d['value'] > 0 and d['value'] == d['value'] and d['ms_per_step'] > 0
+    ag = d['allgather']
+    assert ag['ranks'] == 2 and ag['backend'] == 'gloo' and ag['bytes_gathered'] == 2 * ag['bytes_contributed'] and ag['us'] > 0
+    assert ag['grad_allreduce']['us'] > 0
+    assert ag['hidden_collectives_per_step'] == 2 and ag['stat_collectives_per_step'] > 50
+    assert d['roofline'] is not None and d['cpu_baseline'] is None
+
+
+def _worker_local_bn(rank, world, port, q):
+    """--global_bn=False with two replicas: every replica normalises with ITS OWN batch statistics, so a
+    replica's forward and gradients equal the single-replica step on its own shard except for the contrastive negatives;
+    here the check is on what the bug broke -- the fused tails' Gram-matrix statistics must be divided by the local row
+    count: the bf16 ResNet-50 step with fused tails must match the same step with SIMCLR_CONV3_FUSED=0."""
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from simclr_amd import comm
+        from simclr_amd import model as model_lib
+        from simclr_amd.flags import FLAGS
+        from simclr_amd.resnet import RT
+        from simclr_amd.run import make_single_step
+        depth, image_size, b, num_classes, lr = 50, 64, 8, 10, 0.1
+        g = torch.Generator().manual_seed(21 + rank)
+        images = torch.rand(b, image_size, image_size, 6, generator=g)
+        labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (b,), generator=g), num_classes).float()
+
+        def run(fused):
+            os.environ['SIMCLR_CONV3_FUSED'] = fused
+            FLAGS.reset()
+            FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='bf16', use_blur=False,
+                         train_batch_size=world * b, global_bn=False)
+            RT.reset()
+            RT.device = torch.device('cuda', 0)
+            RT.seed = 5
+            strategy = comm.Strategy()
+            RT.strategy = strategy
+            model = model_lib.Model(num_classes)
+            step = make_single_step(model, model_lib.build_optimizer(lr), strategy)
+            out = step(images.cuda(), {'labels': labels.cuda()})
+            torch.cuda.synchronize()
+            return (float(out['con_loss'].value.item()), torch.cat([v.grad.reshape(-1).double().cpu() for v in model._flat_order]),
+                    strategy.stat_collectives)
+        l2, g2, sc = run('2')
+        l0, g0, _ = run('0')
+        os.environ.pop('SIMCLR_CONV3_FUSED')
+        res = dict(loss_rel=abs(l2 - l0) / abs(l0), grad_one_minus_cos=1.0 - float(torch.dot(g2, g0) / (g2.norm() * g0.norm())),
+                   stat_collectives=sc)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok', res))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, 'FAIL', traceback.format_exc()))
+
+
+def test_two_replicas_without_global_bn_fused_tail_matches_unfused():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_local_bn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in res), res
+    for _, _, m in res:
+        assert m['stat_collectives'] == 0, m           # no statistic exchange without global BatchNorm
+        assert m['loss_rel'] < 2e-3 and m['grad_one_minus_cos'] < 5e-3, m

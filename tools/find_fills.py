@@ -1,32 +1,12 @@
-"""Debug aid: which Python call sites launch fill kernels (torch.zeros / zero_ / fill_ / full / ones) inside a training step.
-python tools/find_fills.py  -> prints call sites with counts for one steady-state step (ResNet-50, 64 px, batch 16)."""
-import collections
+"""Debug aid: which Python call sites launch torch's OWN device kernels (fills, copies, elementwise, reductions) inside a
+steady-state training step -- everything that is not a libsimclr_hip.so launch.
+python tools/find_fills.py  -> aten ops with device time, grouped by the top Python frames (ResNet-50, 64 px, batch 16)."""
 import os
 import sys
-import traceback
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-
-COUNTS = collections.Counter()
-ON = [False]
-
-
-def _wrap(owner, name):
-    orig = getattr(owner, name)
-
-    def f(*a, **k):
-        if ON[0]:
-            st = traceback.extract_stack(limit=4)[:-1]
-            COUNTS[(name,) + tuple('%s:%d' % (os.path.basename(s.filename), s.lineno) for s in st)] += 1
-        return orig(*a, **k)
-    setattr(owner, name, f)
-
-
-for n in ('zeros', 'zeros_like', 'full', 'ones', 'ones_like', 'full_like'):
-    _wrap(torch, n)
-for n in ('zero_', 'fill_', 'new_zeros'):
-    _wrap(torch.Tensor, n)
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 from simclr_amd import model as model_lib  # noqa: E402
 from simclr_amd.flags import FLAGS  # noqa: E402
@@ -43,8 +23,20 @@ step = make_single_step(model, opt, None)
 x = torch.rand(16, 64, 64, 6, device=dev)
 lab = torch.nn.functional.one_hot(torch.randint(0, 10, (16,), device=dev), 10).float()
 for i in range(3):
-    ON[0] = i == 2
     step(x, {'labels': lab})
 torch.cuda.synchronize()
-for k, v in COUNTS.most_common(20):
-    print(v, k)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step(x, {'labels': lab})
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_stack_n=6):
+    dt = getattr(e, 'device_time_total', 0) or getattr(e, 'cuda_time_total', 0)
+    if not e.key.startswith('aten::') or dt <= 0:
+        continue
+    own = [s for s in e.stack if 'simclr_amd' in s or 'bench.py' in s][:3]
+    rows.append((e.count, dt, e.key, ' <- '.join(s.split('/')[-1] for s in own)))
+rows.sort(key=lambda r: -r[0])
+tot = sum(r[0] for r in rows)
+print('aten ops with device kernels in one step: %d' % tot)
+for c, dt, k, st in rows[:60]:
+    print('%4d x %-28s %8.1f us  %s' % (c, k, dt, st))
