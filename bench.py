@@ -345,8 +345,10 @@ def main():
         # HBM traffic per launch of the same kernel family: from the committed rocprofv3 --pmc passes (FETCH_SIZE /
         # WRITE_SIZE collected separately, FETCH x2 for wide loads); PMC counters cannot be sampled from inside this
         # process, so this stays null unless the committed file describes this family, configuration and launch count
-        tpath = os.path.join(HERE, 'profiles', 'r02_pmc_traffic.json')
-        if default_cfg and args.dtype == 'bf16' and os.path.exists(tpath):
+        import glob
+        cands = sorted(glob.glob(os.path.join(HERE, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))
+        tpath = cands[-1] if cands else ''
+        if default_cfg and args.dtype == 'bf16' and tpath:
             try:
                 tj = json.load(open(tpath))
                 # PMC bytes of the family per STEP (committed rocprofv3 passes of this same command) divided by THIS
@@ -355,7 +357,7 @@ def main():
                 if tj.get('kernel') == best and tj.get('family_bytes_per_step'):
                     per_launch = tj['family_bytes_per_step'] / max(roofline['launches_per_step'], 1)
                     roofline['traffic'] = round(per_launch)
-                    roofline['traffic_source'] = 'profiles/r02_pmc_traffic.json'
+                    roofline['traffic_source'] = 'profiles/' + os.path.basename(tpath) + ' (committed rocprofv3 --pmc passes of this command; not sampled in this run)'
                     roofline['traffic_kernel_dispatches_per_step'] = tj.get('kernel_dispatches_per_step')
                     roofline['traffic_over_algorithmic'] = round(per_launch / roofline['algorithmic_bytes_per_launch'], 3)
             except Exception:

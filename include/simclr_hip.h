@@ -232,6 +232,12 @@ int simclr_colsum(const void* x, int rows, int C, int cvalid, float* out, int ac
 int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out, simclr_stream_t stream);
 /* y += a*x: gradient of the supervised head's L2 term (tf2/model.py:49-60, run.py:609-612) */
 int simclr_axpy_f32(float a, const float* x, float* y, long long n, simclr_stream_t stream);
+/* Metric bookkeeping of one step in one launch (tf2/run.py:587-613: update_pretrain_metrics_train, update_finetune_metrics_train,
+ * weight_decay, total_loss = the sum of the loss terms).  src: HOST array of n <= 16 device scalar pointers, scale: host array
+ * of n factors (NULL = 1): dst[i] += scale[i] * *src[i] (dst NULL: skipped); total (nullable) receives the sum of the scaled
+ * terms whose bit is set in total_mask. */
+int simclr_accumulate_scalars(const float* const* src, const float* scale, int n, float* dst, float* total,
+                              int total_mask, simclr_stream_t stream);
 int simclr_l2_loss_f32(const float* x, long long n, float* out, simclr_stream_t stream); /* tf.nn.l2_loss, model.py:49-60 */
 
 /* ---- BatchNorm backward FOLDED into the convolution that produced the BN's input (1x1 expand convs, K <= N): what

@@ -69,6 +69,9 @@ struct ConvP {
   const void* zero;  // 16 zero bytes in device memory (source of padding chunks for direct-to-LDS loads):
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
+  int skew;        // start delay (units of 256 clocks) of the second half of the persistent grid -- the workgroups that
+                   // share CUs with the first half: their row-wise epilogues (fused BatchNorm work, latency-bound global
+                   // operands) then fall into the other workgroup's MFMA phase instead of coinciding with its epilogue
 };
 
 // Diagnostic build (build.sh diag -> libsimclr_hip_diag.so): parts of a kernel can be switched off at run time
@@ -592,6 +595,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   }
   if (WSUM && STATS && LDS_EPI) {
     for (int i = lane; i < BN; i += 64) wred[wave * BN + i] = make_float2(0.f, 0.f);     // own slot: ordered by program order
+  }
+  if ((BNEPI || FAPPLY) && p.skew > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(4);
   }
   // row-wise epilogue state: this thread's fixed 8-channel chunk and its partial sums
   const int e_cc = tid % CPR;
@@ -1941,7 +1947,10 @@ struct StemP {
   int V, HP, WP, OH, OW, N, KHP, KWP, stride, M, KP, nslot, m_tiles;
 };
 
-template <typename T, bool STATS>
+// KS > 0 (the 7x7 stem in bf16: 7 k-steps, one padded kernel row of 8 taps x 4 channels each): the k-loop is unrolled and
+// all 14 activation fragments of a tile are requested before the first MFMA -- one L1/L2 round trip per tile instead of
+// one per kernel row (the runtime loop exposed the load latency seven times per tile).
+template <typename T, bool STATS, int KS = 0>
 __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int KSTEP = 4 * EPC;     // elements per MFMA k-step
@@ -1993,6 +2002,22 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (KS > 0) {
+      u32x4 afk[KS > 0 ? KS : 1][2];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          afk[ks][i] = ok[i] ? ld16(X + base[i] + (long long)ks * p.WP * 4 + g * EPC) : zero16();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const u32x4 bf = *(const u32x4*)(smem + (ni * 16 + fl) * pitch + (ks * 4 + g) * 16);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = MMA<T>::run(bf, afk[ks][mi], acc[ni][mi]);
+        }
+    } else
     for (int ks = 0; ks < ksteps; ++ks) {
       const int e = ks * KSTEP + g * EPC;          // element offset along padded K
       const int kh = e / row_elems, within = e - kh * row_elems;
@@ -2224,7 +2249,14 @@ static bool igemm_use_256(const ConvP& p, bool fwd) {
   if (p.KH != 1 || p.KW != 1 || p.M < 150000) return false;
   if (p.bn_mode && !p.fapply) return false;          // fused BN-backward reduce epilogue
   if (fwd && !p.fapply && p.stats && p.K < 128) return false;
-  return true;
+  // classes (SIMCLR_IGEMM_256_CLASSES, bit mask): 1 = forward with the fused BatchNorm-apply epilogue, 2 = other forward
+  // launches, 4 = plain / K-extended dgrad.  Default 0: inside the training step the wide tile LOSES although every class
+  // wins stand-alone (69.45 vs 67.0 ms/step, interleaved on one box, profiles/r03_notes.md) -- a 151 KB workgroup needs a
+  // whole CU's LDS, so it cannot start until the previous kernel has drained from that CU and nothing can start beside it.
+  const char* c = getenv("SIMCLR_IGEMM_256_CLASSES");
+  const int classes = c ? atoi(c) : 0;
+  const int cls = p.fapply ? 1 : (fwd ? 2 : 4);
+  return (classes & cls) != 0;
 }
 
 template <typename T, int MODE>
@@ -2250,6 +2282,12 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     // persistent grid: 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one per tile
     int bn_, nt_, pg;
     igemm_persistent_grid(p.M, p.N, &bn_, &nt_, &pg);
+    {   // SIMCLR_EPI_SKEW=f: second-half workgroups start f * (k-tiles + 6) * 256 clocks late (about f half tile times)
+      const char* e = getenv("SIMCLR_EPI_SKEW");
+      const float f = e ? (float)atof(e) : 0.f;
+      const int kt = p.ntaps * (p.IC / (sizeof(T) == 2 ? 64 : 32)) + (p.x2 ? p.ic2 / (sizeof(T) == 2 ? 64 : 32) : 0);
+      p.skew = (f > 0.f && pg >= 512) ? (int)(f * (kt + 6)) : 0;
+    }
     const size_t plds = 2 * (128 + BN) * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long);
     // 256 x 256 tile, 8 waves of 128 x 64 (one workgroup per CU): half the L2->LDS bytes per FLOP of the 128 x 128 tile
     // (which needs 64 B/clk/CU from L2 at the MFMA peak -- more than an XCD's L2 delivers) and 0.375 instead of 0.5 KB
@@ -2627,8 +2665,8 @@ size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int C
   // the bf16 kernel variants reduce in chunks of 64 or 32 pixels: size for whichever needs more slabs
   int splits = wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps);
   splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, 32, &cps));
-  if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0)      // nine-tap kernel: 64x64 tiles of all taps, up to 1024 ranges
-    splits = max(splits, wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 64, &cps, 1024, 2048));
+  if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0)      // nine-tap kernel: 64x64 tiles of all taps, up to 2048 ranges
+    splits = max(splits, wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 64, &cps, 2048, 4096));
   if (Cin == 32 && KH * KW * Cin <= 256 && Cout <= 64)            // stem: one 256-row k-tile, up to 1024 pixel ranges
     splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, 256, 64, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps, 1024, 1024));
   return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
@@ -2654,9 +2692,13 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     SIMCLR_CHECK_ARG(q.zero != nullptr, "conv2d_wgrad: zero page symbol not found");
     q.V = V; q.H = IH; q.W = IW; q.IC = Cin; q.N = Cout; q.pixpitch = pixpitch; q.M = p.M;
     q.ci_tiles = Cin / 64; q.co_tiles = Cout / 64;
-    // pixel ranges: ~1024 workgroups in total (2 resident per CU; SIMCLR_WGRAD3_BLOCKS overrides), at most 1024 ranges
-    const int want3 = getenv("SIMCLR_WGRAD3_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD3_BLOCKS")) : 1024;
-    q.splits = wgrad_splits(p.M, Cin, Cout, 64, 64, 64, &q.chunks_per_split, 1024, want3);
+    // pixel ranges (SIMCLR_WGRAD3_BLOCKS overrides the total workgroup target), at most 2048 ranges
+    // measured (us at 1024 views, targets 512 / 768 / 1024 / 1536 / 2048): 56^2 437 517 434 425 418 | 28^2 362 440 370 450
+    // 507 | 14^2 323 379 344 371 515 | 7^2 295 311 312 340 378 -> one full round of 512 (2 per CU), more ranges only
+    // for the single-tile 64 -> 64 layer; partial rounds (768, 1536) are the worst choice
+    const int tiles3 = (Cin / 64) * (Cout / 64);
+    const int want3 = getenv("SIMCLR_WGRAD3_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD3_BLOCKS")) : (tiles3 == 1 ? 2048 : 512);
+    q.splits = wgrad_splits(p.M, Cin, Cout, 64, 64, 64, &q.chunks_per_split, 2048, want3);
     q.hpp = (64 + 2 * IW + 2 + 7) / 8 * 8;
     const int tiles = q.ci_tiles * q.co_tiles;
     const int grid3 = tiles * ceil_div(q.splits, 8) * 8;
@@ -2838,7 +2880,11 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
   const size_t lds = 64 * (p.KP * esz + 16) + 4 * 64 * 2 * sizeof(float) + (esz == 2 ? 128 * 64 * 2 : 0);
   dim3 grid(min(p.m_tiles, 2048), ceil_div(Cout, 64));
   if (dtype == SIMCLR_DT_BF16) {
-    if (stats) hipLaunchKernelGGL((stem_conv_fwd<uint16_t, true>), grid, dim3(256), lds, stream, p);
+    static const bool unroll_on = !getenv("SIMCLR_STEM_UNROLL") || atoi(getenv("SIMCLR_STEM_UNROLL")) != 0;
+    if (unroll_on && KWP * 4 == 32 && p.KP == 7 * 32) {      // one k-step = one padded kernel row, 7 rows
+      if (stats) hipLaunchKernelGGL((stem_conv_fwd<uint16_t, true, 7>), grid, dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((stem_conv_fwd<uint16_t, false, 7>), grid, dim3(256), lds, stream, p);
+    } else if (stats) hipLaunchKernelGGL((stem_conv_fwd<uint16_t, true>), grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((stem_conv_fwd<uint16_t, false>), grid, dim3(256), lds, stream, p);
   } else {
     if (stats) hipLaunchKernelGGL((stem_conv_fwd<float, true>), grid, dim3(256), lds, stream, p);

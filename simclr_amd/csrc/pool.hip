@@ -604,6 +604,26 @@ __global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long l
 }
 
 // y = a*x + y  (fp32) ; also returns nothing.  Used for the sup-head L2 term (tf2/model.py:49-60)
+// dst[i] += scale[i] * *src[i] for up to 16 device scalars in one launch, and optionally total[0] = the sum of the scaled
+// terms whose bit is set in total_mask: the running metric sums and the total loss of a training step
+// (tf2/run.py:587-613, tf2/metrics.py) without one tiny elementwise launch per scalar.
+struct ScalarsP {
+  const float* src[16];
+  float scale[16];
+};
+__global__ void accumulate_scalars(const ScalarsP p, int n, float* __restrict__ dst, float* __restrict__ total,
+                                   unsigned total_mask) {
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float v = p.scale[i] * *p.src[i];
+      if (dst) dst[i] += v;
+      if ((total_mask >> i) & 1u) t += v;
+    }
+    if (total) total[0] = t;
+  }
+}
+
 __global__ void axpy_f32(float a, const float* __restrict__ x, float* __restrict__ y, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
@@ -914,6 +934,20 @@ int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out
     hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, n);
   else
     hipLaunchKernelGGL((cast_kernel<uint16_t, uint16_t>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, n);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+int simclr_accumulate_scalars(const float* const* src, const float* scale, int n, float* dst, float* total,
+                              int total_mask, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(n >= 1 && n <= 16 && src, "accumulate_scalars: n=%d must be in [1, 16]", n);
+  ScalarsP p = {};
+  for (int i = 0; i < n; ++i) {
+    SIMCLR_CHECK_ARG(src[i] != nullptr, "accumulate_scalars: null source %d", i);
+    p.src[i] = src[i];
+    p.scale[i] = scale ? scale[i] : 1.f;
+  }
+  hipLaunchKernelGGL(accumulate_scalars, dim3(1), dim3(64), 0, stream, p, n, dst, total, (unsigned)total_mask);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -11,11 +11,22 @@ import torch
 class Mean:
     def __init__(self, name):
         self.name = name
+        self._bank = None
         self.reset_states()
 
     def reset_states(self):
         self._sum = None
         self._count = 0
+        if getattr(self, '_bank', None) is not None:
+            self._bank[0][self._bank[1]] = 0.0
+
+    def attach(self, sums, index):
+        """Batched bookkeeping (run.make_single_step): this metric's running sum is element `index` of the device tensor
+        `sums`, which ONE simclr_accumulate_scalars launch per step updates for all metrics; `bump()` counts the update."""
+        self._bank = (sums, index)
+
+    def bump(self):
+        self._count += 1
 
     def update_state(self, value):
         if hasattr(value, 'value'):
@@ -29,7 +40,10 @@ class Mean:
     def result(self):
         if self._count == 0:
             return 0.0
-        return float(self._sum.item()) / self._count
+        tot = float(self._sum.item()) if self._sum is not None else 0.0
+        if getattr(self, '_bank', None) is not None:
+            tot += float(self._bank[0][self._bank[1]].item())
+        return tot / self._count
 
 
 class Accuracy:

@@ -42,10 +42,16 @@ def add_weight_decay(model, adjust_per_optimizer=True):
         vs = [v for v in model.trainable_variables if 'batch_normalization' not in v.name]
     if not vs:
         return 0
-    out = torch.zeros(len(vs), device=vs[0].value.device, dtype=torch.float32)
+    nv = len(vs)
+    out = ops.step_scalars(nv + 1, vs[0].value.device)
     for i, v in enumerate(vs):
         ops.l2_loss_f32(v.value, out[i:i + 1])          # tf.nn.l2_loss = sum(v^2)/2
-    return FLAGS.weight_decay * out.sum()
+    if nv > 16:                                         # SGD / Adam: every non-BN variable contributes
+        return FLAGS.weight_decay * out[:nv].sum()
+    # weight_decay * add_n(l2 losses) (:58-60 / :66-68) in one launch
+    ops.accumulate_scalars([out[j:j + 1] for j in range(nv)], scales=[FLAGS.weight_decay] * nv, total=out[nv:nv + 1],
+                           total_mask=(1 << nv) - 1)
+    return out[nv]
 
 
 def get_train_steps(num_examples):

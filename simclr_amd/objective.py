@@ -149,6 +149,25 @@ def add_contrastive_loss(hidden, hidden_norm=True, temperature=1.0, strategy=Non
     return loss, logits_con, labels_con
 
 
+_CLASS_ID_CACHE = {}
+
+
+def _class_ids(labels):
+    """int32 class ids of a one-hot (or already integer) label tensor; cached per (storage, version), so a batch whose
+    labels are reused (both views, several steps of a resident pool) is converted once."""
+    key = (labels.data_ptr(), tuple(labels.shape), labels.dtype, labels._version)
+    hit = _CLASS_ID_CACHE.get(key)
+    if hit is not None and hit[0]() is labels:
+        return hit[1]
+    ids = labels.argmax(1) if labels.dim() == 2 else labels
+    ids = ids.to(torch.int32).contiguous()
+    if len(_CLASS_ID_CACHE) > 64:
+        _CLASS_ID_CACHE.clear()
+    import weakref
+    _CLASS_ID_CACHE[key] = (weakref.ref(labels), ids)
+    return ids
+
+
 def add_supervised_loss(labels, logits):
     """Compute mean supervised loss over local batch (tf2/objective.py:27-32).
 
@@ -156,10 +175,8 @@ def add_supervised_loss(labels, logits):
     it holds b rows and the logits 2b, the labels are reused for both views (tf2/run.py:599-600).
     logits: model.SupLogits.  Returns a loss scalar with .backward() -> dlogits and `.acc`.
     """
-    if labels.dim() == 2:
-        labels = labels.argmax(1)
-    labels = labels.to(torch.int32).contiguous()
-    out = torch.zeros(2, device=logits.z.device, dtype=torch.float32)
+    labels = _class_ids(labels)
+    out = ops.step_scalars(2, logits.z.device)
     gscale = 1.0 / num_replicas(RT.strategy)                    # loss / R, tf2/run.py:617
     dlogits = ops.bias_softmax_xent(logits.z, logits.bias, labels, logits.num_classes, gscale, out)
     loss = _Loss(out[0:1], lambda grad_scale=None: dlogits)

@@ -118,7 +118,7 @@ def ntxent_fwd(z_local, z_all, rank, temperature, ws=None):
     D = z_local.shape[1]
     if ws is None:
         ws = ntxent_workspace(n, N, D, z_local.device)
-    out = torch.zeros(4, device=z_local.device, dtype=torch.float32)
+    out = step_scalars(4, z_local.device)
     row_stats = torch.empty(2 * n, 2, device=z_local.device, dtype=torch.float32)
     _launch('ntxent_fwd', 8.0 * n * N * D, 4.0 * (2 * n + 2 * N) * D,
             lambda: lib().ntxent_fwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(out), _p(row_stats),
@@ -618,6 +618,23 @@ def cast(x, dtype, out=None):
 
 def axpy_f32(a, x, y):
     lib().axpy_f32(float(a), _p(x), _p(y), x.numel(), _s())
+
+
+def step_scalars(n, device):
+    """n zeroed fp32 scalars that live until the next begin_step (a slice of the per-step arena: no fill launch); outside
+    a step a fresh zero tensor."""
+    t = _ARENA.take(n, device)
+    return t if t is not None else torch.zeros(n, device=device, dtype=torch.float32)
+
+
+def accumulate_scalars(srcs, dst=None, scales=None, total=None, total_mask=0):
+    """dst[i] += scales[i] * srcs[i][0] for up to 16 device scalars in ONE launch; total[0] = sum of the scaled terms
+    selected by total_mask (simclr_accumulate_scalars)."""
+    import ctypes
+    n = len(srcs)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    sc = (ctypes.c_float * n)(*[float(x) for x in scales]) if scales is not None else None
+    lib().accumulate_scalars(ptrs, sc, n, _p(dst), _p(total), int(total_mask), _s())
 
 
 def l2_loss_f32(x, out):

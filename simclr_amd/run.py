@@ -129,21 +129,34 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
         RT.weights_version += 1
         ops.end_step()
 
-        # ---- metrics (device scalars, no sync): tf2/run.py:587-613 ----
+        # ---- metrics (device scalars, no sync): tf2/run.py:587-613 -- update_pretrain_metrics_train,
+        # update_finetune_metrics_train, weight_decay and total_loss = the sum of the loss terms, in two launches:
+        # total first, then every running sum (metrics.Mean.attach / bump)
+        if state.get('bank') is None or state['bank'].device != features.device:
+            state['bank'] = torch.zeros(16, device=features.device, dtype=torch.float32)
+            state['zero'] = torch.zeros(1, device=features.device, dtype=torch.float32)
+            for i, name in enumerate(sorted(m)):
+                m[name].attach(state['bank'], i)
+        order = sorted(m)
+        wd_t = weight_decay.reshape(-1)[:1] if torch.is_tensor(weight_decay) else state['zero']
+        total = torch.empty(1, device=features.device, dtype=torch.float32)
+        terms = [wd_t] + ([con_loss.value.reshape(-1)[:1]] if con_loss is not None else []) + \
+                ([sup_loss.value.reshape(-1)[:1]] if sup_loss is not None else [])
+        ops.accumulate_scalars(terms, total=total, total_mask=(1 << len(terms)) - 1)
+        vals = {'train/weight_decay': wd_t, 'train/total_loss': total}
         if con_loss is not None:
-            metrics.update_pretrain_metrics_train(m['train/contrast_loss'], m['train/contrast_acc'],
-                                                  m['train/contrast_entropy'], con_loss, logits_con, labels_con)
+            vals['train/contrast_loss'] = con_loss.value.reshape(-1)[:1]
+            vals['train/contrast_acc'] = logits_con.contrast_acc.reshape(-1)[:1]
+            vals['train/contrast_entropy'] = logits_con.contrast_entropy.reshape(-1)[:1]
         if sup_loss is not None:
-            metrics.update_finetune_metrics_train(m['train/supervised_loss'], m['train/supervised_acc'],
-                                                  sup_loss, None, None)
-        wd_t = weight_decay if torch.is_tensor(weight_decay) else torch.tensor(float(weight_decay))
-        m['train/weight_decay'].update_state(wd_t)
-        total = wd_t.reshape(-1)[:1].to(features.device)
-        if con_loss is not None:
-            total = total + con_loss.value
-        if sup_loss is not None:
-            total = total + sup_loss.value
-        m['train/total_loss'].update_state(total)
+            vals['train/supervised_loss'] = sup_loss.value.reshape(-1)[:1]
+            vals['train/supervised_acc'] = sup_loss.acc.reshape(-1)[:1]
+        names = [nm for nm in order if nm in vals]
+        # one launch: bank[index(name)] += value(name); the metrics absent this step keep their sums
+        srcs = [vals.get(nm, state['zero']) for nm in order]
+        ops.accumulate_scalars(srcs, dst=state['bank'])
+        for nm in names:
+            m[nm].bump()
         return dict(con_loss=con_loss, sup_loss=sup_loss, weight_decay=weight_decay, total_loss=total,
                     logits_con=logits_con if con_loss is not None else None)
 

@@ -497,7 +497,7 @@ def check_avgpool2(V, H, C, stride, dtype, seed=0):
 
 def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_classes=10, seed=0,
                      weight_decay=1e-4, lr=0.1, steps=1, randomize_bn=True, sk_ratio=0.0, width_multiplier=1,
-                     proj_out_dim=128):
+                     proj_out_dim=128, inputs='iid'):
     """Full pretraining steps: HIP path vs the torch-CPU oracle restating tf2/run.py:557-622 on
     identical weights and inputs.
 
@@ -568,7 +568,11 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
             for v in model._flat_order:
                 optimizer.get_slot(v, 'Momentum').copy_(momenta[v.name].to(DEV))
         RT.weights_version += 1
-        images = torch.rand(batch, image_size, image_size, 6, generator=g)
+        # 'structured': image-like inputs (check_train_step_fixed) -- i.i.d. noise images are statistically identical, and a
+        # deep untrained network maps them to nearly the same feature: every BatchNorm then normalises a mean hundreds of
+        # standard deviations away from zero, which no fp32 sum-of-squares statistic survives
+        images = (torch.rand(batch, image_size, image_size, 6, generator=g) if inputs == 'iid'
+                  else structured_images(batch, image_size, 2, g))
         labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes).float()
         p64 = OrderedDict((k, v.double()) for k, v in params.items())
         s64 = OrderedDict((k, v.double()) for k, v in state.items())
