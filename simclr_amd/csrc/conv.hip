@@ -69,9 +69,6 @@ struct ConvP {
   const void* zero;  // 16 zero bytes in device memory (source of padding chunks for direct-to-LDS loads):
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
-  int skew;        // start delay (units of 256 clocks) of the second half of the persistent grid -- the workgroups that
-                   // share CUs with the first half: their row-wise epilogues (fused BatchNorm work, latency-bound global
-                   // operands) then fall into the other workgroup's MFMA phase instead of coinciding with its epilogue
 };
 
 // Diagnostic build (build.sh diag -> libsimclr_hip_diag.so): parts of a kernel can be switched off at run time
@@ -596,9 +593,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   if (WSUM && STATS && LDS_EPI) {
     for (int i = lane; i < BN; i += 64) wred[wave * BN + i] = make_float2(0.f, 0.f);     // own slot: ordered by program order
   }
-  if ((BNEPI || FAPPLY) && p.skew > 0 && blockIdx.x >= (gridDim.x >> 1)) {
-    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(4);
-  }
   // row-wise epilogue state: this thread's fixed 8-channel chunk and its partial sums
   const int e_cc = tid % CPR;
   float e_s[8], e_q[8];
@@ -664,6 +658,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       if (issued < total) issue_next();
   }
   for (int ct = 0; ct < count; ++ct) {
+    const int m0 = (mslot + ct * mslots) * BM;
+    // FAPPLY, flat (1x1 stride-1) layers: the residual rows of this tile's row-wise epilogue are requested NOW, so their
+    // HBM latency runs under the k-loop instead of being exposed between the two epilogue barriers (K = 64 ... 512:
+    // these layers are pure streaming, and the epilogue's loads were the only bytes in flight during that phase)
+    constexpr bool PFX = FAPPLY && BM == 128;
+    constexpr int PER = PFX ? BM / RPP : 1;
+    u32x4 pf_x[PER];
+    const bool pf_on = PFX && flat && p.bn_x != nullptr && !(p.fapply & 2);
+    if (pf_on) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int m = m0 + tid / CPR + i * RPP;
+        const bool ok = m < p.M && n0 + e_cc * 8 < p.N;
+        pf_x[i] = *(const u32x4*)((const uint16_t*)p.bn_x + (ok ? (long long)m * p.N + n0 + e_cc * 8 : 0));
+      }
+    }
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -771,7 +781,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       buf = (buf + 1 == STAGES) ? 0 : buf + 1;
       ++consumed;
     }
-    const int m0 = (mslot + ct * mslots) * BM;
     if (DIAG(4)) {
       if (acc[0][0][0] == 12345.678f) Y[0] = (T)0;     // keeps the accumulators live
       continue;
@@ -839,8 +848,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
       }
       if (FAPPLY && p.bn_x) {          // residual operand of the fused BatchNorm apply
+        if (PFX && pf_on) {
 #pragma unroll
-        for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
+          for (int i = 0; i < ER; ++i) e_xv[i] = pf_x[PFX ? i : 0];
+        } else {
+#pragma unroll
+          for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
+        }
       }
       if (BNEPI) {
         if (p.bn_mode != 4) {
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       }
 #pragma unroll
       for (int i = 0; i < ER; ++i) {
-        if (!(ROWSTATS && !BNEPI) && !erok[i]) continue;
+        if (!FAPPLY && !(ROWSTATS && !BNEPI) && !erok[i]) continue;
         const int r = tid / CPR + (eb + i) * RPP;
         const u32x4 cv = *(const u32x4*)(Cs + r * (BN * 2) + (((e_cc * 2) ^ ((r & 7) << 1)) << 3));
         uint16_t* dst = (uint16_t*)Y + eoff[i];
@@ -883,14 +897,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
             v[e] = p.bn_mode ? fmaxf(o, 0.f) : o;          // bn_mode doubles as the ReLU flag here
           }
           const u32x4 packed = f32_to_chunk<uint16_t>(v);
-          *(u32x4*)dst = packed;
+          const bool ok = erok[i];                          // invalid rows run along (wave-wide shuffles below), store nothing
+          if (ok) *(u32x4*)dst = packed;
           if (p.bn_mask) {                                  // bit e = (stored y[e] > 0), one byte per 16-byte chunk
             float w8[8];
             chunk_to_f32<uint16_t>(packed, w8);
             unsigned bits = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) bits |= (w8[e] > 0.f ? 1u : 0u) << e;
-            ((unsigned char*)p.bn_mask)[eoff[i] >> 3] = (unsigned char)bits;
+            if ((p.N & 31) == 0) {
+              // four neighbouring lanes hold four consecutive mask bytes of one row (validity is uniform over such a
+              // group when N is a multiple of 32): one aligned 4-byte store instead of four 1-byte stores
+              const unsigned b1 = __shfl_down(bits, 1, 64), b2 = __shfl_down(bits, 2, 64), b3 = __shfl_down(bits, 3, 64);
+              if (ok && (e_cc & 3) == 0)
+                *(unsigned*)((unsigned char*)p.bn_mask + (eoff[i] >> 3)) = bits | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            } else if (ok) {
+              ((unsigned char*)p.bn_mask)[eoff[i] >> 3] = (unsigned char)bits;
+            }
           }
           continue;
         }
@@ -2282,12 +2305,6 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     // persistent grid: 2-3 workgroups per CU, rounded to a multiple of 8*n_tiles, at most one per tile
     int bn_, nt_, pg;
     igemm_persistent_grid(p.M, p.N, &bn_, &nt_, &pg);
-    {   // SIMCLR_EPI_SKEW=f: second-half workgroups start f * (k-tiles + 6) * 256 clocks late (about f half tile times)
-      const char* e = getenv("SIMCLR_EPI_SKEW");
-      const float f = e ? (float)atof(e) : 0.f;
-      const int kt = p.ntaps * (p.IC / (sizeof(T) == 2 ? 64 : 32)) + (p.x2 ? p.ic2 / (sizeof(T) == 2 ? 64 : 32) : 0);
-      p.skew = (f > 0.f && pg >= 512) ? (int)(f * (kt + 6)) : 0;
-    }
     const size_t plds = 2 * (128 + BN) * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long);
     // 256 x 256 tile, 8 waves of 128 x 64 (one workgroup per CU): half the L2->LDS bytes per FLOP of the 128 x 128 tile
     // (which needs 64 B/clk/CU from L2 at the MFMA peak -- more than an XCD's L2 delivers) and 0.375 instead of 0.5 KB
@@ -2479,7 +2496,8 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
   p.M = V * OH * OW; p.K = KH * KW * Cin;
-  p.fapply = 1; p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
+  p.fapply = (getenv("SIMCLR_FAPPLY_PF") && atoi(getenv("SIMCLR_FAPPLY_PF")) == 0) ? 3 : 1;    // bit 1: no early residual loads (A/B switch)
+  p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
   p.bn_mean = rscale; p.bn_rstd = rshift;
   launch_igemm<uint16_t, MODE_FWD>(p, stream);
   SIMCLR_CHECK_LAUNCH();

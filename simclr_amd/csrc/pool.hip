@@ -108,6 +108,43 @@ __global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict_
     // windows that contain (iy, ix): oy*stride - pad_t <= iy <= oy*stride - pad_t + ksz - 1  (at most
     // ceil(ksz/stride)^2 of them -- 4 for the 3x3 stride-2 stem pool), enumerated directly
     const int ty = iy + pad_t, tx = ix + pad_l;
+    if (ksz == 3 && stride == 2) {
+      // the stem pool: at most 2 x 2 windows contain a pixel.  All four candidates are requested back to back from
+      // clamped addresses (8 loads in flight per thread) and the invalid ones are masked afterwards -- the loop below
+      // issues its loads one dependent round trip at a time.  Same order of additions: (hi,hi) (hi,lo) (lo,hi) (lo,lo).
+      const int oy1 = ty >> 1, ox1 = tx >> 1;
+      int oys[2] = {oy1, oy1 - 1}, oxs[2] = {ox1, ox1 - 1};
+      bool vy[2] = {oy1 <= OH - 1, oy1 >= 1 && (ty & 1) == 0}, vx[2] = {ox1 <= OW - 1, ox1 >= 1 && (tx & 1) == 0};
+      u32x4 dv[4];
+      uint32_t av[4][EPC / 4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int oy = min(max(oys[a], 0), OH - 1), ox = min(max(oxs[b], 0), OW - 1);
+          const long long op = (((long long)v * OH + oy) * OW + ox) * C + c0;
+          dv[a * 2 + b] = *(const u32x4*)(dy + op);
+          const uint32_t* ap = (const uint32_t*)(arg + op);
+#pragma unroll
+          for (int q = 0; q < EPC / 4; ++q) av[a * 2 + b][q] = ap[q];
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (!(vy[a] && vx[b])) continue;
+          const uint32_t tapid = (uint32_t)((ty - oys[a] * 2) * 3 + (tx - oxs[b] * 2));
+          float d[EPC];
+          chunk_to_f32<T>(dv[a * 2 + b], d);
+#pragma unroll
+          for (int q = 0; q < EPC / 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (((av[a * 2 + b][q] >> (8 * e)) & 0xffu) == tapid) acc[4 * q + e] += d[4 * q + e];
+        }
+      *(u32x4*)(dx + (long long)pix * C + c0) = f32_to_chunk<T>(acc);
+      continue;
+    }
     const int oy_hi = min(OH - 1, ty / stride), ox_hi = min(OW - 1, tx / stride);
     const int oy_lo = max(0, (ty - ksz + stride) / stride), ox_lo = max(0, (tx - ksz + stride) / stride);
     for (int oy = oy_hi; oy >= oy_lo; --oy) {          // ky ascending, kx ascending: fixed summation order

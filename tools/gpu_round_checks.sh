@@ -17,7 +17,7 @@ if [ "$MODE" = "quick" ]; then
   python -c "import json,sys;d=json.load(open('$OUT/bench_quick.json'));print(d['value'],d['ms_per_step']);[print(k,v) for k,v in d['kernels'].items()]"
   exit 0
 fi
-timeout 1200 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -4 "$OUT/pytest_gpu.log"
+timeout 2400 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -4 "$OUT/pytest_gpu.log"; grep -n "^FAILED" "$OUT/pytest_gpu.log" | head
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
 timeout 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-300 "$OUT/bench.json" | tail -1
 timeout 300 python tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.txt" 2>&1
@@ -28,4 +28,20 @@ rm -f "$OUT"/*kernel_trace.csv
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --steps 1 --warmup 1 > "$OUT/pmc_f.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --steps 1 --warmup 1 > "$OUT/pmc_w.log" 2>&1
 gzip -f "$OUT"/pmc_f/*counter_collection.csv "$OUT"/pmc_w/*counter_collection.csv 2>/dev/null
+# north_star: rocprof-reported HBM traffic of the NT-Xent kernels (cfg2 and cfg3 shapes: tools/microbench.py --what ntxent)
+NT="python $R/tools/microbench.py --what ntxent --iters 3 --out $OUT/mb_ntxent.json"
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_nt_f" -o f -- $NT > "$OUT/pmc_nt_f.log" 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_nt_w" -o w -- $NT > "$OUT/pmc_nt_w.log" 2>&1
+cd "$R"
+if [ "$MODE" = "full" ]; then
+  # BASELINE configs[3] and [4] on one GPU (per-GPU share of the 8-GPU global batch): value, step_mfma_frac, peak HBM
+  timeout 400 python bench.py --resnet_depth 50 --width_multiplier 2 --sk_ratio 0.0625 --steps 8 --warmup 3 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"; cut -c1-260 "$OUT/bench_cfg4.json" | tail -1
+  timeout 500 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 128 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg5_b128.json" 2> "$OUT/bench_cfg5_b128.err"; cut -c1-260 "$OUT/bench_cfg5_b128.json" | tail -1
+  PK=$(python -c "import json;print(json.loads(open('$OUT/bench_cfg5_b128.json').read().strip().splitlines()[-1])['peak_hbm_gb'])" 2>/dev/null || echo 999)
+  if python -c "import sys; sys.exit(0 if float('$PK') * 2 < 265 else 1)"; then
+    timeout 600 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 256 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg5_b256.json" 2> "$OUT/bench_cfg5_b256.err"; cut -c1-260 "$OUT/bench_cfg5_b256.json" | tail -1
+  else
+    echo "cfg5 at 256 images/GPU skipped: peak at 128 images = $PK GB"
+  fi
+fi
 ls "$OUT"

@@ -32,7 +32,42 @@ def load(path, counter):
     return tot, calls
 
 
+def ntxent_rows(fpath, wpath, tpath):
+    """HBM traffic of the NT-Xent / l2norm kernels from PMC passes of `tools/microbench.py --what ntxent` (n = N = 512,
+    n 512 / N 4096 (cfg3 per-GPU shape), n 256 / N 2048, n = N = 4096) with per-dispatch durations from the kernel trace."""
+    fetch, calls = load(fpath, 'FETCH_SIZE')
+    write, _ = load(wpath, 'WRITE_SIZE')
+    dur = defaultdict(float)
+    op = gzip.open if tpath.endswith('.gz') else open
+    with op(tpath, 'rt') as f:
+        for r in csv.DictReader(f):
+            dur[r['Kernel_Name']] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    rows = []
+    for n in sorted(set(fetch) | set(write)):
+        if 'ntxent' not in n and 'l2norm' not in n:
+            continue
+        c = max(calls.get(n, 0), 1)
+        by = 2 * fetch.get(n, 0) + write.get(n, 0)
+        rows.append(dict(kernel=n.replace('void (anonymous namespace)::', '')[:70], dispatches=c,
+                         fetch_corrected_bytes_per_dispatch=2 * fetch.get(n, 0) / c, write_bytes_per_dispatch=write.get(n, 0) / c,
+                         avg_us=dur.get(n, 0.0) / c / 1e3, hbm_gbps=(by / dur[n]) if dur.get(n) else None))
+    return rows
+
+
 def main():
+    if sys.argv[1] == '--ntxent':
+        fpath, wpath, tpath, out = sys.argv[2:6]
+        res = json.load(open(out))
+        res['ntxent'] = dict(note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/microbench.py --what ntxent: all four '
+                                  'shapes pooled per kernel; FETCH x2; durations from the FETCH pass kernel trace.  The kernels are bound by '
+                                  'the fp32 matrix pipe and launch latency, not by HBM: GB/s far below the roof is expected.',
+                             per_kernel=ntxent_rows(fpath, wpath, tpath))
+        json.dump(res, open(out, 'w'), indent=1)
+        for r in res['ntxent']['per_kernel']:
+            print('%-70s %4d x  fetch %8.3f MB  write %8.3f MB  %7.1f us  %s GB/s' % (
+                r['kernel'], r['dispatches'], r['fetch_corrected_bytes_per_dispatch'] / 1e6, r['write_bytes_per_dispatch'] / 1e6,
+                r['avg_us'], None if r['hbm_gbps'] is None else round(r['hbm_gbps'], 1)))
+        return
     fpath, wpath, out = sys.argv[1:4]
     fetch, calls = load(fpath, 'FETCH_SIZE')
     write, _ = load(wpath, 'WRITE_SIZE')
