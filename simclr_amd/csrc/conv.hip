@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false, bool FAPPLY = false, bool M4 = false>
+          bool WIN = false, bool FAPPLY = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
   static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
   // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
@@ -424,11 +424,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   // so the convolution output itself never travels to HBM.  The statistics that scale / shift derive from come from a
   // first, store-free pass of the same convolution (STATS instantiation with y == nullptr).
   static_assert(!FAPPLY || (sizeof(T) == 2 && MODE == MODE_FWD && !STATS && !BNEPI && !EXT), "fused BN-apply epilogue: forward bf16");
-  // M4: the fused BN-backward reduce compiled for mask_mode 4 only (ReLU bits + sum(dm); neither the BN input nor the
-  // second moment) -- the dgrad of a block's first 1x1 convolution, whose epilogue adds the residual gradient
-  // (accumulate): without the registers of the other modes there is room to request that operand and the mask bytes at
-  // the start of the tile's k-loop, like FAPPLY does with its residual
-  static_assert(!M4 || (sizeof(T) == 2 && MODE == MODE_DGRAD && BNEPI && STATS && !EXT && !WIN && BM == 128), "mode-4 epilogue");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int WN = BN / 64;           // waves along N
@@ -664,25 +659,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   }
   for (int ct = 0; ct < count; ++ct) {
     const int m0 = (mslot + ct * mslots) * BM;
-    // FAPPLY, flat (1x1 stride-1) layers: the residual rows of this tile's row-wise epilogue are requested NOW, so their
-    // HBM latency runs under the k-loop instead of being exposed between the two epilogue barriers (K = 64 ... 512:
-    // these layers are pure streaming, and the epilogue's loads were the only bytes in flight during that phase)
-    constexpr bool PFX = (FAPPLY || M4) && BM == 128;
-    constexpr int PER = PFX ? BM / RPP : 1;
-    u32x4 pf_x[PER];
-    unsigned pf_m[PER];
-    const bool pf_on = PFX && flat && (FAPPLY ? (p.bn_x != nullptr && !(p.fapply & 2)) : (p.accumulate != 0 && !(p.fapply & 2)));
-    if (pf_on) {
-      const uint16_t* src = FAPPLY ? (const uint16_t*)p.bn_x : (const uint16_t*)Y;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int m = m0 + tid / CPR + i * RPP;
-        const bool ok = m < p.M && n0 + e_cc * 8 < p.N;
-        const long long off = ok ? (long long)m * p.N + n0 + e_cc * 8 : 0;
-        pf_x[i] = *(const u32x4*)(src + off);
-        if (M4) pf_m[i] = ((const unsigned char*)p.bn_mask)[off >> 3];
-      }
-    }
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -853,27 +829,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       for (int i = 0; i < ER; ++i) eld[i] = DIAG(8) ? 0 : eoff[i];
       u32x4 e_ov[ER], e_xv[ER], e_mv[ER];
       if (p.accumulate) {
-        if (M4 && pf_on) {
 #pragma unroll
-          for (int i = 0; i < ER; ++i) e_ov[i] = pf_x[M4 ? i : 0];
-        } else {
-#pragma unroll
-          for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
-        }
+        for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
       }
       if (FAPPLY && p.bn_x) {          // residual operand of the fused BatchNorm apply
-        if (PFX && pf_on) {
 #pragma unroll
-          for (int i = 0; i < ER; ++i) e_xv[i] = pf_x[PFX ? i : 0];
-        } else {
-#pragma unroll
-          for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
-        }
+        for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
       }
-      if (BNEPI && M4) {
-#pragma unroll
-        for (int i = 0; i < ER; ++i) e_mv[i][0] = pf_on ? pf_m[M4 ? i : 0] : ((const unsigned char*)p.bn_mask)[eld[i] >> 3];
-      } else if (BNEPI) {
+      if (BNEPI) {
         if (p.bn_mode != 4) {
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
@@ -948,7 +911,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           // This pass is VALU-bound (profiles/r02_notes.md), so it accumulates the RAW moment sum(dm * x) -- one fma per
           // element -- and the flush turns it into sum(dm * x^) = rstd * (sum(dm * x) - mean * sum(dm)) once per
           // workgroup; mode 4 (sums only) touches neither x nor the second moment.
-          if (M4 || p.bn_mode == 4) {
+          if (p.bn_mode == 4) {
             const unsigned mb = e_mv[i][0];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -2299,12 +2262,13 @@ static bool igemm_use_256(const ConvP& p, bool fwd) {
   return (classes & cls) != 0;
 }
 
-// Short-K layers (1x1 convolutions from <= SIMCLR_IGEMM_BN64_K channels: one or two k-tiles per output tile) are pure
-// streaming: with the 64-wide tile three workgroups fit a CU instead of two, so the load phase of one tile, the MFMA /
-// staging of another and the store phase of a third overlap (the gathered operand is then re-read from L2 by N/64
-// workgroups instead of N/128 -- irrelevant for an HBM-bound layer).
+// Short-K layers (1x1 convolutions from <= SIMCLR_IGEMM_BN64_K channels, default 128: one or two k-tiles per output tile)
+// are pure streaming: with the 64-wide tile three workgroups fit a CU instead of two, so the load phase of one tile, the
+// MFMA / staging of another and the store phase of a third overlap (the gathered operand is then re-read from L2 by N/64
+// workgroups instead of N/128 -- irrelevant for an HBM-bound layer).  Measured in the step: 66.49 / 66.33 vs 66.72 / 66.66 ms
+// (-0.3 ms, two interleaved pairs, profiles/r03_notes.md); K <= 64 alone and K <= 256 give 66.60 / 66.50.
 static bool igemm_narrow(const ConvP& p, size_t esz) {
-  static const int kmax = getenv("SIMCLR_IGEMM_BN64_K") ? atoi(getenv("SIMCLR_IGEMM_BN64_K")) : 0;
+  static const int kmax = getenv("SIMCLR_IGEMM_BN64_K") ? atoi(getenv("SIMCLR_IGEMM_BN64_K")) : 128;
   return esz == 2 && p.N > 64 && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.x2 && p.K <= kmax && p.N / 64 <= 64;
 }
 
@@ -2388,17 +2352,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 64, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
       else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
     } else if (p.bn_mode) {    // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
-      static const bool m4_on = !getenv("SIMCLR_DGRAD_M4") || atoi(getenv("SIMCLR_DGRAD_M4")) != 0;
-      bool done = false;
-      if constexpr (sizeof(T) == 2 && MODE == MODE_DGRAD) {
-        if (m4_on && p.bn_mode == 4 && BN == 128) {       // sums-only epilogue with early operand loads
-          hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_DGRAD, 128, 128, 4, 2, true, true, false, false, false, true>),
-                             dim3(pg), dim3(256), plds, stream, p);
-          done = true;
-        }
-      }
-      if (done) {}
-      else if (BN == 64) LP(64, true, true); else LP(128, true, true);
+      if (BN == 64) LP(64, true, true); else LP(128, true, true);
     } else if (BN == 64) { if (st) LP(64, true, false); else LP(64, false, false); }
     else { if (st) LP(128, true, false); else LP(128, false, false); }
 #undef LP
@@ -2533,8 +2487,7 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
   p.M = V * OH * OW; p.K = KH * KW * Cin;
-  p.fapply = (getenv("SIMCLR_FAPPLY_PF") && atoi(getenv("SIMCLR_FAPPLY_PF")) == 0) ? 3 : 1;    // bit 1: no early residual loads (A/B switch)
-  p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
+  p.fapply = 1; p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
   p.bn_mean = rscale; p.bn_rstd = rshift;
   launch_igemm<uint16_t, MODE_FWD>(p, stream);
   SIMCLR_CHECK_LAUNCH();
