@@ -2253,11 +2253,13 @@ static bool igemm_use_256(const ConvP& p, bool fwd) {
   if (p.bn_mode && !p.fapply) return false;          // fused BN-backward reduce epilogue
   if (fwd && !p.fapply && p.stats && p.K < 128) return false;
   // classes (SIMCLR_IGEMM_256_CLASSES, bit mask): 1 = forward with the fused BatchNorm-apply epilogue, 2 = other forward
-  // launches, 4 = plain / K-extended dgrad.  Default 0: inside the training step the wide tile LOSES although every class
-  // wins stand-alone (69.45 vs 67.0 ms/step, interleaved on one box, profiles/r03_notes.md) -- a 151 KB workgroup needs a
-  // whole CU's LDS, so it cannot start until the previous kernel has drained from that CU and nothing can start beside it.
+  // launches, 4 = plain / K-extended dgrad.  Inside the training step class 1 LOSES 2.5 ms of 67 on ResNet-50 1x although it
+  // wins stand-alone (a 151 KB workgroup needs a whole CU's LDS: it cannot start until the previous kernel has drained
+  // from that CU, nothing can start beside it, and the fused epilogue has no second workgroup to hide behind); classes
+  // 2 and 4 are neutral there (66.96 / 67.01 vs 66.9 ms) and gain 2.5 % on ResNet-50 2x + SK (298.9 vs 305.7 ms,
+  // profiles/r03_notes.md) -> default 6.
   const char* c = getenv("SIMCLR_IGEMM_256_CLASSES");
-  const int classes = c ? atoi(c) : 0;
+  const int classes = c ? atoi(c) : 6;
   const int cls = p.fapply ? 1 : (fwd ? 2 : 4);
   return (classes & cls) != 0;
 }

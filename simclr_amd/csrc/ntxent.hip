@@ -34,15 +34,25 @@ __device__ __forceinline__ void row_cols(int q, int n, int N, int rank, int& mas
   else { int i = q - n; mask_col = N + rank * n + i; pos_col = rank * n + i; }
 }
 
+// A streamed tile (kTile rows x D floats) travels global -> registers -> LDS: tile_fetch issues the loads of the NEXT tile
+// before the MFMAs of the current one, tile_store puts them into the (XOR-swizzled) LDS tile after the barrier -- the
+// global latency runs under the matrix work instead of between two barriers.
 template <int D>
-__device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ src, int row0,
-                                          int nrows_total, int tid) {
+__device__ __forceinline__ void tile_fetch(float4* pf, const float* __restrict__ src, int row0, int nrows_total, int tid) {
   constexpr int C = D / 4;
-  for (int idx = tid; idx < kTile * C; idx += 256) {
-    int r = idx / C, c = idx % C;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < nrows_total) v = *(const float4*)(src + (size_t)(row0 + r) * D + c * 4);
-    *(float4*)(lds + r * D + ((c ^ (r & 15)) * 4)) = v;
+#pragma unroll
+  for (int j = 0; j < kTile * C / 256; ++j) {
+    const int idx = tid + j * 256, r = idx / C, c = idx % C;
+    pf[j] = (row0 + r < nrows_total) ? *(const float4*)(src + (size_t)(row0 + r) * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int D>
+__device__ __forceinline__ void tile_store(float* lds, const float4* pf, int tid) {
+  constexpr int C = D / 4;
+#pragma unroll
+  for (int j = 0; j < kTile * C / 256; ++j) {
+    const int idx = tid + j * 256, r = idx / C, c = idx % C;
+    *(float4*)(lds + r * D + ((c ^ (r & 15)) * 4)) = pf[j];
   }
 }
 
@@ -86,10 +96,13 @@ __global__ __launch_bounds__(256) void ntxent_fwd_partial(
   const int tile_begin = blockIdx.y * tiles_per_split;
   const int ntiles = (two_N + kTile - 1) / kTile;
   const int tile_end = min(ntiles, tile_begin + tiles_per_split);
+  float4 pf[kTile * (D / 4) / 256];
+  if (tile_begin < tile_end) tile_fetch<D>(pf, zk, tile_begin * kTile, two_N, tid);
   for (int kt = tile_begin; kt < tile_end; ++kt) {
     __syncthreads();
-    load_tile<D>(lds, zk, kt * kTile, two_N, tid);
+    tile_store<D>(lds, pf, tid);
     __syncthreads();
+    if (kt + 1 < tile_end) tile_fetch<D>(pf, zk, (kt + 1) * kTile, two_N, tid);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -252,14 +265,24 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
   const int ntiles = (stream_rows + kTile - 1) / kTile;
   const int tile_begin = blockIdx.y * tiles_per_split;
   const int tile_end = min(ntiles, tile_begin + tiles_per_split);
+  constexpr bool PF = D <= 128;        // D = 256: 64 prefetch registers on top of 64 accumulators would spill
+  float4 pf[kTile * (D / 4) / 256];
+  float pst = 0.f;
+  auto fetch = [&](int kt) __attribute__((always_inline)) {
+    tile_fetch<D>(pf, stream_mat, kt * kTile, stream_rows, tid);
+    if (!FIXED_IS_QUERY && tid < 2 * kTile) {
+      const int qq = kt * kTile + (tid >> 1);
+      pst = (qq < two_n) ? row_stats[2 * qq + (tid & 1)] : 0.f;
+    }
+  };
+  if (PF && tile_begin < tile_end) fetch(tile_begin);
   for (int kt = tile_begin; kt < tile_end; ++kt) {
     __syncthreads();
-    load_tile<D>(lds, stream_mat, kt * kTile, stream_rows, tid);
-    if (!FIXED_IS_QUERY && tid < 2 * kTile) {
-      int qq = kt * kTile + (tid >> 1);
-      stats_s[tid] = (qq < two_n) ? row_stats[2 * qq + (tid & 1)] : 0.f;
-    }
+    if (!PF) fetch(kt);
+    tile_store<D>(lds, pf, tid);
+    if (!FIXED_IS_QUERY && tid < 2 * kTile) stats_s[tid] = pst;
     __syncthreads();
+    if (PF && kt + 1 < tile_end) fetch(kt + 1);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -327,7 +350,7 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
 // Both sweeps in ONE launch: blockIdx.z = 0 query-fixed (gradient wrt the local rows + the entropy term),
 // blockIdx.z = 1 key-fixed (gradient wrt the gathered rows).  They are independent, so they share the chip.
 template <int D>
-__global__ __launch_bounds__(256) void ntxent_bwd_sweeps(
+__global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void ntxent_bwd_sweeps(
     const float* __restrict__ z_local, const float* __restrict__ z_all, int n, int N, int rank, float scale2,
     const float* __restrict__ row_stats, int tiles_k, int tiles_q, float* __restrict__ gq, int rows_pad_q,
     float* __restrict__ gk, int rows_pad_k, float* __restrict__ epart, int gxq, int gyq, int gxk, int gyk) {
