@@ -56,6 +56,18 @@ __device__ __forceinline__ void tile_store(float* lds, const float4* pf, int tid
   }
 }
 
+// un-pipelined form (the backward sweeps): each 16-byte piece goes global -> LDS straight away
+template <int D>
+__device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ src, int row0, int nrows_total, int tid) {
+  constexpr int C = D / 4;
+  for (int idx = tid; idx < kTile * C; idx += 256) {
+    const int r = idx / C, c = idx % C;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < nrows_total) v = *(const float4*)(src + (size_t)(row0 + r) * D + c * 4);
+    *(float4*)(lds + r * D + ((c ^ (r & 15)) * 4)) = v;
+  }
+}
+
 // online (max,sum) merge in the base-2 domain
 __device__ __forceinline__ void ml_merge(float& m, float& l, float m2, float l2) {
   float mn = fmaxf(m, m2);
@@ -265,24 +277,16 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
   const int ntiles = (stream_rows + kTile - 1) / kTile;
   const int tile_begin = blockIdx.y * tiles_per_split;
   const int tile_end = min(ntiles, tile_begin + tiles_per_split);
-  constexpr bool PF = D <= 128;        // D = 256: 64 prefetch registers on top of 64 accumulators would spill
-  float4 pf[kTile * (D / 4) / 256];
-  float pst = 0.f;
-  auto fetch = [&](int kt) __attribute__((always_inline)) {
-    tile_fetch<D>(pf, stream_mat, kt * kTile, stream_rows, tid);
-    if (!FIXED_IS_QUERY && tid < 2 * kTile) {
-      const int qq = kt * kTile + (tid >> 1);
-      pst = (qq < two_n) ? row_stats[2 * qq + (tid & 1)] : 0.f;
-    }
-  };
-  if (PF && tile_begin < tile_end) fetch(tile_begin);
+  // (prefetching one tile ahead into registers, as the forward sweep does, was measured SLOWER here: on top of the 32 + 32
+  // accumulator / fixed-row registers it costs a wave of occupancy or spills -- cfg3 shape 183 -> 193 us, profiles/r03_notes.md)
   for (int kt = tile_begin; kt < tile_end; ++kt) {
     __syncthreads();
-    if (!PF) fetch(kt);
-    tile_store<D>(lds, pf, tid);
-    if (!FIXED_IS_QUERY && tid < 2 * kTile) stats_s[tid] = pst;
+    load_tile<D>(lds, stream_mat, kt * kTile, stream_rows, tid);
+    if (!FIXED_IS_QUERY && tid < 2 * kTile) {
+      int qq = kt * kTile + (tid >> 1);
+      stats_s[tid] = (qq < two_n) ? row_stats[2 * qq + (tid & 1)] : 0.f;
+    }
     __syncthreads();
-    if (PF && kt + 1 < tile_end) fetch(kt + 1);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -350,7 +354,7 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
 // Both sweeps in ONE launch: blockIdx.z = 0 query-fixed (gradient wrt the local rows + the entropy term),
 // blockIdx.z = 1 key-fixed (gradient wrt the gathered rows).  They are independent, so they share the chip.
 template <int D>
-__global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void ntxent_bwd_sweeps(
+__global__ __launch_bounds__(256) void ntxent_bwd_sweeps(
     const float* __restrict__ z_local, const float* __restrict__ z_all, int n, int N, int rank, float scale2,
     const float* __restrict__ row_stats, int tiles_k, int tiles_q, float* __restrict__ gq, int rows_pad_q,
     float* __restrict__ gk, int rows_pad_k, float* __restrict__ epart, int gxq, int gyq, int gxk, int gyk) {
