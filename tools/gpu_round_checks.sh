@@ -24,7 +24,7 @@ timeout 300 python tools/microbench.py --out "$OUT/microbench.json" > "$OUT/micr
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no_cpu_baseline --no_kernel_events --no_f32"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- $B --steps 3 --warmup 1 > "$OUT/prof.log" 2>&1
-rm -f "$OUT"/*kernel_trace.csv
+gzip -f "$OUT"/*kernel_trace.csv 2>/dev/null      # per-dispatch durations (tools/per_dispatch.py)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --steps 1 --warmup 1 > "$OUT/pmc_f.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --steps 1 --warmup 1 > "$OUT/pmc_w.log" 2>&1
 gzip -f "$OUT"/pmc_f/*counter_collection.csv "$OUT"/pmc_w/*counter_collection.csv 2>/dev/null
@@ -36,12 +36,7 @@ cd "$R"
 if [ "$MODE" = "full" ]; then
   # BASELINE configs[3] and [4] on one GPU (per-GPU share of the 8-GPU global batch): value, step_mfma_frac, peak HBM
   timeout 400 python bench.py --resnet_depth 50 --width_multiplier 2 --sk_ratio 0.0625 --steps 8 --warmup 3 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"; cut -c1-260 "$OUT/bench_cfg4.json" | tail -1
-  timeout 500 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 128 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg5_b128.json" 2> "$OUT/bench_cfg5_b128.err"; cut -c1-260 "$OUT/bench_cfg5_b128.json" | tail -1
-  PK=$(python -c "import json;print(json.loads(open('$OUT/bench_cfg5_b128.json').read().strip().splitlines()[-1])['peak_hbm_gb'])" 2>/dev/null || echo 999)
-  if python -c "import sys; sys.exit(0 if float('$PK') * 2 < 265 else 1)"; then
-    timeout 600 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 256 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg5_b256.json" 2> "$OUT/bench_cfg5_b256.err"; cut -c1-260 "$OUT/bench_cfg5_b256.json" | tail -1
-  else
-    echo "cfg5 at 256 images/GPU skipped: peak at 128 images = $PK GB"
-  fi
+  # cfg5 at its real per-GPU share (global 2048 / 8 = 256 images): peaks at 192 GB of the 288 GB (104 GB at 128 images, r03_call5)
+  timeout 700 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 256 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg5_b256.json" 2> "$OUT/bench_cfg5_b256.err"; cut -c1-260 "$OUT/bench_cfg5_b256.json" | tail -1
 fi
 ls "$OUT"
