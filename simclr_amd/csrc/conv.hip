@@ -1373,7 +1373,10 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
 // GRAM: the "gradient" operand IS the activation tile (dy == x, BNW == BKW, one tile spans all channels): h^T h with a single
 // DMA stream, plus the column sums of h from one extra MFMA per k-fragment against an all-ones fragment (slab layout
 // [K*K | K]).  Used by the folded BatchNorm backward (csrc/bn.hip bn_fold_*).
-template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false>
+// MT (multi-tap k-tile, the stem: KW = 1, IC = 32 packed elements per kernel row, all 7 kernel rows in ONE 256-row k-tile so
+// that the gradient tensor is read once): every 16-byte chunk of a tile row has its OWN tap, so the tap offset is per lane
+// instead of per workgroup.  Needs 16-byte aligned sources (stride 2 on an even-width packed image: every pixel index even).
+template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false, bool MT = false>
 __global__ __launch_bounds__(WK * WNN * 64,
                              WK * WNN == 8 ? 1 : ((STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
 void conv_wgrad_dma(const WgradP p) {
@@ -1444,6 +1447,7 @@ void conv_wgrad_dma(const WgradP p) {
 
   // ---- per-lane source state (fixed LDS slot per lane and instruction; only the pixel advances) ----
   int a_m[AJ], a_v[AJ], a_oy[AJ], a_ox[AJ];
+  int a_ty[AJ];              // MT: kernel row of this lane's chunk, -1 = beyond K (zero padding of the 256-row tile)
   const T* a_ptr[AJ];        // flat: current source; otherwise X + channel offset (pixel part recomputed)
   int b_m[BJ];
   const T* b_ptr[BJ];
@@ -1461,6 +1465,11 @@ void conv_wgrad_dma(const WgradP p) {
       const int v = m / ohow, rem = m - v * ohow;
       a_v[j] = v; a_oy[j] = rem / p.OW; a_ox[j] = rem - a_oy[j] * p.OW;
       a_ptr[j] = X + ci0 + lc * EPC;
+      if (MT) {
+        const int kidx = kk0 + lc * EPC;
+        a_ty[j] = kidx < p.K ? kidx / p.IC : -1;
+        a_ptr[j] = X + (kidx - max(a_ty[j], 0) * p.IC);
+      }
       if (shift) a_ptr[j] += ((long long)m + (ty - p.pad) * p.IW + (tx - p.pad)) * p.pixpitch;
     }
   }
@@ -1506,8 +1515,8 @@ void conv_wgrad_dma(const WgradP p) {
     } else {
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
-        const int iy = a_oy[j] * p.stride - p.pad + ty, ix = a_ox[j] * p.stride - p.pad + tx;
-        const bool ok = a_m[j] < p.M && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int iy = a_oy[j] * p.stride - p.pad + (MT ? a_ty[j] : ty), ix = a_ox[j] * p.stride - p.pad + tx;
+        const bool ok = a_m[j] < p.M && (!MT || a_ty[j] >= 0) && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
         const int pix = (a_v[j] * p.IH + iy) * p.IW + ix;
         const void* src = ok ? (const void*)(a_ptr[j] + (long long)pix * p.pixpitch) : p.zero;
         a_ox[j] += dcol;
@@ -2779,8 +2788,17 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   const size_t lds = (size_t)(cfg == 0 ? 2 : stages) * br * (bkw + bnw) * esz;
 #define LW(TT, A, B) hipLaunchKernelGGL((conv_wgrad<TT, A, B>), dim3(grid), dim3(256), lds, stream, p)
 #define LD(TT, A, B, M_, S_) hipLaunchKernelGGL((conv_wgrad_dma<TT, A, B, M_, S_>), dim3(grid), dim3(256), lds, stream, p)
+  // stem over LDS-DMA: stride 2 on an even-width packed image makes every source 16-byte aligned
+  static const bool stem_dma_on = !getenv("SIMCLR_STEM_WGRAD_DMA") || atoi(getenv("SIMCLR_STEM_WGRAD_DMA")) != 0;
+  const bool stem_dma = stem_mt && stem_dma_on && dtype == SIMCLR_DT_BF16 && KW == 1 && pad == 0 && stride % 2 == 0 && IW % 2 == 0 &&
+                        pixpitch == 4 && Cin == 32;
   if (big256) {
     hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 256, 1, 4, 2, 4>), dim3(grid), dim3(512), lds, stream, p);
+  } else if (stem_dma) {
+    const size_t lds_s = (size_t)2 * 64 * (256 + 64) * 2;      // 2 stages x 64 pixels x (256 + 64) bf16
+    p.xcd_map = 1;
+    const int grid_s = p.k_tiles * p.n_tiles * ceil_div(p.splits, 8) * 8;
+    hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 64, 2, 2, 2, 2, false, true>), dim3(grid_s), dim3(256), lds_s, stream, p);
   } else if (stem_mt) {
     if (dtype == SIMCLR_DT_BF16) hipLaunchKernelGGL((conv_wgrad<uint16_t, 256, 64, true>), dim3(grid), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((conv_wgrad<float, 256, 64, true>), dim3(grid), dim3(256), lds, stream, p);
