@@ -17,7 +17,9 @@ if [ "$MODE" = "quick" ]; then
   python -c "import json,sys;d=json.load(open('$OUT/bench_quick.json'));print(d['value'],d['ms_per_step']);[print(k,v) for k,v in d['kernels'].items()]"
   exit 0
 fi
+if [ "$MODE" != "prof" ]; then      # prof: bench line, microbench, rocprofv3 stats / trace and the two PMC passes only
 timeout 2400 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -4 "$OUT/pytest_gpu.log"; grep -n "^FAILED" "$OUT/pytest_gpu.log" | head
+fi
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
 timeout 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-300 "$OUT/bench.json" | tail -1
 timeout 300 python tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.txt" 2>&1
@@ -28,6 +30,7 @@ gzip -f "$OUT"/*kernel_trace.csv 2>/dev/null      # per-dispatch durations (tool
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --steps 1 --warmup 1 > "$OUT/pmc_f.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- $B --steps 1 --warmup 1 > "$OUT/pmc_w.log" 2>&1
 gzip -f "$OUT"/pmc_f/*counter_collection.csv "$OUT"/pmc_w/*counter_collection.csv 2>/dev/null
+if [ "$MODE" = "prof" ]; then ls "$OUT"; exit 0; fi
 # north_star: rocprof-reported HBM traffic of the NT-Xent kernels (cfg2 and cfg3 shapes: tools/microbench.py --what ntxent)
 NT="python $R/tools/microbench.py --what ntxent --iters 3 --out $OUT/mb_ntxent.json"
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_nt_f" -o f -- $NT > "$OUT/pmc_nt_f.log" 2>&1
