@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
           bool WIN = false, bool FAPPLY = false>
-__global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
   static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
   // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
   // before it is stored -- y = act(bf16(conv) * scale + shift + res) with exactly the arithmetic of bn_apply (csrc/bn.hip),
@@ -2344,27 +2344,6 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         return;
       }
     }
-    // 64 x 64 tile (4 waves of 16 x 64, <= 128 registers, 34 KB of LDS): FOUR workgroups per CU for the big-output short-K
-    // streaming layers (conv3 with the fused BatchNorm apply, the dgrad of a block's first 1x1 convolution), whose row-wise
-    // epilogue (~190 us per launch at 56^2) two or three resident workgroups do not hide.  SIMCLR_IGEMM_T64_K: largest K.
-    if constexpr (sizeof(T) == 2) {
-      static const int t64k = getenv("SIMCLR_IGEMM_T64_K") ? atoi(getenv("SIMCLR_IGEMM_T64_K")) : 0;
-      if (narrow && p.K <= t64k && (p.fapply || p.bn_mode) && !p.x2 && p.N % 64 == 0) {
-        p.m_tiles = ceil_div(p.M, 64);
-        p.n_tiles = p.N / 64;
-        const int unit = 8 * p.n_tiles;
-        int pg3 = max(unit, (1024 / unit) * unit);
-        pg3 = min(pg3, ceil_div(p.m_tiles, 8) * unit);
-        const size_t lds3 = 2 * (64 + 64) * 128 + 5 * 64 * sizeof(float) + 64 * sizeof(long long);
-        if (p.fapply) {
-          if constexpr (MODE == MODE_FWD)
-            hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 64, 64, 4, 2, false, false, false, false, true>), dim3(pg3), dim3(256), lds3, stream, p);
-        } else {
-          hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 64, 64, 4, 2, true, true>), dim3(pg3), dim3(256), lds3, stream, p);
-        }
-        return;
-      }
-    }
 #define LP(BNv, STv, BEv) \
     hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
     if (p.fapply) {
@@ -2468,13 +2447,7 @@ extern "C" {
 int simclr_conv2d_stats_slots(long long M, int C) {
   int bn, nt, pg;
   igemm_persistent_grid(M, C, &bn, &nt, &pg);
-  int slots = pg / nt;
-  if (C % 64 == 0) {      // the 64 x 64 tile of the short-K streaming layers: up to 1024 workgroups (launch_igemm_one)
-    const int unit = 8 * (C / 64);
-    const int pg3 = min(max(unit, (1024 / unit) * unit), (int)ceil_div(ceil_div(M, 64), 8) * unit);
-    slots = max(slots, pg3 / (C / 64));
-  }
-  return slots;
+  return pg / nt;
 }
 // same for simclr_stem_conv_fwd (M = V*OH*OW output pixels)
 int simclr_stem_stats_slots(long long M) { return (int)min((M + 127) / 128, 2048ll); }
