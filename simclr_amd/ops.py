@@ -289,10 +289,18 @@ _wgrad_ws = {}
 
 
 def _workspace(nbytes, device, key='ws'):
-    buf = _wgrad_ws.get((key, device))
+    """One scratch buffer per (purpose, device, STREAM): launches on one stream are ordered, so they can share it; a launch
+    on the weight-gradient side stream (SIMCLR_WGRAD_STREAM=1) gets its own, so it can never race a main-stream user of the
+    same scratch space.  A buffer that has to grow is replaced, the old one stays referenced by the launches
+    already queued on its stream (same stream: the allocator orders the reuse)."""
+    import os
+    # (default: one stream, one buffer -- the configuration the GPU suite runs; the per-stream key only exists with the side stream)
+    side = os.environ.get('SIMCLR_WGRAD_STREAM', '0') not in ('', '0')
+    k = (key, device, torch.cuda.current_stream(device).cuda_stream) if side else (key, device)
+    buf = _wgrad_ws.get(k)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _wgrad_ws[(key, device)] = buf
+        _wgrad_ws[k] = buf
     return buf
 
 
