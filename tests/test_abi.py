@@ -118,3 +118,35 @@ def test_header_is_plain_c():
         r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(root, 'include'), '-fsyntax-only', src],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_metric_mean_with_attached_bank():
+    """metrics.Mean keeps tf.keras.metrics.Mean semantics when its running sum lives in the step's shared device tensor
+    (run.make_single_step: one simclr_accumulate_scalars launch per step updates every attached metric)."""
+    import torch
+    from simclr_amd.metrics import Mean
+    bank = torch.zeros(4)
+    m, other = Mean('a'), Mean('b')
+    m.attach(bank, 2)
+    other.attach(bank, 0)
+    assert m.result() == 0.0
+    for v in (1.0, 2.0, 6.0):          # what the kernel does: bank[i] += value; the host only counts
+        bank[2] += v
+        m.bump()
+    assert m.result() == 3.0 and other.result() == 0.0
+    m.update_state(torch.tensor([3.0]))                       # the stand-alone path still works next to the bank
+    assert m.result() == 3.0
+    m.reset_states()
+    assert m.result() == 0.0 and float(bank[2]) == 0.0 and m._count == 0
+
+
+def test_class_id_cache_follows_the_label_tensor():
+    import torch
+    from simclr_amd.objective import _class_ids
+    lab = torch.nn.functional.one_hot(torch.tensor([2, 0, 1]), 3).float()
+    a = _class_ids(lab)
+    assert a.dtype == torch.int32 and a.tolist() == [2, 0, 1]
+    assert _class_ids(lab) is a                                # same storage, same version: converted once
+    lab[0] = torch.tensor([1.0, 0.0, 0.0])                     # in-place change bumps the version -> recomputed
+    assert _class_ids(lab).tolist() == [0, 0, 1]
+    assert _class_ids(torch.tensor([1, 2])).tolist() == [1, 2]

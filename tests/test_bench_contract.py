@@ -25,6 +25,10 @@ def test_roofline_entry_memory_bound_family():
     assert abs(r['achieved_tflops'] - 400.0) < 1e-6 and abs(r['mfma_frac'] - 0.16) < 1e-4
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r
+    # the strict SURVEY 8(d) fraction beside the one that counts the fused-epilogue operands, and an
+    # explicit statement that `traffic` comes from the committed PMC passes, not from this run
+    assert r['strict_frac'] == r['frac'] and abs(r['fused_operands_frac'] - 3000.0 / 8000.0) < 1e-4
+    assert r['traffic_measured_in_run'] is False
 
 
 def test_roofline_entry_compute_bound_family():
@@ -44,3 +48,15 @@ def test_step_time_percentiles_and_self_launch_command():
     src = inspect.getsource(b.relaunch_multi_gpu)
     for needle in ('torch.distributed.run', '--nproc-per-node', '--master-addr', '127.0.0.1'):
         assert needle in src
+
+
+def test_flop_table_and_backend_flag():
+    """cfg4 / cfg5 carry their own FLOP-per-image constants, so `step_mfma_frac` is never null for them; the
+    gloo backend switch exists for exercising the N > 1 path on one GPU."""
+    b = _bench()
+    assert b.FLOP_PER_IMAGE_BY_MODEL[(50, 1, False)] == b.FLOP_PER_IMAGE == 49.15e9
+    assert b.FLOP_PER_IMAGE_BY_MODEL[(50, 2, True)] == 296.6e9 and b.FLOP_PER_IMAGE_BY_MODEL[(152, 3, True)] == 1893.6e9
+    import inspect
+    src = inspect.getsource(b.main)
+    for needle in ("'--backend'", 'SIMCLR_DIST_BACKEND', 'SIMCLR_SHARE_GPU', 'peak_hbm_gb', 'stat_collectives_per_step'):
+        assert needle in src, needle
