@@ -72,6 +72,14 @@ int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long
                              double* norms, simclr_stream_t stream);
 
 /* ---- convolution / dense: tf2/resnet.py:183-208 (Conv2dFixedPadding), tf2/model.py:143-154 ----- */
+/* Matrix arithmetic of the SIMCLR_DT_F32 convolution / dense launches (the reference's tf.nn.conv2d / tf.matmul on float32,
+ * resnet.py:196-208, model.py:148-153): number of bf16 terms per fp32 product, for the forward GEMM and for the two backward
+ * GEMMs (dgrad, wgrad).  0 (default) = exact fp32 MFMA; 3 = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi (~2^-17 per product);
+ * 6 = every term of weight >= 2^-18 of a three-way split (fp32 level).  Storage, accumulation, statistics and every
+ * elementwise kernel stay fp32; bf16 launches are unaffected.  Process-wide, not stream-ordered: set it between steps.
+ * simclr_get_f32_matmul(0 | 1) returns the forward | backward setting. */
+int simclr_set_f32_matmul(int fwd_terms, int bwd_terms);
+int simclr_get_f32_matmul(int which);
 /* master HWIO fp32 -> compute copies.  mode 0: [Cout][KH*KW*Cin] (fwd), 1: [Cin][KH*KW*Cout]
  * (dgrad), 2: stem [Cout][KHP][KWP][4] zero padded.  CinP/CoutP (0 = none): zero-padded channel dims. */
 int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('SIMCLR_HIP_LIB') or os.path.join(_HERE, 'libsimclr_hi
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'simclr_hip.h')
 
 # bumped whenever an entry point's buffer-size contract or argument list changes (csrc/runtime.hip)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DT_F32 = 0
 DT_BF16 = 1
@@ -82,7 +82,7 @@ class _Lib:
         self._int_fns = {n for n, (r, _) in self.signatures.items() if r is ctypes.c_int}
         self._no_check = {'simclr_abi_version', 'simclr_lars_chunk_elems', 'simclr_conv2d_stats_slots',
                           'simclr_stem_stats_slots', 'simclr_bn_bwd_reduce_slots', 'simclr_bn_bwd_pool_slots',
-                          'simclr_prep_chunk_elems'}
+                          'simclr_prep_chunk_elems', 'simclr_get_f32_matmul'}
 
     def last_error(self):
         return self._dll.simclr_last_error().decode()

@@ -69,6 +69,7 @@ struct ConvP {
   const void* zero;  // 16 zero bytes in device memory (source of padding chunks for direct-to-LDS loads):
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
+  int split;       // fp32 instantiations: 0 = exact fp32 MFMA, 3 / 6 = split-bf16 terms (simclr_set_f32_matmul)
 };
 
 // Diagnostic build (build.sh diag -> libsimclr_hip_diag.so): parts of a kernel can be switched off at run time
@@ -95,6 +96,103 @@ template <> struct MMA<float> {
     return c;
   }
 };
+
+// ---- split-bf16 arithmetic on fp32 operands (the fast parity mode) --------------------------------------
+// gfx950 has no xf32 / TF32 matrix path: fp32-input MFMA runs at 1/16 of the bf16 rate.  A fp32 value is instead split
+// after the LDS read into bf16 terms x = hi + lo (+ lo2), hi = bf16(x), lo = bf16(x - hi), lo2 = bf16(x - hi - lo) (each
+// subtraction is exact in fp32), and a product a*b becomes 3 (terms of weight >= 2^-9: hi*hi + hi*lo + lo*hi, ~2^-17
+// relative) or 6 (weight >= 2^-18: + hi*lo2 + lo2*hi + lo*lo, ~2^-24 = fp32 level) v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation -- bf16 products are exact in fp32.  Storage, statistics and every elementwise kernel stay fp32.
+// Two consecutive 16-byte chunks (8 floats) of a fragment row become one 8-element bf16 operand.
+__device__ __forceinline__ void split_terms2(const u32x4& c0, const u32x4& c1, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = __uint_as_float(j < 2 ? c0[2 * j] : c1[2 * j - 4]), x1 = __uint_as_float(j < 2 ? c0[2 * j + 1] : c1[2 * j - 3]);
+    const uint32_t h = pack_bf16x2(x0, x1);
+    hi[j] = h;
+    lo[j] = pack_bf16x2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
+  }
+}
+__device__ __forceinline__ void split_terms3(const u32x4& c0, const u32x4& c1, u32x4& hi, u32x4& lo, u32x4& lo2) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = __uint_as_float(j < 2 ? c0[2 * j] : c1[2 * j - 4]), x1 = __uint_as_float(j < 2 ? c0[2 * j + 1] : c1[2 * j - 3]);
+    const uint32_t h = pack_bf16x2(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    const uint32_t l = pack_bf16x2(r0, r1);
+    hi[j] = h;
+    lo[j] = l;
+    lo2[j] = pack_bf16x2(r0 - __uint_as_float(l << 16), r1 - __uint_as_float(l & 0xffff0000u));
+  }
+}
+__device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc(i, j) += A_i . B_j over the 32 reduction elements of one k-step; lda(i, h) / ldb(j, h) return 16-byte chunk h (0 | 1) of
+// fragment row i / j (fp32: 4 values; the two chunks of a row are this lane's 8 reduction elements).
+// terms (compile time: the six-term path needs ~60 more registers): 0 = exact fp32 MFMA (8 x v_mfma_f32_16x16x4_f32 per pair), 3 / 6 = split bf16 (small terms accumulated first,
+// term-major so that consecutive MFMAs write different accumulators).  The B operand is split once, the A operand one
+// fragment at a time (register pressure: NB x 12 + 12 split registers instead of (NA + NB) x 12).
+// TR: the accumulator array is indexed [j][i] (acc[NB][NA]) instead of [i][j].
+template <int NA, int NB, bool TR, int terms, typename LA, typename LB>
+__device__ __forceinline__ void mma_f32_chunks(f32x4* __restrict__ accp, LA lda, LB ldb) {
+  static_assert(terms == 0 || terms == 3 || terms == 6, "0 = exact fp32, 3 / 6 = split-bf16 terms");
+#define acc_(i, j) accp[TR ? (j) * NA + (i) : (i) * NB + (j)]
+  if constexpr (terms == 0) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 a[NA], b[NB];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[i] = lda(i, ks);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[j] = ldb(j, ks);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc_(i, j) = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), __uint_as_float(b[j][e]), acc_(i, j), 0, 0, 0);
+    }
+  } else if constexpr (terms == 3) {
+    u32x4 bh[NB], bl[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) split_terms2(ldb(j, 0), ldb(j, 1), bh[j], bl[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      u32x4 ah, al;
+      split_terms2(lda(i, 0), lda(i, 1), ah, al);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(al, bh[j], acc_(i, j));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(ah, bl[j], acc_(i, j));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(ah, bh[j], acc_(i, j));
+    }
+  } else {
+    u32x4 bh[NB], bl[NB], bm[NB];     // h = hi, l = lo, m = lo2
+#pragma unroll
+    for (int j = 0; j < NB; ++j) split_terms3(ldb(j, 0), ldb(j, 1), bh[j], bl[j], bm[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      u32x4 ah, al, am;
+      split_terms3(lda(i, 0), lda(i, 1), ah, al, am);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(al, bl[j], acc_(i, j));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(am, bh[j], acc_(i, j));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(ah, bm[j], acc_(i, j));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(al, bh[j], acc_(i, j));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(ah, bl[j], acc_(i, j));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(ah, bh[j], acc_(i, j));
+    }
+  }
+#undef acc_
+}
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 __device__ __forceinline__ u32x4 zero16() { return (u32x4){0u, 0u, 0u, 0u}; }
@@ -254,6 +352,12 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
     for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto compute_tile = [&](int buf) {
+    if constexpr (sizeof(T) == 4) {
+      // the weight fragment is the MFMA A operand; the activation side (MI fragments) is the one split once per k-tile
+      mma_f32_chunks<NI, MI, false, 0>(&acc[0][0],
+          [&](int i, int ks) { const int r = wn * 64 + i * 16 + fl; return Bs[buf * BN * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))]; },
+          [&](int i, int ks) { const int r = wm * (MI * 16) + i * 16 + fl; return As[buf * BM * 8 + r * 8 + ((ks * 4 + g) ^ (r & 7))]; });
+    } else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4 af[MI], bf[NI];
@@ -416,7 +520,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false, bool FAPPLY = false>
+          bool WIN = false, bool FAPPLY = false, int SPL = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
   static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
   // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
@@ -424,6 +528,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   // so the convolution output itself never travels to HBM.  The statistics that scale / shift derive from come from a
   // first, store-free pass of the same convolution (STATS instantiation with y == nullptr).
   static_assert(!FAPPLY || (sizeof(T) == 2 && MODE == MODE_FWD && !STATS && !BNEPI && !EXT), "fused BN-apply epilogue: forward bf16");
+  static_assert(SPL == 0 || sizeof(T) == 4, "split-bf16 terms: fp32 storage only");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int WN = BN / 64;           // waves along N
@@ -739,6 +844,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         __syncthreads();
       }
       if (issued < total) issue_next();
+      if constexpr (sizeof(T) == 4) {
+        if (!DIAG(1))
+          mma_f32_chunks<NI, MI, false, SPL>(&acc[0][0],
+              [&](int i, int ks) { const int r = wn * 64 + i * 16 + fl; return Bs[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))]; },
+              [&](int i, int ks) { const int r = wm * (MI * 16) + i * 16 + fl; return As[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))]; });
+      } else
       if (!DIAG(1))
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -1119,6 +1230,7 @@ struct WgradP {
   int xcd_map;   // 1: all tiles of a pixel range on one XCD (big tensors); 0: plain interleaving
   const void* zero;   // 16 zero bytes (padding source for the direct-to-LDS loads)
   int diag;
+  int split;     // fp32: 0 = exact fp32 MFMA, 3 / 6 = split-bf16 terms (simclr_set_f32_matmul)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -1376,9 +1488,9 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
 // MT (multi-tap k-tile, the stem: KW = 1, IC = 32 packed elements per kernel row, all 7 kernel rows in ONE 256-row k-tile so
 // that the gradient tensor is read once): every 16-byte chunk of a tile row has its OWN tap, so the tap offset is per lane
 // instead of per workgroup.  Needs 16-byte aligned sources (stride 2 on an even-width packed image: every pixel index even).
-template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false, bool MT = false>
+template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false, bool MT = false, int SPL = 0>
 __global__ __launch_bounds__(WK * WNN * 64,
-                             WK * WNN == 8 ? 1 : ((STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
+                             WK * WNN == 8 ? 1 : ((SPL == 0 && STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
 void conv_wgrad_dma(const WgradP p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BR = BRM * 4 * EPC;           // pixels per reduction chunk
@@ -1580,6 +1692,27 @@ void conv_wgrad_dma(const WgradP p) {
             acs[ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
                                                               __builtin_bit_cast(bf16x8, af[ki]), acs[ki], 0, 0, 0);
         }
+      }
+    } else if constexpr (SPL != 0) {
+      // split-bf16 terms: lane group g holds pixels {4j + g : j = 0..7} of a 32-pixel step for both operands
+      static_assert(!GRAM && BR % 32 == 0, "split-bf16 weight gradient: 32-pixel reduction steps, no Gram variant");
+#pragma unroll
+      for (int ks = 0; ks < BR / 32; ++ks) {
+        mma_f32_chunks<NI, KI, true, SPL>(&acc[0][0],
+            [&](int i, int h) {
+              u32x4 c;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                c[e] = *(const uint32_t*)(Bs + elem_off(B_RB, B_BLK, ks * 32 + (h * 4 + e) * 4 + g, wn * (NI * 16) + i * 16 + fl));
+              return c;
+            },
+            [&](int i, int h) {
+              u32x4 c;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                c[e] = *(const uint32_t*)(As + elem_off(A_RB, A_BLK, ks * 32 + (h * 4 + e) * 4 + g, wk * (KI * 16) + i * 16 + fl));
+              return c;
+            });
       }
     } else {
 #pragma unroll 4
@@ -2235,6 +2368,9 @@ __global__ void unpack_stem_dw(const float* __restrict__ src, float* __restrict_
 }
 
 // device address of g_zero16 (looked up once); nullptr if the lookup fails -- entry points refuse to launch then
+// fp32 matrix arithmetic of the forward and of the two backward GEMMs (process-wide, simclr_set_f32_matmul)
+static int g_f32_terms_fwd = 0, g_f32_terms_bwd = 0;
+
 static const void* zero_page() {
   static void* zp = nullptr;
   if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess) zp = nullptr;
@@ -2301,6 +2437,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   p.m_tiles = ceil_div(p.M, 128);
   p.n_tiles = ceil_div(p.N, BN);
   if (p.M <= 0) return;
+  p.split = MODE == MODE_FWD ? g_f32_terms_fwd : g_f32_terms_bwd;
 #ifdef SIMCLR_DIAG
   { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
 #endif
@@ -2344,8 +2481,18 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         return;
       }
     }
-#define LP(BNv, STv, BEv) \
-    hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv>), dim3(pg), dim3(256), plds, stream, p)
+    // fp32 storage: one instantiation per matrix arithmetic (exact fp32 MFMA, 3 or 6 split-bf16 terms)
+#define LPX(BNv, STv, BEv, EXv)                                                                                              \
+    do {                                                                                                                     \
+      if constexpr (sizeof(T) == 4) {                                                                                        \
+        if (p.split == 3) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3>), dim3(pg), dim3(256), plds, stream, p); \
+        else if (p.split == 6) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 6>), dim3(pg), dim3(256), plds, stream, p); \
+        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
+      } else {                                                                                                               \
+        hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
+      }                                                                                                                      \
+    } while (0)
+#define LP(BNv, STv, BEv) LPX(BNv, STv, BEv, false)
     if (p.fapply) {
       if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, 64, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
       else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, 128, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
@@ -2368,16 +2515,15 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       return;
     }
     if (!p.bn_mode && p.x2) {  // K-extended dgrad, plain epilogue (the conv input is not a BatchNorm output: block entry)
-      if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 64, 4, 2, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
-      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
+      if (BN == 64) LPX(64, false, false, true); else LPX(128, false, false, true);
     } else if (p.bn_mode && p.x2) {   // K-extended dgrad (folded BatchNorm backward of the consumer's output) + fused BN reduce
-      if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 64, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
-      else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, true, true, true>), dim3(pg), dim3(256), plds, stream, p);
+      if (BN == 64) LPX(64, true, true, true); else LPX(128, true, true, true);
     } else if (p.bn_mode) {    // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
       if (BN == 64) LP(64, true, true); else LP(128, true, true);
     } else if (BN == 64) { if (st) LP(64, true, false); else LP(64, false, false); }
     else { if (st) LP(128, true, false); else LP(128, false, false); }
 #undef LP
+#undef LPX
     return;
   }
 #define L(BNv, STv)                                                                                    \
@@ -2441,6 +2587,19 @@ int launch_igemm(const ConvP& p0, hipStream_t stream) {
 }  // namespace
 
 extern "C" {
+
+// Matrix arithmetic of the fp32 (parity) convolution / dense kernels: number of bf16 terms per product, separately for
+// the forward GEMM and for the two backward GEMMs (dgrad, wgrad).  0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32, the
+// default), 3 = hi*hi + hi*lo + lo*hi (~2^-17 relative per product), 6 = all terms of weight >= 2^-18 (fp32 level).
+// Storage stays fp32; bf16 launches are unaffected.  Process-wide; returns 1 on a bad argument.
+int simclr_set_f32_matmul(int fwd_terms, int bwd_terms) {
+  SIMCLR_CHECK_ARG((fwd_terms == 0 || fwd_terms == 3 || fwd_terms == 6) && (bwd_terms == 0 || bwd_terms == 3 || bwd_terms == 6),
+                   "set_f32_matmul: terms must be 0, 3 or 6 (got %d, %d)", fwd_terms, bwd_terms);
+  g_f32_terms_fwd = fwd_terms;
+  g_f32_terms_bwd = bwd_terms;
+  return 0;
+}
+int simclr_get_f32_matmul(int which) { return which == 0 ? g_f32_terms_fwd : g_f32_terms_bwd; }
 
 // Number of partial-statistics slots that makes the statistics of simclr_conv2d_fwd / simclr_conv2d_dgrad_bn
 // deterministic for an output of M rows x C channels (one slot per persistent workgroup of an N-tile).
@@ -2782,6 +2941,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   { const char* e = getenv("SIMCLR_WGRAD_XCD"); if (e && atoi(e) >= 0) p.xcd_map = atoi(e); }
 #endif
   p.zero = zero_page();
+  p.split = g_f32_terms_bwd;
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d_wgrad: zero page symbol not found");
   const int grid = p.k_tiles * p.n_tiles * (p.xcd_map ? ceil_div(p.splits, 8) * 8 : p.splits);
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
@@ -2817,11 +2977,18 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
       else LW(float, 32, 64);
     }
   } else if (dtype != SIMCLR_DT_BF16) {
-    if (bkw == 128 && bnw == 128) LD(float, 128, 128, 2, 2);
-    else if (bkw == 128) LD(float, 128, 64, 2, 2);
-    else if (bkw == 64 && bnw == 128) LD(float, 64, 128, 2, 2);
-    else if (bkw == 64) LD(float, 64, 64, 2, 2);
-    else LD(float, 32, 64, 2, 2);
+#define LDS_(A, B)                                                                                                          \
+    do {                                                                                                                     \
+      if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
+      else if (p.split == 6) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 6>), dim3(grid), dim3(256), lds, stream, p); \
+      else LD(float, A, B, 2, 2);                                                                                            \
+    } while (0)
+    if (bkw == 128 && bnw == 128) LDS_(128, 128);
+    else if (bkw == 128) LDS_(128, 64);
+    else if (bkw == 64 && bnw == 128) LDS_(64, 128);
+    else if (bkw == 64) LDS_(64, 64);
+    else LDS_(32, 64);
+#undef LDS_
   } else if (stages == 2) {
     if (bkw == 128 && bnw == 128) LD(uint16_t, 128, 128, 2, 2);
     else if (bkw == 128) LD(uint16_t, 128, 64, 2, 2);

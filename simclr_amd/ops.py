@@ -410,8 +410,23 @@ class _StatsArena:
 _ARENA = _StatsArena()
 
 
+F32_MATMUL_TERMS = {'exact': (0, 0), 'bf16x3': (3, 3), 'bf16x6': (6, 6), 'bf16x6_3': (6, 3)}
+
+
+def set_f32_matmul(mode):
+    """Matrix arithmetic of the fp32 convolution / dense kernels (FLAGS.f32_matmul; simclr_set_f32_matmul).  Process-wide."""
+    if mode not in F32_MATMUL_TERMS:
+        raise ValueError('f32_matmul must be one of %s, got %r' % (sorted(F32_MATMUL_TERMS), mode))
+    fwd, bwd = F32_MATMUL_TERMS[mode]
+    L = lib()
+    if (L.get_f32_matmul(0), L.get_f32_matmul(1)) != (fwd, bwd):
+        L.set_f32_matmul(fwd, bwd)
+
+
 def begin_step(device):
-    """Zero the statistics arena; call once at the start of every training step."""
+    """Zero the statistics arena and select the fp32 matrix arithmetic; call once at the start of every training step."""
+    from .flags import FLAGS
+    set_f32_matmul(getattr(FLAGS, 'f32_matmul', 'exact'))
     _ARENA.begin_step(device)
 
 

@@ -11,6 +11,17 @@ pytestmark = pytest.mark.gpu
 BF, F32 = torch.bfloat16, torch.float32
 
 
+@pytest.fixture(autouse=True)
+def _exact_f32_matmul():
+    """simclr_set_f32_matmul is process-wide: every test starts (and leaves) the library in the exact fp32 mode."""
+    from simclr_amd import ops
+    from simclr_amd.flags import FLAGS
+    ops.set_f32_matmul('exact')
+    yield
+    FLAGS.update(f32_matmul='exact')
+    ops.set_f32_matmul('exact')
+
+
 def _assert(results):
     bad = [r for r in results if not r['ok']]
     assert not bad, '\n'.join('%s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']) for r in bad)
@@ -89,6 +100,24 @@ def test_conv_fwd_dgrad_wgrad(V, H, Cin, Cout, k, s, dtype):
     _assert(gc.check_conv(V, H, H, Cin, Cout, k, s, dtype))
 
 
+@pytest.mark.parametrize('matmul', ['bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s', [CONV_CASES[i] for i in (0, 1, 2, 3, 4, 5, 8, 10)])
+def test_conv_f32_split_bf16_matmul(V, H, Cin, Cout, k, s, matmul):
+    """The fast parity mode (simclr_set_f32_matmul): fp32 storage, every product as 3 / 6 bf16 MFMA terms, against float64."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_conv(V, H, H, Cin, Cout, k, s, F32, matmul=matmul))
+
+
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s,bn_case', [(1024, 14, 256, 256, 3, 1, (2, 0)), (256, 56, 256, 64, 1, 1, (3, 1)),
+                                                       (256, 56, 128, 128, 3, 2, None), (256, 28, 128, 512, 1, 1, (1, 0))])
+def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case):
+    """Split-bf16 arithmetic on the persistent / XCD-mapped code paths the benchmark runs (full-tensor float64 reference)."""
+    from simclr_amd import ops
+    from tests import gpu_checks as gc
+    ops.set_f32_matmul('bf16x6_3')
+    _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, F32, bn_case=bn_case, bwd_tol_scale=2.0))
+
+
 # BASELINE cfg2 (ResNet-50 1x, 224 px) layer classes at the row counts the benchmark runs: every persistent
 # igemm workgroup walks several tiles (count >= 2), wgrad takes the XCD-mapped / 256x256 paths.
 # (V, H, Cin, Cout, k, stride, bn_case=(mask_mode, accumulate) of the fused dgrad + BN-backward reduce)
@@ -156,6 +185,17 @@ def test_train_step_resnet50_224_batch32_fixed_thresholds(compute_dtype):
     (f32: north_star 1e-3 loss / 1e-5 embeddings; bf16: loss 1e-2, gradient 1-cos 1e-2) on image-like inputs."""
     from tests import gpu_checks as gc
     res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype=compute_dtype)
+    for r in res:
+        print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
+    _assert(res)
+    torch.cuda.empty_cache()
+
+
+def test_train_step_resnet50_224_batch32_fast_parity_mode():
+    """the same step with fp32 storage and split-bf16 matrix arithmetic (six terms forward, three
+    backward) must pass the FP32 gates -- north_star's 1e-3 loss / 1e-5 embeddings included."""
+    from tests import gpu_checks as gc
+    res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f32', f32_matmul='bf16x6_3')
     for r in res:
         print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
     _assert(res)

@@ -127,6 +127,48 @@ def main():
             del x, dy, y, dx
         print('weighted totals (ms): fwd+stats %.2f / %.2f  fwd %.2f / %.2f  dgrad %.2f / %.2f  dgrad_bn %.2f / %.2f' % (
             tot[0] / 1e3, tot[4] / 1e3, tot[1] / 1e3, tot[5] / 1e3, tot[2] / 1e3, tot[6] / 1e3, tot[3] / 1e3, tot[7] / 1e3), flush=True)
+    if 'comparator' in what:
+        # the vendor libraries on the SAME shapes, as a yardstick only (never on the product path):
+        # MIOpen through torch.nn.functional.conv2d (bf16, channels_last = NHWC memory) forward / data gradient / weight
+        # gradient, and hipBLASLt through torch.matmul for the 1x1 stride-1 layers (the same GEMMs without the conv wrapper).
+        import torch.nn.functional as F
+        torch.backends.cudnn.benchmark = os.environ.get('SIMCLR_CMP_FIND', '0') == '1'     # default: MIOpen immediate mode (heuristic pick)
+        print('%-26s | ours fwd dgrad wgrad | MIOpen fwd dgrad wgrad | hipBLASLt fwd dgrad wgrad | bound us (MFMA / HBM@8)' % 'layer')
+        for (H, Cin, Cout, k, s, cnt) in R50:
+            pad = (k - 1) // 2
+            OH = (H + (k - 1) - k) // s + 1
+            x = torch.randn(V, H, H, Cin, device=dev).to(dt)
+            w = (torch.randn(k, k, Cin, Cout, device=dev) * (k * k * Cin) ** -0.5)
+            dy = torch.randn(V, OH, OH, Cout, device=dev).to(dt)
+            w_t = ops.prep_weights(w, 0, dt); w_d = ops.prep_weights(w, 1, dt)
+            y = torch.empty(V, OH, OH, Cout, device=dev, dtype=dt)
+            dx = torch.empty(V, H, H, Cin, device=dev, dtype=dt)
+            dw = torch.empty(k * k * Cin, Cout, device=dev)
+            ours = [timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=None, out=y), args.iters),
+                    timeit(lambda: ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H, out=dx), args.iters),
+                    timeit(lambda: ops.conv2d_wgrad(x, dy, k, k, s, pad, out=dw), args.iters)]
+            xn = x.permute(0, 3, 1, 2)                       # NCHW view of the NHWC tensor = channels_last
+            dyn = dy.permute(0, 3, 1, 2)
+            wn = w.permute(3, 2, 0, 1).to(dt).contiguous(memory_format=torch.channels_last)
+            mi = [float('nan')] * 3
+            try:
+                mi[0] = timeit(lambda: F.conv2d(xn, wn, None, s, pad), args.iters)
+                mi[1] = timeit(lambda: torch.ops.aten.convolution_backward(dyn, xn, wn, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]), args.iters)
+                mi[2] = timeit(lambda: torch.ops.aten.convolution_backward(dyn, xn, wn, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]), args.iters)
+            except Exception as e:  # noqa: BLE001
+                print('   MIOpen failed on this shape:', repr(e)[:200])
+            bl = [float('nan')] * 3
+            if k == 1 and s == 1:
+                A = x.view(-1, Cin); G = dy.view(-1, Cout); W2 = w.view(Cin, Cout).to(dt); W2t = W2.t().contiguous()
+                bl = [timeit(lambda: torch.matmul(A, W2), args.iters), timeit(lambda: torch.matmul(G, W2t), args.iters),
+                      timeit(lambda: torch.matmul(A.t(), G), args.iters)]
+            fl = 2.0 * V * OH * OH * k * k * Cin * Cout
+            by = x.element_size() * (x.numel() + y.numel() + w.numel())
+            name = '%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt)
+            print('%-26s | %5.0f %5.0f %5.0f | %5.0f %5.0f %5.0f | %5.0f %5.0f %5.0f | %4.0f / %4.0f' % (
+                name, *ours, *mi, *bl, fl / 2.5e9, by / 8e6), flush=True)
+            res.append(dict(layer='cmp ' + name, ours=ours, miopen=mi, hipblaslt=bl, flops=fl, bytes=by, count=cnt))
+            del x, dy, y, dx, xn, dyn
     if 'bn' in what:
         print('%-22s %9s %9s %9s %9s | GB/s apply resid bwd_red bwd_app' % ('tensor', 'apply_us', 'resid_us', 'bwdred_us', 'bwdapp_us'))
         shapes = [(56, 64, 7), (56, 256, 4), (28, 128, 8), (28, 512, 5), (14, 256, 12), (14, 1024, 7), (7, 512, 6), (7, 2048, 4)]
