@@ -80,6 +80,14 @@ int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long
  * simclr_get_f32_matmul(0 | 1) returns the forward | backward setting. */
 int simclr_set_f32_matmul(int fwd_terms, int bwd_terms);
 int simclr_get_f32_matmul(int which);
+/* Scheduling of simclr_conv2d_fwd / _dgrad / _dgrad_bn / _fwd_bn_apply (no reference counterpart: TensorFlow's runtime
+ * schedules its own kernels): the persistent grid runs floor(tiles / workgroups) whole output tiles per workgroup and
+ * shares every left-over tile between 2..8 workgroups along the reduction ("split tail"); the partial fp32 accumulators
+ * meet in a scratch buffer the LIBRARY owns -- the one exception to "never allocates": <= 64 MB per stream, hipMalloc'ed
+ * on the first launch that needs it (outside any graph capture), kept for the life of the process.  Results are
+ * deterministic (fixed summation order).  Environment SIMCLR_IGEMM_SPLIT=0 disables it.  The hook below returns the
+ * number of parts the most recent launch used (0 = whole tiles only); tests use it to prove the path ran. */
+int simclr_conv2d_last_split_parts(void);
 /* master HWIO fp32 -> compute copies.  mode 0: [Cout][KH*KW*Cin] (fwd), 1: [Cin][KH*KW*Cout]
  * (dgrad), 2: stem [Cout][KHP][KWP][4] zero padded.  CinP/CoutP (0 = none): zero-padded channel dims. */
 int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,

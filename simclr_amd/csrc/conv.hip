@@ -70,6 +70,15 @@ struct ConvP {
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
   int split;       // fp32 instantiations: 0 = exact fp32 MFMA, 3 / 6 = split-bf16 terms (simclr_set_f32_matmul)
+  // Split tail (tile-quantisation fix of the persistent grid): every workgroup walks `rem_full` whole M-tiles; the
+  // rem_tiles M-tiles left over (fewer than there are workgroups per N-tile) are each shared by rem_parts consecutive
+  // workgroups along the REDUCTION (k-steps [j*KT/P, (j+1)*KT/P) for part j).  Parts j > 0 store their fp32 accumulators
+  // into part_ws (slot (tile * n_tiles + nt) * (rem_parts - 1) + j - 1, lane-linear) and publish part_flags[slot] = seq
+  // (agent-scope release); part 0 acquires, adds the parts in the order j = 1, 2, ... (deterministic) and runs the epilogue.
+  int rem_full, rem_tiles, rem_parts;
+  float* part_ws;
+  unsigned* part_flags;
+  unsigned seq;
 };
 
 // Diagnostic build (build.sh diag -> libsimclr_hip_diag.so): parts of a kernel can be switched off at run time
@@ -588,7 +597,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   const int mslots = gridDim.x / p.n_tiles;
   const int mslot = (l / p.n_tiles) * 8 + xcd;
   const int n0 = nt * BN;
-  const int count = (mslot < p.m_tiles) ? (p.m_tiles - mslot + mslots - 1) / mslots : 0;
+  // split tail: rem_parts >= 2 -> every workgroup owns exactly rem_full whole tiles, then (mslot < rem_tiles * rem_parts)
+  // part `pj` of remainder tile `ptile` over the k-steps (WIN: 64-channel chunks) [pka, pkb)
+  // (the part's geometry is recomputed from the kernel arguments where it is needed -- tile transitions only -- instead of
+  // living in registers across the k-loop: these kernels sit at the SGPR / VGPR limits)
+  const int count = p.rem_parts >= 2 ? p.rem_full : ((mslot < p.m_tiles) ? (p.m_tiles - mslot + mslots - 1) / mslots : 0);
+  const bool has_part = p.rem_parts >= 2 && mslot < p.rem_tiles * p.rem_parts;
+  auto part_tile = [&]() __attribute__((always_inline)) { return p.rem_full * mslots + mslot / p.rem_parts; };
+  auto part_index = [&]() __attribute__((always_inline)) { return mslot % p.rem_parts; };
   const int kpt = p.IC / BK;
   const int kpt2 = EXT ? p.ic2 / BK : 0;          // k-tiles of the second source (appended after the regular taps)
   const int KT = p.ntaps * kpt + kpt2;
@@ -715,7 +731,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   // k-tiles are in flight across every barrier (counted vmcnt leaves the newest one outstanding).
   int it = 0, iti = 0, ici = 0, ibuf = 0, buf = 0;
   int issued = 0, consumed = 0;
-  const int total = count * KT;
+  const int KU = WIN ? kpt : KT;                          // reduction units of one tile the tail is split in
+  auto part_begin = [&]() __attribute__((always_inline)) { return (part_index() * KU) / p.rem_parts; };
+  auto part_end = [&]() __attribute__((always_inline)) { return ((part_index() + 1) * KU) / p.rem_parts; };
+  const int part_units = has_part ? part_end() - part_begin() : 0;
+  const int total = WIN ? (count * kpt + part_units) * 9 : count * KT + part_units;
   auto issue_next = [&]() __attribute__((always_inline)) {
     issue_tile(iti, ici, ibuf);
     ibuf = (ibuf + 1 == STAGES) ? 0 : ibuf + 1;
@@ -724,14 +744,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       ici = 0;
       if (++iti == p.ntaps + ((EXT && kpt2 > 0) ? 1 : 0)) {
         iti = 0;
-        if (++it < count) setup_rows(mslot + it * mslots);
+        ++it;
+        if (it < count) setup_rows(mslot + it * mslots);
+        else if (it == count && has_part) {           // the partial tile starts at k-step part_begin()
+          setup_rows(part_tile());
+          const int pka = part_begin();
+          iti = pka / kpt; ici = pka - iti * kpt;      // (EXT: steps >= ntaps * kpt belong to the second source)
+          if (EXT && iti > p.ntaps) { iti = p.ntaps; ici = pka - p.ntaps * kpt; }
+        }
       }
-      if (it < count && iti < p.ntaps) set_tap(iti);
+      if (it < count + (has_part ? 1 : 0) && iti < p.ntaps) set_tap(iti);
     }
   };
   // ---- halo-window variant: B tiles run one step ahead through the 2-stage ring, the A window is per (tile, chunk)
   const int Wd = p.IW;
-  int wti = 0, wci = 0;                    // B issue cursor: (tap, chunk), chunk-major steps
+  int wti = 0, wci = (WIN && count == 0 && has_part) ? part_begin() : 0, wit = 0;   // B issue cursor: (tap, chunk) of tile wit, chunk-major steps
   auto issue_b = [&]() __attribute__((always_inline)) {
     const int k0 = (int)((p.tap_w >> (4 * wti)) & 15) * p.IC + wci * BK;
     unsigned char* b_dst = (unsigned char*)(Bw + ibuf * (BN * 8)) + wave * BJ * 1024;
@@ -742,7 +769,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     }
     ibuf ^= 1;
     ++issued;
-    if (++wti == 9) { wti = 0; if (++wci == kpt) wci = 0; }
+    if (++wti == 9) {
+      wti = 0;
+      if (++wci == kpt) { wci = 0; if (++wit == count && has_part) wci = part_begin(); }     // next: the partial tile's first chunk
+    }
   };
   auto issue_win = [&](int m0w, int c) __attribute__((always_inline)) {
     for (int j = 0; j < p.win_j; ++j) {
@@ -754,23 +784,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   };
   if (WIN) {
     if (tid < 8) Wn[zrow * 8 + tid] = zero16();
-    if (count > 0) issue_b();
-  } else if (count > 0) {
-    setup_rows(mslot);
-    set_tap(0);
+    if (total > 0) issue_b();
+  } else if (total > 0) {
+    if (count > 0) {
+      setup_rows(mslot);
+      set_tap(0);
+    } else {                                   // only the partial tile: start at k-step part_begin()
+      setup_rows(part_tile());
+      const int pka = part_begin();
+      iti = pka / kpt; ici = pka - iti * kpt;
+      if (EXT && iti > p.ntaps) { iti = p.ntaps; ici = pka - p.ntaps * kpt; }
+      if (iti < p.ntaps) set_tap(iti);
+    }
 #pragma unroll
     for (int sidx = 0; sidx < STAGES - 1; ++sidx)
       if (issued < total) issue_next();
   }
-  for (int ct = 0; ct < count; ++ct) {
-    const int m0 = (mslot + ct * mslots) * BM;
+  for (int ct = 0; ct < count + (has_part ? 1 : 0); ++ct) {
+    const bool part = ct == count;                       // the shared remainder tile (split tail)
+    const int m0 = (part ? part_tile() : mslot + ct * mslots) * BM;
+    const int kt0 = part ? part_begin() : 0, kt1 = part ? part_end() : KU;
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (WIN) {
-      const int m0w = (mslot + ct * mslots) * BM;
+      const int m0w = m0;
       // per fragment row: window row of the centre pixel and the 9-bit validity mask of its 3x3 neighbourhood
       int rb[MI];
       unsigned vm[MI];
@@ -820,7 +860,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           win_mma(af, bf);
         }
       };
-      for (int c = 0; c < kpt; ++c) {
+      for (int c = kt0; c < kt1; ++c) {
         __syncthreads();                     // every wave is done with the previous window / C staging contents
         issue_win(m0w, c);
         for (int t = 0; t < 9; ++t) {
@@ -833,7 +873,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         }
       }
     } else
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
       // the tile about to be consumed must have landed; newer tiles may stay in flight
       if (STAGES == 3 && issued - consumed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ + BJ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -880,6 +920,49 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     if (DIAG(4)) {
       if (acc[0][0][0] == 12345.678f) Y[0] = (T)0;     // keeps the accumulators live
       continue;
+    }
+    if (part) {
+      // split tail: fp32 accumulators travel lane-linear ([fragment][thread] float4: fully coalesced both ways).
+      // Publish / acquire exactly as cdna_hip_programming.md section 5 prescribes for in-launch split-K partials: plain stores,
+      // every wave drains vmcnt, barrier, ONE lane: agent-scope release fence + drained flag store; the owner polls relaxed,
+      // fences (acquire) once, barrier, plain loads.  Correct for any placement of the parts over CUs / XCDs.
+      const long long slot0 = ((long long)(mslot / p.rem_parts) * p.n_tiles + nt) * (p.rem_parts - 1);
+      const int pj = part_index();
+      constexpr int FR = NI * MI;
+      if (pj != 0) {
+        f32x4* dst = (f32x4*)p.part_ws + (slot0 + pj - 1) * (long long)(FR * NTH);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) dst[(ni * MI + mi) * NTH + tid] = acc[ni][mi];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(p.part_flags + slot0 + pj - 1, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        continue;                                        // the last tile of this workgroup: on to the statistics flush
+      }
+      if (tid == 0) {
+        for (int j = 1; j < p.rem_parts; ++j) {
+          int spins = 0;                                 // bounded: a lost partner must not hang the GPU (~0.5 s)
+          while (__hip_atomic_load(p.part_flags + slot0 + j - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq &&
+                 ++spins < (1 << 22))
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      for (int j = 1; j < p.rem_parts; ++j) {
+        const f32x4* src = (const f32x4*)p.part_ws + (slot0 + j - 1) * (long long)(FR * NTH);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {              // one row of fragments at a time: the loads must not all be live at once
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] += src[(ni * MI + mi) * NTH + tid];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     auto row_off = [&](int m) __attribute__((always_inline)) -> long long {
       if (m >= p.M) return -1;
@@ -2430,6 +2513,69 @@ static bool igemm_narrow(const ConvP& p, size_t esz) {
   return esz == 2 && p.N > 64 && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.x2 && p.K <= kmax && p.N / 64 <= 64;
 }
 
+// ---- split tail of the persistent forward / dgrad grid (ConvP::rem_*) -------------------------------------------------
+// The persistent grid gives every workgroup ceil(m_tiles / mslots) tiles although the last round is mostly empty: 3.06
+// rounds of work cost 4 (7^2 layers at 1024 views: +31 %), 6.1 cost 7 (14^2: +14 %).  With the split tail every workgroup
+// runs floor(m_tiles / mslots) whole tiles and the R left-over tiles are shared along the reduction by P = mslots / R
+// workgroups each (at most 8, at least two k-steps per part), combined through an fp32 scratch owned by the library:
+// one buffer per stream (launches of one stream are ordered, so a slot is free again when the next launch starts),
+// allocated on first use, grown when a launch needs more.  SIMCLR_IGEMM_SPLIT=0 switches it off (A/B runs).
+struct SplitScratch { hipStream_t stream; float* ws; size_t floats; unsigned* flags; size_t nflags; unsigned seq; };
+static SplitScratch g_split_scratch[8];
+static int g_split_scratch_n = 0;
+
+// units: pieces one tile's reduction can be cut in (k-steps; 64-channel chunks of nine k-steps on the halo-window path)
+static int g_last_split_parts = 0;      // simclr_conv2d_last_split_parts (tests)
+static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size_t tile_floats, hipStream_t stream) {
+  g_last_split_parts = 0;
+  p.rem_parts = 0; p.rem_full = 0; p.rem_tiles = 0; p.part_ws = nullptr; p.part_flags = nullptr; p.seq = 0;
+  const char* e = getenv("SIMCLR_IGEMM_SPLIT");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || p.n_tiles <= 0 || grid % p.n_tiles != 0) return true;
+  const int mslots = grid / p.n_tiles;
+  const int full = p.m_tiles / mslots, R = p.m_tiles - full * mslots;
+  const int max_parts = mode > 1 ? mode : 8;
+  int P = R > 0 ? mslots / R : 0;
+  if (P > max_parts) P = max_parts;
+  const int max_by_steps = unit_steps >= 2 ? units : units / 2;      // at least two k-steps per part
+  if (P > max_by_steps) P = max_by_steps;
+  // nothing to gain: no remainder, too few workgroups per remainder tile, short reductions (streaming layers: the
+  // partial exchange would cost more than the idle round), or so many rounds that one more is noise
+  if (R == 0 || full == 0 || P < 2 || units * unit_steps < 8 || full > 24) return true;
+  const size_t slots = (size_t)R * p.n_tiles * (P - 1);
+  SplitScratch* sc = nullptr;
+  for (int i = 0; i < g_split_scratch_n; ++i)
+    if (g_split_scratch[i].stream == stream) sc = &g_split_scratch[i];
+  if (!sc) {
+    if (g_split_scratch_n == 8) return true;        // more streams than scratch buffers: run without the split
+    sc = &g_split_scratch[g_split_scratch_n++];
+    *sc = SplitScratch{stream, nullptr, 0, nullptr, 0, 0};
+  }
+  if (sc->floats < slots * tile_floats || sc->nflags < slots) {
+    // grow (hipFree synchronises with the device: earlier launches that use the old buffers have finished)
+    if (sc->ws) (void)hipFree(sc->ws);
+    if (sc->flags) (void)hipFree(sc->flags);
+    sc->ws = nullptr; sc->flags = nullptr; sc->floats = 0; sc->nflags = 0;
+    const size_t want_f = slots * tile_floats, want_n = slots < 1024 ? 1024 : slots;
+    if (hipMalloc((void**)&sc->ws, want_f * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&sc->flags, want_n * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(sc->flags, 0, want_n * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (sc->ws) (void)hipFree(sc->ws);
+      if (sc->flags) (void)hipFree(sc->flags);
+      sc->ws = nullptr; sc->flags = nullptr;
+      return true;                                   // no scratch: the un-split schedule is still correct
+    }
+    sc->floats = want_f; sc->nflags = want_n; sc->seq = 0;
+  }
+  p.rem_full = full; p.rem_tiles = R; p.rem_parts = P;
+  g_last_split_parts = P;
+  p.part_ws = sc->ws; p.part_flags = sc->flags;
+  p.seq = ++sc->seq;
+  if (p.seq == 0) p.seq = ++sc->seq;                  // 0 is the "never written" value of a flag
+  return true;
+}
+
 template <typename T, int MODE>
 void launch_igemm_one(ConvP p, hipStream_t stream) {
   const bool narrow = igemm_narrow(p, sizeof(T));
@@ -2469,6 +2615,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         int pg2 = max(unit, (256 / unit) * unit);
         pg2 = min(pg2, ceil_div(p.m_tiles, 8) * unit);
         const size_t lds2 = 2 * (256 + 256) * 128 + 5 * 256 * sizeof(float) + 256 * sizeof(long long) + 8 * 256 * 2 * sizeof(float);
+        igemm_split_tail(p, pg2, p.ntaps * (p.IC / 64) + (p.x2 ? p.ic2 / 64 : 0), 1, (size_t)256 * 256, stream);
 #define L2(STv, BEv, EXv, FAv) \
         hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv>), dim3(pg2), dim3(512), lds2, stream, p)
         if (p.fapply) { if constexpr (MODE == MODE_FWD) L2(false, false, false, true); }
@@ -2481,6 +2628,15 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         return;
       }
     }
+    const int bk_elems = 128 / (int)sizeof(T);
+    const bool win3 = [&] {
+      static const bool no_win = []{ const char* e = getenv("SIMCLR_CONV3_WIN"); return e && e[0] == '0'; }();
+      return sizeof(T) == 2 && !no_win && !p.fapply && !p.x2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.cs == 1 &&
+             p.ntaps == 9 && p.IH == p.OH && p.IW == p.OW && p.IW <= 62;
+    }();
+    // reduction units the tail can be split in: k-steps, or 64-channel chunks on the halo-window path
+    igemm_split_tail(p, pg, win3 ? p.IC / bk_elems : p.ntaps * (p.IC / bk_elems) + (p.x2 ? p.ic2 / bk_elems : 0),
+                     win3 ? 9 : 1, (size_t)128 * BN, stream);
     // fp32 storage: one instantiation per matrix arithmetic (exact fp32 MFMA, 3 or 6 split-bf16 terms)
 #define LPX(BNv, STv, BEv, EXv)                                                                                              \
     do {                                                                                                                     \
@@ -2499,9 +2655,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       return;
     }
     // 3x3 stride-1 bf16: halo-window operand path (one window load per 64-channel chunk instead of nine gathers)
-    static const bool no_win = []{ const char* e = getenv("SIMCLR_CONV3_WIN"); return e && e[0] == '0'; }();
-    if (sizeof(T) == 2 && !no_win && !p.x2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.cs == 1 &&
-        p.ntaps == 9 && p.IH == p.OH && p.IW == p.OW && p.IW <= 62) {
+    if (win3) {
       const int rows = ((128 + 2 * (p.IW + 1)) + 31) / 32 * 32;
       p.win_j = rows / 32;
       p.win_bytes = rows * 128 > 128 * BN * 2 ? rows * 128 : 128 * BN * 2;
@@ -2600,6 +2754,9 @@ int simclr_set_f32_matmul(int fwd_terms, int bwd_terms) {
   return 0;
 }
 int simclr_get_f32_matmul(int which) { return which == 0 ? g_f32_terms_fwd : g_f32_terms_bwd; }
+// Test hook: into how many parts the most recent forward / dgrad launch of this process split each left-over tile
+// (0 = the launch ran whole tiles only).  See "split tail" above.
+int simclr_conv2d_last_split_parts(void) { return g_last_split_parts; }
 
 // Number of partial-statistics slots that makes the statistics of simclr_conv2d_fwd / simclr_conv2d_dgrad_bn
 // deterministic for an output of M rows x C channels (one slot per persistent workgroup of an N-tile).

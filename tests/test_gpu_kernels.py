@@ -118,6 +118,39 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case):
     _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, F32, bn_case=bn_case, bwd_tol_scale=2.0))
 
 
+# (V, H, Cin, Cout, k, stride, bn_case, dtype, tile): shapes with one full round of the persistent grid plus a remainder
+SPLIT_TAIL_CASES = [
+    (24, 56, 512, 128, 1, 1, (2, 0), BF, None),      # 1x1, 8 k-steps: 588 M-tiles on 512 workgroups -> 76 left-over tiles in 4 parts
+    (24, 56, 128, 128, 3, 1, (3, 1), BF, None),      # halo-window 3x3: split by 64-channel chunk (2 parts)
+    (96, 56, 128, 128, 3, 2, None, BF, None),        # strided 3x3 gather (forward) / class-decomposed dgrad
+    (24, 56, 256, 256, 1, 1, (2, 0), BF, '256'),     # 256 x 256 tile: 294 M-tiles on 256 workgroups
+    (24, 56, 256, 128, 1, 1, (1, 0), F32, None),     # fp32 storage: 8 k-steps of 32
+]
+
+
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s,bn_case,dtype,tile', SPLIT_TAIL_CASES)
+def test_conv_split_tail_paths(V, H, Cin, Cout, k, s, bn_case, dtype, tile):
+    """The left-over tiles of the persistent grid are shared along the reduction by several workgroups (fp32 partials
+    through the library's scratch, agent-scope release / acquire): full tensors vs float64, and the path must have run."""
+    from simclr_amd import ops
+    from simclr_amd._lib import lib
+    from tests import gpu_checks as gc
+    if tile:
+        os.environ['SIMCLR_IGEMM_TILE'] = tile
+    try:
+        x = torch.randn(V, H, H, Cin, device='cuda').to(dtype)
+        w_t = ops.prep_weights(torch.randn(k, k, Cin, Cout, device='cuda') * 0.05, 0, dtype)
+        OH = (H + (k - 1) - k) // s + 1
+        ops.conv2d_fwd(x, w_t, k, k, s, (k - 1) // 2, OH, OH)
+        assert lib().conv2d_last_split_parts() >= 2, 'this shape was meant to exercise the split tail'
+        del x, w_t
+        res = gc.check_conv_bench_path(V, H, Cin, Cout, k, s, dtype, bn_case=bn_case)
+        res += gc.check_conv_bench_path(V, H, Cin, Cout, k, s, dtype, bn_case=bn_case, seed=1)     # scratch slots reused
+    finally:
+        os.environ.pop('SIMCLR_IGEMM_TILE', None)
+    _assert(res)
+
+
 # BASELINE cfg2 (ResNet-50 1x, 224 px) layer classes at the row counts the benchmark runs: every persistent
 # igemm workgroup walks several tiles (count >= 2), wgrad takes the XCD-mapped / 256x256 paths.
 # (V, H, Cin, Cout, k, stride, bn_case=(mask_mode, accumulate) of the fused dgrad + BN-backward reduce)
