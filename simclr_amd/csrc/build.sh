@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unuse
 mkdir -p $B
 pids=()
 for f in runtime ntxent lars conv bn pool augment; do
-  if [ ! -f $B/$f.o ] || [ $f.hip -nt $B/$f.o ] || [ common.h -nt $B/$f.o ]; then
+  if [ ! -f $B/$f.o ] || [ $f.hip -nt $B/$f.o ] || [ common.h -nt $B/$f.o ] || { [ $f = conv ] && [ igemm_wide.h -nt $B/$f.o ]; }; then
     hipcc $FLAGS -c $f.hip -o $B/$f.o &
     pids+=($!)
   fi

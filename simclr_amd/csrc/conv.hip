@@ -79,6 +79,9 @@ struct ConvP {
   float* part_ws;
   unsigned* part_flags;
   unsigned seq;
+  unsigned x_bytes;  // conv_igemm_wide: size of the gathered tensor in bytes (range check of its buffer descriptor)
+  // conv_igemm_wide: (images, class rows, class columns) that 8, 128 and 136 consecutive GEMM rows advance an output pixel
+  int rs_dq[3], rs_drow[3], rs_dcol[3];
 };
 
 // Diagnostic build (build.sh diag -> libsimclr_hip_diag.so): parts of a kernel can be switched off at run time
@@ -923,25 +926,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     }
     if (part) {
       // split tail: fp32 accumulators travel lane-linear ([fragment][thread] float4: fully coalesced both ways).
-      // Publish / acquire exactly as cdna_hip_programming.md section 5 prescribes for in-launch split-K partials: plain stores,
-      // every wave drains vmcnt, barrier, ONE lane: agent-scope release fence + drained flag store; the owner polls relaxed,
-      // fences (acquire) once, barrier, plain loads.  Correct for any placement of the parts over CUs / XCDs.
+      // Publish / acquire as cdna_hip_programming.md section 5 prescribes for in-launch split-K partials (write-through form):
+      // sc1 stores, every wave drains vmcnt, barrier, ONE lane stores the flag (relaxed, agent scope); the owner polls
+      // relaxed, fences (acquire, agent) once, barrier, plain loads.  Correct for any placement of the parts over CUs / XCDs.
       const long long slot0 = ((long long)(mslot / p.rem_parts) * p.n_tiles + nt) * (p.rem_parts - 1);
       const int pj = part_index();
       constexpr int FR = NI * MI;
       if (pj != 0) {
         f32x4* dst = (f32x4*)p.part_ws + (slot0 + pj - 1) * (long long)(FR * NTH);
+        // write-through (sc1) stores: the data leaves this XCD's L2 at once, so no release fence is needed -- an agent-scope
+        // release (buffer_wbl2) would write back EVERY dirty line of the L2, i.e. the output tiles all the other workgroups
+        // are streaming (measured: +2.2 ms per training step with the fence form)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) dst[(ni * MI + mi) * NTH + tid] = acc[ni][mi];
+          for (int mi = 0; mi < MI; ++mi) {
+            // scalar base + one 32-bit lane offset (per-fragment 64-bit lane addresses cost 2 registers each)
+            const f32x4* fb = dst + (ni * MI + mi) * NTH;
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(tid * 16), "v"(acc[ni][mi]), "s"(fb) : "memory");
+          }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0)
           __hip_atomic_store(p.part_flags + slot0 + pj - 1, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         continue;                                        // the last tile of this workgroup: on to the statistics flush
       }
       if (tid == 0) {
@@ -1295,6 +1302,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     }
   }
 }
+
+#include "igemm_wide.h"
 
 // ------------------------------------------------------------------------------------
 // wgrad: dW[K, N] (fp32 split-slabs) = sum over pixels A(m, k) * dY(m, n).
@@ -2503,6 +2512,22 @@ static bool igemm_use_256(const ConvP& p, bool fwd) {
   return (classes & cls) != 0;
 }
 
+// Eight-phase 256 x 256 tile (csrc/igemm_wide.h).  SIMCLR_IGEMM_WIDE: 0 = off, 1 = on for the layers the rule below picks,
+// 2 = on wherever the kernel is applicable (tests).  Applicable: bf16, Cout a multiple of 256, whole 64-channel k-tiles, no
+// K-extension / fused BatchNorm-apply epilogue (those stay on conv_igemm_persistent).
+static bool igemm_use_wide(const ConvP& p, bool fwd) {
+  const char* e = getenv("SIMCLR_IGEMM_WIDE");
+  const int mode = e ? atoi(e) : 0;
+  if (mode <= 0) return false;
+  if (p.N % 256 != 0 || p.N / 256 > 32 || p.ntaps <= 0 || p.IC % 64 != 0 || p.x2 || p.fapply) return false;
+  if (p.bn_mode && p.bn_mode != 4 && !p.bn_x) return false;
+  // 32-bit byte offsets into the operands, below the out-of-range marker of the kernel (0xF0000000)
+  if ((long long)p.V * p.IH * p.IW * p.pixpitch * 2 >= 0xE0000000ll || (long long)p.N * p.K * 2 >= 0xE0000000ll) return false;
+  if (mode >= 2) return true;
+  // the MFMA- / L2-bound layers: a reduction of >= 8 k-tiles over >= 256 M-tiles
+  return (long long)p.ntaps * (p.IC / 64) >= 8 && p.M >= 65536;
+}
+
 // Short-K layers (1x1 convolutions from <= SIMCLR_IGEMM_BN64_K channels, default 128: one or two k-tiles per output tile)
 // are pure streaming: with the 64-wide tile three workgroups fit a CU instead of two, so the load phase of one tile, the
 // MFMA / staging of another and the store phase of a third overlap (the gathered operand is then re-read from L2 by N/64
@@ -2537,11 +2562,15 @@ static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size
   const int max_parts = mode > 1 ? mode : 8;
   int P = R > 0 ? mslots / R : 0;
   if (P > max_parts) P = max_parts;
-  const int max_by_steps = unit_steps >= 2 ? units : units / 2;      // at least two k-steps per part
-  if (P > max_by_steps) P = max_by_steps;
+  // at least `min_steps` k-steps per part: a part must be worth its exchange (64 - 256 KB written through + re-read, one
+  // acquire on the owner: 3 - 6 us, i.e. several k-steps)
+  static const int min_steps = getenv("SIMCLR_IGEMM_SPLIT_MINSTEPS") ? atoi(getenv("SIMCLR_IGEMM_SPLIT_MINSTEPS")) : 8;
+  int max_parts_u = (units * unit_steps) / (min_steps > 0 ? min_steps : 1);      // parts are whole units
+  if (max_parts_u > units) max_parts_u = units;
+  if (P > max_parts_u) P = max_parts_u;
   // nothing to gain: no remainder, too few workgroups per remainder tile, short reductions (streaming layers: the
   // partial exchange would cost more than the idle round), or so many rounds that one more is noise
-  if (R == 0 || full == 0 || P < 2 || units * unit_steps < 8 || full > 24) return true;
+  if (R == 0 || full == 0 || P < 2 || full > 24) return true;
   const size_t slots = (size_t)R * p.n_tiles * (P - 1);
   SplitScratch* sc = nullptr;
   for (int i = 0; i < g_split_scratch_n; ++i)
@@ -2608,6 +2637,35 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     // layer class, profiles/r03_notes.md).  The statistics slots of the 128-wide geometry (simclr_conv2d_stats_slots)
     // are never fewer than this grid's M-slots.
     if constexpr (sizeof(T) == 2) {
+      if (igemm_use_wide(p, MODE == MODE_FWD)) {
+        // eight-phase 256 x 256 tile (csrc/igemm_wide.h): one 8-wave workgroup per CU, 150 KB of LDS
+        p.x_bytes = (unsigned)((long long)p.V * p.IH * p.IW * p.pixpitch * 2);
+        { const int dist[3] = {8, 128, 136}, chw = p.cls_h * p.cls_w;
+          for (int i = 0; i < 3; ++i) {
+            p.rs_dq[i] = dist[i] / chw;
+            const int r = dist[i] - p.rs_dq[i] * chw;
+            p.rs_drow[i] = r / p.cls_w; p.rs_dcol[i] = r - p.rs_drow[i] * p.cls_w;
+          } }
+        p.m_tiles = ceil_div(p.M, 256);
+        p.n_tiles = p.N / 256;
+        const int unit = 8 * p.n_tiles;
+        int pgw = max(unit, (256 / unit) * unit);
+        pgw = min(pgw, ceil_div(p.m_tiles, 8) * unit);
+        // ring 128 KB + BN parameters 4 KB + row offsets 2 KB + per-wave statistics 16 KB + border coordinates 8 KB
+        const size_t ldsw = 131072 + 4 * 256 * sizeof(float) + 256 * sizeof(long long) + 8 * 256 * 2 * sizeof(float) + 4 * 512 * sizeof(int);
+        igemm_split_tail(p, pgw, p.ntaps * (p.IC / 64), 1, (size_t)256 * 256, stream);
+        const bool flatw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.cs == 1 && p.IH == p.OH && p.IW == p.OW;
+#define LWD(STv, BEv)                                                                                                          \
+        do {                                                                                                                   \
+          if (flatw) hipLaunchKernelGGL((conv_igemm_wide<MODE, STv, BEv, true>), dim3(pgw), dim3(512), ldsw, stream, p);       \
+          else hipLaunchKernelGGL((conv_igemm_wide<MODE, STv, BEv, false>), dim3(pgw), dim3(512), ldsw, stream, p);            \
+        } while (0)
+        if (p.bn_mode) LWD(true, true);
+        else if (st) LWD(true, false);
+        else LWD(false, false);
+#undef LWD
+        return;
+      }
       if (igemm_use_256(p, MODE == MODE_FWD)) {
         p.m_tiles = ceil_div(p.M, 256);
         p.n_tiles = p.N / 256;

@@ -120,11 +120,11 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case):
 
 # (V, H, Cin, Cout, k, stride, bn_case, dtype, tile): shapes with one full round of the persistent grid plus a remainder
 SPLIT_TAIL_CASES = [
-    (24, 56, 512, 128, 1, 1, (2, 0), BF, None),      # 1x1, 8 k-steps: 588 M-tiles on 512 workgroups -> 76 left-over tiles in 4 parts
-    (24, 56, 128, 128, 3, 1, (3, 1), BF, None),      # halo-window 3x3: split by 64-channel chunk (2 parts)
-    (96, 56, 128, 128, 3, 2, None, BF, None),        # strided 3x3 gather (forward) / class-decomposed dgrad
-    (24, 56, 256, 256, 1, 1, (2, 0), BF, '256'),     # 256 x 256 tile: 294 M-tiles on 256 workgroups
-    (24, 56, 256, 128, 1, 1, (1, 0), F32, None),     # fp32 storage: 8 k-steps of 32
+    (24, 56, 1024, 128, 1, 1, (2, 0), BF, None),     # 1x1, 16 k-steps: 588 M-tiles on 512 workgroups -> 76 left-over tiles in 2 parts
+    (24, 56, 128, 128, 3, 1, (3, 1), BF, None),      # halo-window 3x3: split by 64-channel chunk (2 parts of 9 k-steps)
+    (96, 56, 128, 128, 3, 2, None, BF, None),        # strided 3x3 gather (forward, 18 k-steps) / class-decomposed dgrad
+    (24, 56, 1024, 256, 1, 1, (2, 0), BF, '256'),    # 256 x 256 tile: 294 M-tiles on 256 workgroups
+    (24, 56, 512, 128, 1, 1, (1, 0), F32, None),     # fp32 storage: 16 k-steps of 32
 ]
 
 
@@ -198,6 +198,44 @@ def test_conv_256_tile_paths(V, H, Cin, Cout, k, s, bn_case):
     finally:
         os.environ.pop('SIMCLR_IGEMM_TILE')
     torch.cuda.empty_cache()
+
+
+WIDE_CASES = [c for c in BENCH_PATH_CASES if c[2] % 256 == 0 or c[3] % 256 == 0] + [
+    (300, 14, 1024, 256, 1, 1, (3, 1)),     # flat, 16 k-tiles, residual accumulate + ReLU bits in the dgrad epilogue
+    (37, 28, 512, 256, 1, 1, (1, 0)),       # ragged last tile (M = 29 008)
+    (5, 9, 256, 256, 3, 1, (2, 0)),         # M = 405: two tiles, 81-pixel images (every row near a border), one k-tile per tap x 4
+    (1024, 14, 1024, 256, 1, 1, (2, 0)),    # 784 tiles on 256 workgroups: three rounds + a split tail
+    (64, 28, 256, 256, 3, 2, None),         # strided 3x3 gather / class-decomposed dgrad
+]
+
+
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s,bn_case', WIDE_CASES)
+def test_conv_wide_eight_phase_tile(V, H, Cin, Cout, k, s, bn_case):
+    """csrc/igemm_wide.h (256 x 256 x 64, eight-phase ping-pong schedule, buffer-descriptor gather) forced on wherever it is
+    applicable: forward with statistics, plain / class-decomposed dgrad, dgrad with the fused BatchNorm-backward reduce --
+    the same full-tensor float64 bar as the 128-wide tiles (tf2/resnet.py:183-208)."""
+    import os
+    from tests import gpu_checks as gc
+    os.environ['SIMCLR_IGEMM_WIDE'] = '2'
+    try:
+        res = gc.check_conv_bench_path(V, H, Cin, Cout, k, s, BF, bn_case=bn_case)
+        if k == 1 and Cin % 256 == 0 and V <= 64:      # sums-only epilogue (mode 4)
+            res += gc.check_dgrad_bn(min(V, 8), H, Cin, Cout, 1, BF, 4, 0)
+    finally:
+        os.environ.pop('SIMCLR_IGEMM_WIDE')
+    _assert(res)
+    torch.cuda.empty_cache()
+
+
+def test_train_step_bf16_with_wide_tiles():
+    """ResNet-50 bf16 step vs the oracle with the eight-phase tile forced on wherever it is applicable."""
+    import os
+    from tests import gpu_checks as gc
+    os.environ['SIMCLR_IGEMM_WIDE'] = '2'
+    try:
+        _assert(gc.check_train_step(depth=50, image_size=64, batch=8, compute_dtype='bf16', num_classes=1000, randomize_bn=False))
+    finally:
+        os.environ.pop('SIMCLR_IGEMM_WIDE')
 
 
 def test_train_step_bf16_with_256_tiles():

@@ -127,6 +127,44 @@ def main():
             del x, dy, y, dx
         print('weighted totals (ms): fwd+stats %.2f / %.2f  fwd %.2f / %.2f  dgrad %.2f / %.2f  dgrad_bn %.2f / %.2f' % (
             tot[0] / 1e3, tot[4] / 1e3, tot[1] / 1e3, tot[5] / 1e3, tot[2] / 1e3, tot[6] / 1e3, tot[3] / 1e3, tot[7] / 1e3), flush=True)
+    if 'wide' in what:
+        # A/B of the forward / dgrad schedules, us per launch: 128-wide persistent tiles without / with the split tail, the
+        # eight-phase 256 x 256 tile (csrc/igemm_wide.h) without / with it.  Columns: fwd+stats, dgrad, dgrad + BN reduce.
+        cfgs = [('narrow', dict(SIMCLR_IGEMM_SPLIT='0')), ('narrow+split', {}), ('wide', dict(SIMCLR_IGEMM_WIDE='2', SIMCLR_IGEMM_SPLIT='0')),
+                ('wide+split', dict(SIMCLR_IGEMM_WIDE='2'))]
+        print('%-26s | %s' % ('layer', ' | '.join('%-22s' % c[0] for c in cfgs)))
+        tot = {c[0]: [0.0, 0.0, 0.0] for c in cfgs}
+        for (H, Cin, Cout, k, s, cnt) in R50:
+            if Cout % 256 and Cin % 256:
+                continue
+            pad = (k - 1) // 2
+            OH = (H + (k - 1) - k) // s + 1
+            x = torch.randn(V, H, H, Cin, device=dev).to(dt)
+            w = (torch.randn(k, k, Cin, Cout, device=dev) * (k * k * Cin) ** -0.5)
+            dy = torch.randn(V, OH, OH, Cout, device=dev).to(dt)
+            w_t = ops.prep_weights(w, 0, dt); w_d = ops.prep_weights(w, 1, dt)
+            y = torch.empty(V, OH, OH, Cout, device=dev, dtype=dt)
+            dx = torch.empty(V, H, H, Cin, device=dev, dtype=dt)
+            stats = ops.conv_stats(V * OH * OH, Cout, dev)
+            bn = dict(x=x, mask=None, scale=torch.rand(Cin, device=dev) - 0.4, shift=torch.randn(Cin, device=dev) * 0.3,
+                      mean=torch.randn(Cin, device=dev) * 0.2, rstd=torch.rand(Cin, device=dev) + 0.5, mode=2)
+            row = {}
+            for name, env in cfgs:
+                for kk, vv in env.items():
+                    os.environ[kk] = vv
+                ts = [timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=stats, out=y), args.iters),
+                      timeit(lambda: ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H, out=dx), args.iters),
+                      timeit(lambda: ops.conv2d_dgrad_bn(dy, w_d, k, k, pad, H, H, bn, out=dx), args.iters) if s == 1 else 0.0]
+                for kk in env:
+                    os.environ.pop(kk)
+                row[name] = ts
+                for i in range(3):
+                    tot[name][i] += cnt * ts[i]
+            name = '%dx%d %d->%d k%d s%d x%d' % (H, H, Cin, Cout, k, s, cnt)
+            print('%-26s | %s' % (name, ' | '.join('%6.0f %6.0f %6.0f  ' % tuple(row[c[0]]) for c in cfgs)), flush=True)
+            res.append(dict(layer='wide ' + name, count=cnt, **row))
+            del x, dy, y, dx
+        print('%-26s | %s' % ('weighted totals (ms)', ' | '.join('%6.2f %6.2f %6.2f  ' % tuple(v / 1e3 for v in tot[c[0]]) for c in cfgs)), flush=True)
     if 'comparator' in what:
         # the vendor libraries on the SAME shapes, as a yardstick only (never on the product path):
         # MIOpen through torch.nn.functional.conv2d (bf16, channels_last = NHWC memory) forward / data gradient / weight
