@@ -114,7 +114,9 @@ int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype);
 
 /* y[V,OH,OW,Cout] = conv(x[V,IH,IW,Cin], w), explicit symmetric padding `pad` (resnet.py:167-180).
  * stats (nullable) float[nslot][2][Cout], zeroed by caller: per-channel partial (sum, sum sq) of y
- * for BatchNorm (resnet.py:50-78).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0.
+ * for BatchNorm (resnet.py:50-78) -- of the fp32 accumulators on the 128-wide tiles, of the bf16-ROUNDED outputs (the tensor
+ * the reference's moments see) on the 256-wide tiles of the bf16 path (which tile runs depends on shape and environment:
+ * the two differ by the output rounding, <= 2^-9 relative per element, ~1e-5 sigma on the mean).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0.
  * y == NULL (bf16, stats required): statistics-only pass -- the convolution is computed, nothing is stored. */
 int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V, int IH,
                       int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
@@ -251,9 +253,10 @@ int simclr_axpy_f32(float a, const float* x, float* y, long long n, simclr_strea
 /* Metric bookkeeping of one step in one launch (tf2/run.py:587-613: update_pretrain_metrics_train, update_finetune_metrics_train,
  * weight_decay, total_loss = the sum of the loss terms).  src: HOST array of n <= 16 device scalar pointers, scale: host array
  * of n factors (NULL = 1): dst[i] += scale[i] * *src[i] (dst NULL: skipped); total (nullable) receives the sum of the scaled
- * terms whose bit is set in total_mask. */
+ * terms whose bit is set in total_mask; copy (nullable, n floats) receives the scaled terms themselves -- the step's
+ * scalars live in a per-step arena that the next step reuses, the copy is what a caller may keep. */
 int simclr_accumulate_scalars(const float* const* src, const float* scale, int n, float* dst, float* total,
-                              int total_mask, simclr_stream_t stream);
+                              int total_mask, float* copy, simclr_stream_t stream);
 int simclr_l2_loss_f32(const float* x, long long n, float* out, simclr_stream_t stream); /* tf.nn.l2_loss, model.py:49-60 */
 
 /* ---- BatchNorm backward FOLDED into the convolution that produced the BN's input (1x1 expand convs, K <= N): what

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false, bool FAPPLY = false, int SPL = 0>
+          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
   static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
   // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
@@ -604,8 +604,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   // part `pj` of remainder tile `ptile` over the k-steps (WIN: 64-channel chunks) [pka, pkb)
   // (the part's geometry is recomputed from the kernel arguments where it is needed -- tile transitions only -- instead of
   // living in registers across the k-loop: these kernels sit at the SGPR / VGPR limits)
-  const int count = p.rem_parts >= 2 ? p.rem_full : ((mslot < p.m_tiles) ? (p.m_tiles - mslot + mslots - 1) / mslots : 0);
-  const bool has_part = p.rem_parts >= 2 && mslot < p.rem_tiles * p.rem_parts;
+  // TAIL instantiations only (the launcher picks them when ConvP::rem_parts >= 2): on the short-K streaming layers every
+  // k-step is a tile transition, and the extra state of the split tail costs them 30-45 % (spills in that path)
+  const int count = (TAIL && p.rem_parts >= 2) ? p.rem_full : ((mslot < p.m_tiles) ? (p.m_tiles - mslot + mslots - 1) / mslots : 0);
+  const bool has_part = TAIL && p.rem_parts >= 2 && mslot < p.rem_tiles * p.rem_parts;
   auto part_tile = [&]() __attribute__((always_inline)) { return p.rem_full * mslots + mslot / p.rem_parts; };
   auto part_index = [&]() __attribute__((always_inline)) { return mslot % p.rem_parts; };
   const int kpt = p.IC / BK;
@@ -933,18 +935,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       const int pj = part_index();
       constexpr int FR = NI * MI;
       if (pj != 0) {
-        f32x4* dst = (f32x4*)p.part_ws + (slot0 + pj - 1) * (long long)(FR * NTH);
         // write-through (sc1) stores: the data leaves this XCD's L2 at once, so no release fence is needed -- an agent-scope
         // release (buffer_wbl2) would write back EVERY dirty line of the L2, i.e. the output tiles all the other workgroups
-        // are streaming (measured: +2.2 ms per training step with the fence form)
+        // are streaming (measured: +2.2 ms per training step with the fence form).  Buffer stores through a descriptor of
+        // this part's slot: one 32-bit lane offset + a scalar fragment offset (per-fragment 64-bit lane addresses cost two
+        // registers each; an inline-asm global_store with a scalar base misses the VALU-writes-SGPR wait states hipcc only
+        // inserts for its own instructions -- memory faults).  aux = 16: sc1.
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((f32x4*)p.part_ws + (slot0 + pj - 1) * (long long)(FR * NTH)), 0, FR * NTH * 16, 0x00020000);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            // scalar base + one 32-bit lane offset (per-fragment 64-bit lane addresses cost 2 registers each)
-            const f32x4* fb = dst + (ni * MI + mi) * NTH;
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(tid * 16), "v"(acc[ni][mi]), "s"(fb) : "memory");
-          }
+          for (int mi = 0; mi < MI; ++mi)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), rp, tid * 16, (ni * MI + mi) * NTH * 16, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
@@ -2674,8 +2677,12 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         pg2 = min(pg2, ceil_div(p.m_tiles, 8) * unit);
         const size_t lds2 = 2 * (256 + 256) * 128 + 5 * 256 * sizeof(float) + 256 * sizeof(long long) + 8 * 256 * 2 * sizeof(float);
         igemm_split_tail(p, pg2, p.ntaps * (p.IC / 64) + (p.x2 ? p.ic2 / 64 : 0), 1, (size_t)256 * 256, stream);
-#define L2(STv, BEv, EXv, FAv) \
-        hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv>), dim3(pg2), dim3(512), lds2, stream, p)
+        if (p.fapply) { p.rem_parts = 0; g_last_split_parts = 0; }
+#define L2(STv, BEv, EXv, FAv)                                                                                                \
+        do {                                                                                                                   \
+          if (p.rem_parts >= 2) { if constexpr (!(FAv)) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv, 0, true>), dim3(pg2), dim3(512), lds2, stream, p); } \
+          else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv>), dim3(pg2), dim3(512), lds2, stream, p); \
+        } while (0)
         if (p.fapply) { if constexpr (MODE == MODE_FWD) L2(false, false, false, true); }
         else if (p.x2 && p.bn_mode) L2(true, true, true, false);
         else if (p.x2) L2(false, false, true, false);
@@ -2693,8 +2700,11 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
              p.ntaps == 9 && p.IH == p.OH && p.IW == p.OW && p.IW <= 62;
     }();
     // reduction units the tail can be split in: k-steps, or 64-channel chunks on the halo-window path
-    igemm_split_tail(p, pg, win3 ? p.IC / bk_elems : p.ntaps * (p.IC / bk_elems) + (p.x2 ? p.ic2 / bk_elems : 0),
-                     win3 ? 9 : 1, (size_t)128 * BN, stream);
+    // (bf16 128 x 128 tiles only: the 64-wide tiles are the short-K streaming layers, the fp32 kernels keep whole tiles)
+    if (sizeof(T) == 2 && BN == 128 && !p.fapply)
+      igemm_split_tail(p, pg, win3 ? p.IC / bk_elems : p.ntaps * (p.IC / bk_elems) + (p.x2 ? p.ic2 / bk_elems : 0),
+                       win3 ? 9 : 1, (size_t)128 * BN, stream);
+    else { p.rem_parts = 0; g_last_split_parts = 0; }
     // fp32 storage: one instantiation per matrix arithmetic (exact fp32 MFMA, 3 or 6 split-bf16 terms)
 #define LPX(BNv, STv, BEv, EXv)                                                                                              \
     do {                                                                                                                     \
@@ -2702,6 +2712,8 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         if (p.split == 3) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3>), dim3(pg), dim3(256), plds, stream, p); \
         else if (p.split == 6) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 6>), dim3(pg), dim3(256), plds, stream, p); \
         else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
+      } else if ((BNv) == 128 && p.rem_parts >= 2) {                                                                         \
+        hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, STv, BEv, EXv, false, false, 0, true>), dim3(pg), dim3(256), plds, stream, p); \
       } else {                                                                                                               \
         hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
       }                                                                                                                      \
@@ -2718,8 +2730,11 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       p.win_j = rows / 32;
       p.win_bytes = rows * 128 > 128 * BN * 2 ? rows * 128 : 128 * BN * 2;
       const size_t wlds = (size_t)p.win_bytes + 2 * BN * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long) + 128;
-#define LW(BNv, STv, BEv) \
-      hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, BNv, 4, 2, STv, BEv, false, true>), dim3(pg), dim3(256), wlds, stream, p)
+#define LW(BNv, STv, BEv)                                                                                                     \
+      do {                                                                                                                     \
+        if ((BNv) == 128 && p.rem_parts >= 2) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, STv, BEv, false, true, false, 0, true>), dim3(pg), dim3(256), wlds, stream, p); \
+        else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, BNv, 4, 2, STv, BEv, false, true>), dim3(pg), dim3(256), wlds, stream, p); \
+      } while (0)
       if (p.bn_mode) { if (BN == 64) LW(64, true, true); else LW(128, true, true); }
       else if (BN == 64) { if (st) LW(64, true, false); else LW(64, false, false); }
       else { if (st) LW(128, true, false); else LW(128, false, false); }
@@ -3101,7 +3116,8 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     // 507 | 14^2 323 379 344 371 515 | 7^2 295 311 312 340 378 -> one full round of 512 (2 per CU), more ranges only
     // for the single-tile 64 -> 64 layer; partial rounds (768, 1536) are the worst choice
     const int tiles3 = (Cin / 64) * (Cout / 64);
-    const int want3 = getenv("SIMCLR_WGRAD3_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD3_BLOCKS")) : (tiles3 == 1 ? 2048 : 512);
+    // (never more than the 4096 simclr_conv2d_wgrad_workspace_bytes sizes the slabs for)
+    const int want3 = min(4096, max(8, getenv("SIMCLR_WGRAD3_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD3_BLOCKS")) : (tiles3 == 1 ? 2048 : 512)));
     q.splits = wgrad_splits(p.M, Cin, Cout, 64, 64, 64, &q.chunks_per_split, 2048, want3);
     q.hpp = (64 + 2 * IW + 2 + 31) / 32 * 32;
     const int tiles = q.ci_tiles * q.co_tiles;

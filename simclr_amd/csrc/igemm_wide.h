@@ -309,17 +309,18 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide(const ConvP p) {
       const long long slot0 = ((long long)(mslot / p.rem_parts) * p.n_tiles + nt) * (p.rem_parts - 1);
       const int pj = part_index();
       if (pj != 0) {
-        f32x4* dst = (f32x4*)p.part_ws + (slot0 + pj - 1) * (long long)(32 * NTH);
+        // write-through (sc1, aux = 16) buffer stores through a descriptor of this part's slot: one 32-bit lane offset + a
+        // scalar fragment offset (32 per-fragment 64-bit lane addresses would not fit beside the accumulators)
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((f32x4*)p.part_ws + (slot0 + pj - 1) * (long long)(32 * NTH)), 0, 32 * NTH * 16, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              // scalar base + one 32-bit lane offset: 32 per-fragment 64-bit lane addresses would not fit beside the accumulators
-              const f32x4* fb = dst + ((q * 4 + mi) * 2 + ni) * NTH;
-              asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(tid * 16), "v"(acc[q][mi][ni]), "s"(fb) : "memory");
-            }
+            for (int ni = 0; ni < 2; ++ni)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[q][mi][ni]), rp, tid * 16,
+                                                     ((q * 4 + mi) * 2 + ni) * NTH * 16, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)

@@ -649,12 +649,13 @@ struct ScalarsP {
   float scale[16];
 };
 __global__ void accumulate_scalars(const ScalarsP p, int n, float* __restrict__ dst, float* __restrict__ total,
-                                   unsigned total_mask) {
+                                   unsigned total_mask, float* __restrict__ copy) {
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int i = 0; i < n; ++i) {
       const float v = p.scale[i] * *p.src[i];
       if (dst) dst[i] += v;
+      if (copy) copy[i] = v;
       if ((total_mask >> i) & 1u) t += v;
     }
     if (total) total[0] = t;
@@ -976,7 +977,7 @@ int simclr_cast(const void* x, void* y, long long n, int dtype_in, int dtype_out
 }
 
 int simclr_accumulate_scalars(const float* const* src, const float* scale, int n, float* dst, float* total,
-                              int total_mask, hipStream_t stream) {
+                              int total_mask, float* copy, hipStream_t stream) {
   SIMCLR_CHECK_ARG(n >= 1 && n <= 16 && src, "accumulate_scalars: n=%d must be in [1, 16]", n);
   ScalarsP p = {};
   for (int i = 0; i < n; ++i) {
@@ -984,7 +985,7 @@ int simclr_accumulate_scalars(const float* const* src, const float* scale, int n
     p.src[i] = src[i];
     p.scale[i] = scale ? scale[i] : 1.f;
   }
-  hipLaunchKernelGGL(accumulate_scalars, dim3(1), dim3(64), 0, stream, p, n, dst, total, (unsigned)total_mask);
+  hipLaunchKernelGGL(accumulate_scalars, dim3(1), dim3(64), 0, stream, p, n, dst, total, (unsigned)total_mask, copy);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -23,6 +23,10 @@ class Mean:
     def attach(self, sums, index):
         """Batched bookkeeping (run.make_single_step): this metric's running sum is element `index` of the device tensor
         `sums`, which ONE simclr_accumulate_scalars launch per step updates for all metrics; `bump()` counts the update."""
+        if self._bank is not None and self._bank[0] is not sums:
+            # re-attached to another step function's bank: carry the sum accumulated so far over instead of dropping it
+            prev = self._bank[0][self._bank[1]].detach().reshape(1).clone()
+            self._sum = prev if self._sum is None else self._sum + prev.to(self._sum.device)
         self._bank = (sums, index)
 
     def bump(self):

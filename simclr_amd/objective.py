@@ -56,15 +56,22 @@ class LazyLogits:
         self._ensure_entropy = ensure_entropy
         n, N = z_local.shape[0] // 2, z_all.shape[0] // 2
         self.shape = (n, N)
+        self._kept = None
 
     @property
     def contrast_acc(self):          # tf2/metrics.py:28-31
-        return self._out[1]
+        return self._kept[0] if self._kept is not None else self._out[1]
 
     @property
     def contrast_entropy(self):      # tf2/metrics.py:33-35 (produced by the backward sweep)
+        if self._kept is not None:
+            return self._kept[1]
         self._ensure_entropy()
         return self._out[2]
+
+    def keep(self, acc, entropy):
+        """Re-point the two metrics at copies that outlive the step arena (run.make_single_step)."""
+        self._kept = (acc, entropy)
 
     def dense(self):
         return ops.ntxent_logits_ab(self._z_local, self._z_all, self._t)

@@ -650,14 +650,15 @@ def step_scalars(n, device):
     return t if t is not None else torch.zeros(n, device=device, dtype=torch.float32)
 
 
-def accumulate_scalars(srcs, dst=None, scales=None, total=None, total_mask=0):
+def accumulate_scalars(srcs, dst=None, scales=None, total=None, total_mask=0, copy=None):
     """dst[i] += scales[i] * srcs[i][0] for up to 16 device scalars in ONE launch; total[0] = sum of the scaled terms
-    selected by total_mask (simclr_accumulate_scalars)."""
+    selected by total_mask; copy[i] = the scaled term (simclr_accumulate_scalars)."""
+    assert 1 <= len(srcs) <= 16, 'accumulate_scalars: 1..16 scalars per launch, got %d' % len(srcs)
     import ctypes
     n = len(srcs)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
     sc = (ctypes.c_float * n)(*[float(x) for x in scales]) if scales is not None else None
-    lib().accumulate_scalars(ptrs, sc, n, _p(dst), _p(total), int(total_mask), _s())
+    lib().accumulate_scalars(ptrs, sc, n, _p(dst), _p(total), int(total_mask), _p(copy), _s())
 
 
 def l2_loss_f32(x, out):

@@ -154,9 +154,25 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
         names = [nm for nm in order if nm in vals]
         # one launch: bank[index(name)] += value(name); the metrics absent this step keep their sums
         srcs = [vals.get(nm, state['zero']) for nm in order]
-        ops.accumulate_scalars(srcs, dst=state['bank'])
+        assert len(order) <= 16, 'the metric bank holds 16 running sums (simclr_accumulate_scalars)'
+        # The loss / metric scalars above are views into the per-step arena, which the NEXT step zeroes and refills: the same
+        # launch writes them into `keep` (a fresh tensor per step) and the handles this function returns are re-pointed at
+        # it, so a caller may hold them across steps (deferred .item() logging, trajectory lists).
+        keep = torch.empty(len(order), device=features.device, dtype=torch.float32)
+        ops.accumulate_scalars(srcs, dst=state['bank'], copy=keep)
         for nm in names:
             m[nm].bump()
+        at = {nm: keep[i:i + 1] for i, nm in enumerate(order) if nm in vals}
+        if con_loss is not None and 'train/contrast_loss' in at:
+            con_loss.value = at['train/contrast_loss']
+            if 'train/contrast_acc' in at and 'train/contrast_entropy' in at:
+                logits_con.keep(at['train/contrast_acc'], at['train/contrast_entropy'])
+        if sup_loss is not None and 'train/supervised_loss' in at:
+            sup_loss.value = at['train/supervised_loss']
+            if 'train/supervised_acc' in at:
+                sup_loss.acc = at['train/supervised_acc']
+        if torch.is_tensor(weight_decay) and 'train/weight_decay' in at:
+            weight_decay = at['train/weight_decay']
         return dict(con_loss=con_loss, sup_loss=sup_loss, weight_decay=weight_decay, total_loss=total,
                     logits_con=logits_con if con_loss is not None else None)
 

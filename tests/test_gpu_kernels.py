@@ -124,7 +124,7 @@ SPLIT_TAIL_CASES = [
     (24, 56, 128, 128, 3, 1, (3, 1), BF, None),      # halo-window 3x3: split by 64-channel chunk (2 parts of 9 k-steps)
     (96, 56, 128, 128, 3, 2, None, BF, None),        # strided 3x3 gather (forward, 18 k-steps) / class-decomposed dgrad
     (24, 56, 1024, 256, 1, 1, (2, 0), BF, '256'),    # 256 x 256 tile: 294 M-tiles on 256 workgroups
-    (24, 56, 512, 128, 1, 1, (1, 0), F32, None),     # fp32 storage: 16 k-steps of 32
+    (24, 56, 1024, 128, 1, 1, (1, 0), BF, None),     # mask-tensor epilogue (mode 1)
 ]
 
 
