@@ -2520,15 +2520,24 @@ static bool igemm_use_256(const ConvP& p, bool fwd) {
 // K-extension / fused BatchNorm-apply epilogue (those stay on conv_igemm_persistent).
 static bool igemm_use_wide(const ConvP& p, bool fwd) {
   const char* e = getenv("SIMCLR_IGEMM_WIDE");
-  const int mode = e ? atoi(e) : 0;
+  const int mode = e ? atoi(e) : 1;
   if (mode <= 0) return false;
   if (p.N % 256 != 0 || p.N / 256 > 32 || p.ntaps <= 0 || p.IC % 64 != 0 || p.x2 || p.fapply) return false;
   if (p.bn_mode && p.bn_mode != 4 && !p.bn_x) return false;
   // 32-bit byte offsets into the operands, below the out-of-range marker of the kernel (0xF0000000)
   if ((long long)p.V * p.IH * p.IW * p.pixpitch * 2 >= 0xE0000000ll || (long long)p.N * p.K * 2 >= 0xE0000000ll) return false;
   if (mode >= 2) return true;
-  // the MFMA- / L2-bound layers: a reduction of >= 8 k-tiles over >= 256 M-tiles
-  return (long long)p.ntaps * (p.IC / 64) >= 8 && p.M >= 65536;
+  // Rule from the per-layer A/B at 1024 views (tools/microbench.py --what wide, profiles/r04_notes.md; us, 128-wide -> wide):
+  //   forward (statistics, plain or statistics-only): wins wherever it applies -- 56^2 64->256 544 -> 443, 14^2 1024->512
+  //   254 -> 223, 14^2 1024->2048 s2 288 -> 239, 7^2 2048->512 132 -> 113 -- except the 3x3 stride-1 layers, where the
+  //   halo-window path of the 128-wide tile moves fewer bytes (14^2 260 vs 267);
+  //   plain dgrad (no fused BatchNorm reduce): 1x1 layers with >= 8 k-tiles (14^2 1024->512 267 -> 243, 1024->2048 s2
+  //   360 -> 313, 7^2 512->2048 115 -> 105); shorter reductions and the strided 3x3 lose;
+  //   dgrad + BatchNorm-backward reduce: loses everywhere but at 7^2 (+4 ... +29 %: one workgroup per CU cannot hide the
+  //   row pass's operand loads) -> stays on conv_igemm_persistent.
+  if (p.M < 32768) return false;
+  if (fwd) return !(p.KH == 3 && p.KW == 3 && p.stride == 1);
+  return !p.bn_mode && !p.accumulate && p.KH == 1 && p.KW == 1 && p.IC >= 512;
 }
 
 // Short-K layers (1x1 convolutions from <= SIMCLR_IGEMM_BN64_K channels, default 128: one or two k-tiles per output tile)
@@ -2554,11 +2563,16 @@ static int g_split_scratch_n = 0;
 
 // units: pieces one tile's reduction can be cut in (k-steps; 64-channel chunks of nine k-steps on the halo-window path)
 static int g_last_split_parts = 0;      // simclr_conv2d_last_split_parts (tests)
-static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size_t tile_floats, hipStream_t stream) {
+// `wide`: the caller is the eight-phase 256 x 256 launch.  Default policy (SIMCLR_IGEMM_SPLIT unset): split the tail of the
+// wide launches only -- measured per ResNet-50 layer at 1024 views (profiles/r04_notes.md) the 128-wide tiles gain 4-6 % on the
+// 3x3 layers at 14^2 / 7^2 and LOSE up to 14 % on the 1x1 layers at 7^2 (a 17-30 us tile is not long enough to pay for the
+// exchange), -0.65 ms per training step in sum; the 256-wide tiles gain 1-4 % (their tiles are four times longer).
+// SIMCLR_IGEMM_SPLIT=0: never, =1: every eligible launch, >= 2: every eligible launch with at most that many parts.
+static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size_t tile_floats, hipStream_t stream, bool wide = false) {
   g_last_split_parts = 0;
   p.rem_parts = 0; p.rem_full = 0; p.rem_tiles = 0; p.part_ws = nullptr; p.part_flags = nullptr; p.seq = 0;
   const char* e = getenv("SIMCLR_IGEMM_SPLIT");
-  const int mode = e ? atoi(e) : 1;
+  const int mode = e ? atoi(e) : (wide ? 1 : 0);
   if (mode == 0 || p.n_tiles <= 0 || grid % p.n_tiles != 0) return true;
   const int mslots = grid / p.n_tiles;
   const int full = p.m_tiles / mslots, R = p.m_tiles - full * mslots;
@@ -2656,7 +2670,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         pgw = min(pgw, ceil_div(p.m_tiles, 8) * unit);
         // ring 128 KB + BN parameters 4 KB + row offsets 2 KB + per-wave statistics 16 KB + border coordinates 8 KB
         const size_t ldsw = 131072 + 4 * 256 * sizeof(float) + 256 * sizeof(long long) + 8 * 256 * 2 * sizeof(float) + 4 * 512 * sizeof(int);
-        igemm_split_tail(p, pgw, p.ntaps * (p.IC / 64), 1, (size_t)256 * 256, stream);
+        igemm_split_tail(p, pgw, p.ntaps * (p.IC / 64), 1, (size_t)256 * 256, stream, true);
         const bool flatw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.cs == 1 && p.IH == p.OH && p.IW == p.OW;
 #define LWD(STv, BEv)                                                                                                          \
         do {                                                                                                                   \

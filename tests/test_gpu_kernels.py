@@ -137,6 +137,8 @@ def test_conv_split_tail_paths(V, H, Cin, Cout, k, s, bn_case, dtype, tile):
     from tests import gpu_checks as gc
     if tile:
         os.environ['SIMCLR_IGEMM_TILE'] = tile
+    os.environ['SIMCLR_IGEMM_SPLIT'] = '1'       # default: the wide launches only
+    os.environ['SIMCLR_IGEMM_WIDE'] = '0'
     try:
         x = torch.randn(V, H, H, Cin, device='cuda').to(dtype)
         w_t = ops.prep_weights(torch.randn(k, k, Cin, Cout, device='cuda') * 0.05, 0, dtype)
@@ -148,6 +150,8 @@ def test_conv_split_tail_paths(V, H, Cin, Cout, k, s, bn_case, dtype, tile):
         res += gc.check_conv_bench_path(V, H, Cin, Cout, k, s, dtype, bn_case=bn_case, seed=1)     # scratch slots reused
     finally:
         os.environ.pop('SIMCLR_IGEMM_TILE', None)
+        os.environ.pop('SIMCLR_IGEMM_SPLIT', None)
+        os.environ.pop('SIMCLR_IGEMM_WIDE', None)
     _assert(res)
 
 
@@ -218,7 +222,7 @@ def test_conv_wide_eight_phase_tile(V, H, Cin, Cout, k, s, bn_case):
     from tests import gpu_checks as gc
     os.environ['SIMCLR_IGEMM_WIDE'] = '2'
     try:
-        res = gc.check_conv_bench_path(V, H, Cin, Cout, k, s, BF, bn_case=bn_case)
+        res = gc.check_conv_bench_path(V, H, Cin, Cout, k, s, BF, bn_case=bn_case, rounded_stats=True)
         if k == 1 and Cin % 256 == 0 and V <= 64:      # sums-only epilogue (mode 4)
             res += gc.check_dgrad_bn(min(V, 8), H, Cin, Cout, 1, BF, 4, 0)
     finally:
