@@ -201,6 +201,53 @@ def build_step(args, dtype, strategy, world, rank, dev, f32_matmul=None):
     return step_fn, data, global_batch, model
 
 
+def sample_pmc_traffic(family):
+    """HBM bytes per step of the dominant kernel family, measured in THIS run: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, never combined with trace domains: the rule of
+    MI355X_MICROARCH.md), two steps each, parsed like tools/pmc_traffic.py (KB counters x 1024, FETCH x 2 for the 16 B/lane
+    loads every streaming kernel of this library uses).  None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    if shutil.which('rocprofv3') is None:
+        return None
+    tot = {}
+    calls = defaultdict(int)
+    try:
+        with tempfile.TemporaryDirectory(dir='/tmp') as td:
+            env = dict(os.environ, TMPDIR='/tmp')
+            for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+                out = os.path.join(td, ctr)
+                cmd = ['rocprofv3', '--pmc', ctr, '--output-format', 'csv', '-d', out, '-o', 'p', '--', sys.executable,
+                       os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no_cpu_baseline', '--no_kernel_events',
+                       '--no_f32', '--no_pmc']
+                subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                acc = defaultdict(float)
+                files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
+                if not files:
+                    return None
+                for fpath in files:
+                    with open(fpath) as f:
+                        for r in csv.DictReader(f):
+                            if r['Counter_Name'] == ctr:
+                                acc[r['Kernel_Name']] += float(r['Counter_Value']) * 1024.0
+                                if ctr == 'FETCH_SIZE':
+                                    calls[r['Kernel_Name']] += 1
+                tot[ctr] = acc
+    except Exception:
+        return None
+    steps = 2.0                                     # 1 warm-up + 1 timed step per child run
+    names = set(tot['FETCH_SIZE']) | set(tot['WRITE_SIZE'])
+    fam = [n for n in names if family in n]
+    side = [n for n in names if 'aug_' in n]         # the augmentation side measurement is not part of the step
+    by = lambda ns: sum(2.0 * tot['FETCH_SIZE'].get(n, 0.0) + tot['WRITE_SIZE'].get(n, 0.0) for n in ns) / steps
+    return dict(family_bytes_per_step=by(fam), kernel_dispatches_per_step=sum(calls[n] for n in fam) / steps,
+                step_total_bytes=by([n for n in names if n not in side]))
+
+
 def collective_bench(strategy, n, dev, flat_numel):
     """Collective A as the step issues it ([2n,128] fp32 per rank, tf2/objective.py:92-127) and one full-buffer gradient
     all-reduce (tf2/run.py:614-622): HIP events on the current stream, which waits for the communicator's stream."""
@@ -224,6 +271,13 @@ def collective_bench(strategy, n, dev, flat_numel):
     out = dict(bytes_contributed=contributed, bytes_gathered=contributed * R, us=round(t_ag, 1),
                # per-GPU wire traffic of an all-gather: (R-1) peers' blocks received
                gbps=round((R - 1) * contributed / (t_ag * 1e-6) / 1e9, 2), ranks=R)
+    # collective C as the step issues it: one [2, 2048] fp64 statistic block (tf2/resnet.py:50-60), over the collective
+    # library and -- when SIMCLR_PEER_STATS=1 mapped the mailboxes -- over the one-launch peer-mapped exchange (csrc/comm.hip)
+    st = torch.randn(2, 2048, device=dev, dtype=torch.float64)
+    out['stat_exchange_us'] = dict(library=round(timeit(lambda: dist.all_reduce(st, group=strategy.stat_group)), 1))
+    if getattr(strategy, 'peer_stats', None) is not None:
+        out['stat_exchange_us']['peer_mapped'] = round(timeit(lambda: strategy.peer_stats.all_reduce_sum(st)), 1)
+        out['stat_exchange_us']['peers_missing'] = int(strategy.peer_stats.status.item())
     g = torch.randn(flat_numel, device=dev)
     t_ar = timeit(lambda: dist.all_reduce(g, group=strategy.grad_group), iters=10, warm=2)
     out['grad_allreduce'] = dict(bytes=flat_numel * 4, us=round(t_ar, 1),
@@ -248,6 +302,7 @@ def main():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_kernel_events', action='store_true', help='skip the instrumented steps (rocprof runs)')
     ap.add_argument('--no_f32', action='store_true', help='skip the fp32 parity-mode measurement')
+    ap.add_argument('--no_pmc', action='store_true', help='do not sample HBM traffic (two rocprofv3 --pmc child runs of this script)')
     ap.add_argument('--prof_steps', type=int, default=3)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo: the ranks talk over gloo and share cuda:0 when the box has fewer GPUs than ranks (exercises '
@@ -353,7 +408,19 @@ def main():
         import glob
         cands = sorted(glob.glob(os.path.join(HERE, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))
         tpath = cands[-1] if cands else ''
-        if default_cfg and args.dtype == 'bf16' and tpath:
+        sampled = None
+        if default_cfg and args.dtype == 'bf16' and world == 1 and not args.no_pmc:
+            sampled = sample_pmc_traffic(best)
+        if sampled:
+            per_launch = sampled['family_bytes_per_step'] / max(roofline['launches_per_step'], 1)
+            roofline['traffic'] = round(per_launch)
+            roofline['traffic_measured_in_run'] = True
+            roofline['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this script on this box '
+                                          '(separate passes, FETCH x2 for 16 B/lane loads, MI355X_MICROARCH.md)')
+            roofline['traffic_kernel_dispatches_per_step'] = sampled['kernel_dispatches_per_step']
+            roofline['traffic_over_algorithmic'] = round(per_launch / roofline['algorithmic_bytes_per_launch'], 3)
+            roofline['step_total_traffic_gb'] = round(sampled['step_total_bytes'] / 1e9, 2)
+        elif default_cfg and args.dtype == 'bf16' and tpath:
             try:
                 tj = json.load(open(tpath))
                 # PMC bytes of the family per STEP (committed rocprofv3 passes of this same command) divided by THIS

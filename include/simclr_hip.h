@@ -302,6 +302,23 @@ size_t simclr_augment_workspace_bytes(int b, int views, int H, int W);
 int simclr_augment_views(const void* src, int src_dtype, const float* params, void* workspace, float* out, int b,
                          int views, int Hs, int Ws, int H, int W, simclr_stream_t stream);
 
+/* ---- collective C without a collective library: tf2/resnet.py:50-60 (SyncBatchNormalization moment all-reduce) -------
+ * One-shot exchange over peer-mapped memory (csrc/comm.hip): every rank owns a mailbox all peers map through hipIpc;
+ * an exchange is ONE single-workgroup launch per rank that writes its block into every peer's mailbox, publishes a
+ * sequence flag, waits (bounded) for the R flags of its own mailbox and adds the R blocks in rank order (bit-identical
+ * on every replica).  The 64-byte handles travel between processes by the caller's means (simclr_amd/comm.py:
+ * torch.distributed.all_gather_object).  RCCL remains the fallback (FLAGS / SIMCLR_PEER_STATS) and carries A and B. */
+size_t simclr_comm_mailbox_bytes(int world, int max_doubles);
+/* allocates (library-owned, uncached where available) + zeroes the mailbox; ipc_handle_64: 64 bytes out; 3 = no hipIpc */
+int simclr_comm_create(int world, int max_doubles, void** mailbox, void* ipc_handle_64);
+int simclr_comm_open(const void* ipc_handle_64, void** mapped);
+int simclr_comm_close(void* mapped);
+int simclr_comm_destroy(void* mailbox);
+/* out[i] = sum_r in_r[i] (rank order), count <= max_doubles fp64 values; peers: HOST array of `world` mapped mailboxes
+ * (peers[rank] = own); seq = 1, 2, ... identical on all ranks per exchange; status (nullable device int) = peers missing */
+int simclr_comm_stats_allreduce(const double* in, double* out, int count, void* const* peers, int rank, int world,
+                                int max_doubles, unsigned seq, int* status, simclr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

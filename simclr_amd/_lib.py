@@ -22,7 +22,7 @@ DT_BF16 = 1
 
 _SCALARS = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double,
-    'long long': ctypes.c_longlong, 'size_t': ctypes.c_size_t,
+    'long long': ctypes.c_longlong, 'size_t': ctypes.c_size_t, 'unsigned': ctypes.c_uint,
     'simclr_stream_t': ctypes.c_void_p,
 }
 

@@ -16,6 +16,52 @@ import torch
 import torch.distributed as dist
 
 
+class PeerStats:
+    """Collective C over peer-mapped memory (csrc/comm.hip, simclr_comm_*): every rank's mailbox is mapped into every
+    process through hipIpc, an all-reduce of <= max_doubles fp64 values is ONE single-workgroup launch per rank, summed in
+    rank order (bit-identical on all replicas).  Opt-in: SIMCLR_PEER_STATS=1 (RCCL / gloo stay the default transport until
+    the path has run on a multi-GPU node; two or four processes on one GPU exercise it: tests/test_gpu_distributed.py)."""
+
+    def __init__(self, group, rank, world, device, max_doubles=16384):
+        import ctypes
+        from ._lib import lib
+        L = lib()
+        self.rank, self.world, self.max_doubles = rank, world, max_doubles
+        torch.cuda.set_device(device)
+        mailbox = ctypes.c_void_p()
+        handle = (ctypes.c_ubyte * 64)()
+        L.comm_create(world, max_doubles, ctypes.byref(mailbox), handle)
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(handle), group=group)
+        self._mailbox = mailbox.value
+        self._peers = (ctypes.c_void_p * world)()
+        for r in range(world):
+            if r == rank:
+                self._peers[r] = mailbox.value
+            else:
+                mapped = ctypes.c_void_p()
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(handles[r])
+                L.comm_open(buf, ctypes.byref(mapped))
+                self._peers[r] = mapped.value
+        self._seq = 0
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)     # peers that never arrived (0 = healthy)
+        self.exchanges = 0
+        dist.barrier(group=group)            # every mailbox is mapped everywhere before the first exchange
+
+    def usable(self, tensor):
+        return tensor.is_cuda and tensor.dtype == torch.float64 and tensor.is_contiguous() and 0 < tensor.numel() <= self.max_doubles
+
+    def all_reduce_sum(self, tensor):
+        import ctypes
+        from ._lib import lib
+        self._seq += 1
+        lib().comm_stats_allreduce(tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), ctypes.cast(self._peers, ctypes.c_void_p),
+                                   self.rank, self.world, self.max_doubles, self._seq, self.status.data_ptr(),
+                                   torch.cuda.current_stream(tensor.device).cuda_stream)
+        self.exchanges += 1
+        return tensor
+
+
 class Strategy:
     """Minimal replica context: num_replicas_in_sync, replica id and the collectives.
 
@@ -43,6 +89,11 @@ class Strategy:
             self.grad_group = dist.new_group(ranks)
         self.stat_collectives = 0                          # counters (bench / tests): collectives issued so far
         self.hidden_collectives = 0
+        # collective C over peer-mapped memory instead of the collective library (opt-in, see PeerStats)
+        self.peer_stats = None
+        if os.environ.get('SIMCLR_PEER_STATS') == '1' and self.num_replicas_in_sync > 1 and torch.cuda.is_available():
+            self.peer_stats = PeerStats(self.stat_group, self.replica_id_in_sync_group, self.num_replicas_in_sync,
+                                        torch.device('cuda', torch.cuda.current_device()))
 
     @property
     def rank(self):
@@ -77,8 +128,10 @@ class Strategy:
 
     # -- collective C (SyncBN statistics): its own communicator
     def all_reduce_sum(self, tensor):
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.stat_group)
         self.stat_collectives += 1
+        if self.peer_stats is not None and self.peer_stats.usable(tensor):
+            return self.peer_stats.all_reduce_sum(tensor)
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.stat_group)
         return tensor
 
     def all_reduce_sum_many(self, tensors):

@@ -91,6 +91,11 @@ def _worker(rank, world, port, q, backend='gloo'):
             for k in np64)
         res['stat_collectives'] = strategy.stat_collectives
         res['hidden_collectives'] = strategy.hidden_collectives
+        res['peer_exchanges'] = strategy.peer_stats.exchanges if strategy.peer_stats is not None else 0
+        res['peer_missing'] = int(strategy.peer_stats.status.item()) if strategy.peer_stats is not None else 0
+        # bit-level fingerprint of the updated weights (the peer-mapped exchange must not change a single bit for R = 2)
+        res['checksum'] = [float(sum(float(byname[k].value.double().sum()) for k in np64)),
+                           float(max(float(byname[k].value.double().abs().max()) for k in np64))]
         res['bn_moving_worst_rel'] = max(
             float((v.value.double().cpu() - ns64[v.name]).abs().max()) / (float(ns64[v.name].abs().max()) + 1e-30)
             for v in model.variables if v.name in ns64)
@@ -102,7 +107,17 @@ def _worker(rank, world, port, q, backend='gloo'):
         q.put((rank, 'FAIL', traceback.format_exc()))
 
 
-def _run(world, backend):
+def _run(world, backend, env=None):
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    try:
+        return _run_inner(world, backend)
+    finally:
+        for k in (env or {}):
+            os.environ.pop(k, None)
+
+
+def _run_inner(world, backend):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -123,10 +138,71 @@ def _run(world, backend):
         # projection blocks batch (shortcut BN, bn1) forward and (tail BN, shortcut BN) backward into one exchange each
         assert m['hidden_collectives'] == 2, m
         assert m['stat_collectives'] <= 2 * 24 - 8, m
+    return [m for _, _, m in sorted(res)]
 
 
 def test_two_replica_step_equals_global_batch_oracle():
     _run(2, 'gloo')
+
+
+def _peer_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from simclr_amd import comm
+        ps = comm.PeerStats(None, rank, world, torch.device('cuda', 0), max_doubles=4096)
+        g = torch.Generator().manual_seed(100 + rank)
+        worst = 0.0
+        for it in range(40):
+            n = [1, 2, 128, 130, 1024, 4096, 777, 2 * 2048][it % 8]
+            x = (torch.randn(n, generator=g, dtype=torch.float64) * 10.0 ** (it % 5 - 2)).cuda()
+            mine = x.clone()
+            ps.all_reduce_sum(mine)
+            # reference: every rank's block gathered over gloo, added in rank order
+            blocks = [torch.zeros(n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(blocks, x.cpu())
+            ref = torch.zeros(n, dtype=torch.float64)
+            for b in blocks:
+                ref = ref + b
+            torch.cuda.synchronize()
+            worst = max(worst, float((mine.cpu() - ref).abs().max()))
+        missing = int(ps.status.item())
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok', dict(worst=worst, missing=missing, exchanges=ps.exchanges)))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, 'FAIL', traceback.format_exc()))
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_peer_mapped_stats_exchange(world):
+    """csrc/comm.hip: `world` processes on ONE GPU map each other's mailboxes through hipIpc; 40 exchanges of 1 ... 4096
+    fp64 values each must equal the rank-ordered sum bit for bit, no peer may time out."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in res), res
+    for _, _, m in res:
+        assert m['worst'] == 0.0 and m['missing'] == 0 and m['exchanges'] == 40, m
+
+
+def test_two_replica_step_with_peer_mapped_statistics():
+    """The two-replica training step with collective C on the peer-mapped exchange (SIMCLR_PEER_STATS=1): the same gates
+    against the float64 oracle, every statistic all-reduce taken by the new path, and weights bit-identical to the gloo run."""
+    a = _run(2, 'gloo')
+    b = _run(2, 'gloo', env={'SIMCLR_PEER_STATS': '1'})
+    for ma, mb in zip(a, b):
+        assert ma['peer_exchanges'] == 0 and mb['peer_exchanges'] >= mb['stat_collectives'] - 2 and mb['peer_missing'] == 0, (ma, mb)
+        assert ma['checksum'] == mb['checksum'], (ma['checksum'], mb['checksum'])
 
 
 def test_two_replica_step_over_rccl():

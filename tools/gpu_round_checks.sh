@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 cd "$R"
 if [ "$MODE" = "quick" ]; then
   timeout 200 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "test_conv_fwd or dgrad or batch_norm or pooling" 2>&1 | tail -3
-  timeout 120 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_f32 > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
+  timeout 120 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_f32 --no_pmc > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
   python -c "import json,sys;d=json.load(open('$OUT/bench_quick.json'));print(d['value'],d['ms_per_step']);[print(k,v) for k,v in d['kernels'].items()]"
   exit 0
 fi
@@ -24,7 +24,7 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')
 timeout 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-300 "$OUT/bench.json" | tail -1
 timeout 300 python tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.txt" 2>&1
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --no_cpu_baseline --no_kernel_events --no_f32"
+B="python $R/bench.py --no_cpu_baseline --no_kernel_events --no_f32 --no_pmc"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- $B --steps 3 --warmup 1 > "$OUT/prof.log" 2>&1
 gzip -f "$OUT"/*kernel_trace.csv 2>/dev/null      # per-dispatch durations (tools/per_dispatch.py)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- $B --steps 1 --warmup 1 > "$OUT/pmc_f.log" 2>&1
@@ -38,8 +38,8 @@ timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O
 cd "$R"
 if [ "$MODE" = "full" ]; then
   # BASELINE configs[3] and [4] on one GPU (per-GPU share of the 8-GPU global batch): value, step_mfma_frac, peak HBM
-  timeout 400 python bench.py --resnet_depth 50 --width_multiplier 2 --sk_ratio 0.0625 --steps 8 --warmup 3 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"; cut -c1-260 "$OUT/bench_cfg4.json" | tail -1
+  timeout 400 python bench.py --resnet_depth 50 --width_multiplier 2 --sk_ratio 0.0625 --steps 8 --warmup 3 --no_cpu_baseline --no_f32 --no_pmc --prof_steps 1 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"; cut -c1-260 "$OUT/bench_cfg4.json" | tail -1
   # cfg5 at its real per-GPU share (global 2048 / 8 = 256 images): peaks at 192 GB of the 288 GB (104 GB at 128 images, r03_call5)
-  timeout 700 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 256 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --prof_steps 1 > "$OUT/bench_cfg5_b256.json" 2> "$OUT/bench_cfg5_b256.err"; cut -c1-260 "$OUT/bench_cfg5_b256.json" | tail -1
+  timeout 700 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 256 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --no_pmc --prof_steps 1 > "$OUT/bench_cfg5_b256.json" 2> "$OUT/bench_cfg5_b256.err"; cut -c1-260 "$OUT/bench_cfg5_b256.json" | tail -1
 fi
 ls "$OUT"
