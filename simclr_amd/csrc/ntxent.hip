@@ -80,32 +80,6 @@ __device__ __forceinline__ void arg_merge(float& v, int& i, float v2, int i2) {
 }
 
 // ------------------------------------------------------------------------------
-// Last-arriver hand-off between the workgroups of ONE launch (cdna_hip_programming.md section 5 / Guideline 16): a workgroup
-// that has written its partial results calls arrive_is_last(); exactly one caller per counter -- the one that draws ticket
-// `expected - 1` -- gets true and may then read what all the others wrote.  Publisher: every wave drains its stores, barrier,
-// ONE lane: agent-scope release fence, drained, relaxed agent-scope ticket; the last arriver: ONE agent-scope acquire fence,
-// barrier, plain loads.  The last arriver also puts the counter back to zero (the ticket buffer is zero when the library
-// creates it and every launch leaves it zero).  Placement-independent: correct wherever the workgroups run.
-// ------------------------------------------------------------------------------
-__device__ __forceinline__ bool arrive_is_last(unsigned* counter, unsigned expected, int* sh_flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = t == expected - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    *sh_flag = last;
-  }
-  __syncthreads();
-  return *sh_flag != 0;
-}
-
-// ------------------------------------------------------------------------------
 // Forward sweep: per (query row, key split) partial statistics.
 // part[split][row][8] = {m0, l0, m1, l1, pos, argval, argidx(bits), 0}
 //   set0 = key cols [0,N), set1 = key cols [N,2N); values are logits*log2(e).
@@ -113,10 +87,8 @@ __device__ __forceinline__ bool arrive_is_last(unsigned* counter, unsigned expec
 template <int D>
 __global__ __launch_bounds__(256) void ntxent_fwd_partial(
     const float* __restrict__ zq, const float* __restrict__ zk, int n, int N, int rank,
-    float scale2 /* log2(e)/T */, int tiles_per_split, float* __restrict__ part, int rows_pad,
-    float* __restrict__ row_stats, float* __restrict__ rowterm, float* __restrict__ out, unsigned* __restrict__ tickets) {
+    float scale2 /* log2(e)/T */, int tiles_per_split, float* __restrict__ part, int rows_pad) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int sh_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, fl = lane & 15;
   const int q = blockIdx.x * kTile + wave * 16 + fl;
@@ -193,64 +165,75 @@ __global__ __launch_bounds__(256) void ntxent_fwd_partial(
     p[0] = m0; p[1] = l0; p[2] = m1; p[3] = l1; p[4] = pos; p[5] = av;
     p[6] = __int_as_float(ai); p[7] = 0.f;
   }
-  // ---- finalize in the same launch.  Level 1: the last of this row tile's key splits merges the splits of its 64 rows
-  // (16 lanes per row, fixed xor-shuffle tree: the arithmetic of the former ntxent_finalize_rows launch); level 2: the
-  // last row tile adds the 2n row terms in a fixed order (the former ntxent_reduce_out launch).
-  if (!arrive_is_last(tickets + blockIdx.x, gridDim.y, &sh_last)) return;
-  const int nsplit = gridDim.y;
-  for (int pass = 0; pass < kTile / 16; ++pass) {
-    const int fq = blockIdx.x * kTile + pass * 16 + (tid >> 4);
-    const int j = tid & 15;
-    float fm0 = -INFINITY, fl0 = 0.f, fm1 = -INFINITY, fl1 = 0.f, fpos = -INFINITY, fav = -INFINITY;
-    int fai = 0x7fffffff;
-    if (fq < two_n) {
-      for (int sp = j; sp < nsplit; sp += 16) {
-        const float4 a = *(const float4*)(part + ((size_t)sp * rows_pad + fq) * kPartStride);
-        const float4 b = *(const float4*)(part + ((size_t)sp * rows_pad + fq) * kPartStride + 4);
-        ml_merge(fm0, fl0, a.x, a.y);
-        ml_merge(fm1, fl1, a.z, a.w);
-        fpos = fmaxf(fpos, b.x);
-        arg_merge(fav, fai, b.y, __float_as_int(b.z));
-      }
-    }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      float om0 = __shfl_xor(fm0, o, 64), ol0 = __shfl_xor(fl0, o, 64);
-      float om1 = __shfl_xor(fm1, o, 64), ol1 = __shfl_xor(fl1, o, 64);
-      float op = __shfl_xor(fpos, o, 64), oav = __shfl_xor(fav, o, 64);
-      int oai = __shfl_xor(fai, o, 64);
-      ml_merge(fm0, fl0, om0, ol0);
-      ml_merge(fm1, fl1, om1, ol1);
-      fpos = fmaxf(fpos, op);
-      arg_merge(fav, fai, oav, oai);
-    }
-    if (j == 0 && fq < two_n) {
-      const float lse_ab2 = fm1 + log2f(fl1);
-      float mf = fm0, lf = fl0;
-      ml_merge(mf, lf, fm1, fl1);
-      const float lse2 = mf + log2f(lf);
-      row_stats[2 * fq] = lse2;
-      row_stats[2 * fq + 1] = lse_ab2;
-      int mc, pc;
-      row_cols(fq, n, N, rank, mc, pc);
-      rowterm[2 * fq] = (lse2 - fpos) * kLn2;
-      rowterm[2 * fq + 1] = (fq < n && fai == pc) ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------------------
+// Finalize, part 1: merge the key splits of every query row -- 16 lanes per row (lane j merges splits j, j+16, ...;
+// a fixed xor-shuffle tree joins them), 16 rows per 256-thread workgroup.  Writes row_stats[row] = {lse_full2, lse_ab2}
+// and rowterm[row] = {loss term, arg-max hit}.  Part 2 (ntxent_reduce_out) adds the row terms in a fixed order:
+// out[0] = loss, out[1] = contrast_acc.  (The former single-workgroup finalize serialised 2n * nsplit dependent loads.)
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ntxent_finalize_rows(const float* __restrict__ part, int nsplit,
+                                                            int rows_pad, int n, int N, int rank,
+                                                            float* __restrict__ row_stats,
+                                                            float* __restrict__ rowterm) {
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int j = threadIdx.x & 15;
+  float m0 = -INFINITY, l0 = 0.f, m1 = -INFINITY, l1 = 0.f, pos = -INFINITY, av = -INFINITY;
+  int ai = 0x7fffffff;
+  if (q < 2 * n) {
+    for (int s = j; s < nsplit; s += 16) {
+      const float4 a = *(const float4*)(part + ((size_t)s * rows_pad + q) * kPartStride);
+      const float4 b = *(const float4*)(part + ((size_t)s * rows_pad + q) * kPartStride + 4);
+      ml_merge(m0, l0, a.x, a.y);
+      ml_merge(m1, l1, a.z, a.w);
+      pos = fmaxf(pos, b.x);
+      arg_merge(av, ai, b.y, __float_as_int(b.z));
     }
   }
-  if (!arrive_is_last(tickets + gridDim.x, gridDim.x, &sh_last)) return;
-  double* shd = (double*)lds;                       // the key tile is no longer needed: 2 x 256 doubles
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    float om0 = __shfl_xor(m0, o, 64), ol0 = __shfl_xor(l0, o, 64);
+    float om1 = __shfl_xor(m1, o, 64), ol1 = __shfl_xor(l1, o, 64);
+    float op = __shfl_xor(pos, o, 64), oav = __shfl_xor(av, o, 64);
+    int oai = __shfl_xor(ai, o, 64);
+    ml_merge(m0, l0, om0, ol0);
+    ml_merge(m1, l1, om1, ol1);
+    pos = fmaxf(pos, op);
+    arg_merge(av, ai, oav, oai);
+  }
+  if (j == 0 && q < 2 * n) {
+    const float lse_ab2 = m1 + log2f(l1);
+    float mf = m0, lf = l0;
+    ml_merge(mf, lf, m1, l1);
+    const float lse2 = mf + log2f(lf);
+    row_stats[2 * q] = lse2;
+    row_stats[2 * q + 1] = lse_ab2;
+    int mask_col, pos_col;
+    row_cols(q, n, N, rank, mask_col, pos_col);
+    rowterm[2 * q] = (lse2 - pos) * kLn2;
+    rowterm[2 * q + 1] = (q < n && ai == pos_col) ? 1.f : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ntxent_reduce_out(const float* __restrict__ rowterm, int n, float* __restrict__ out) {
+  __shared__ double sh_loss[256];
+  __shared__ double sh_hit[256];
   double loss = 0.0, hit = 0.0;
-  for (int r = tid; r < two_n; r += 256) { loss += (double)rowterm[2 * r]; hit += (double)rowterm[2 * r + 1]; }
-  shd[tid] = loss;
-  shd[256 + tid] = hit;
+  for (int q = threadIdx.x; q < 2 * n; q += 256) { loss += (double)rowterm[2 * q]; hit += (double)rowterm[2 * q + 1]; }
+  sh_loss[threadIdx.x] = loss;
+  sh_hit[threadIdx.x] = hit;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (tid < st) { shd[tid] += shd[tid + st]; shd[256 + tid] += shd[256 + tid + st]; }
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sh_loss[threadIdx.x] += sh_loss[threadIdx.x + s];
+      sh_hit[threadIdx.x] += sh_hit[threadIdx.x + s];
+    }
     __syncthreads();
   }
-  if (tid == 0) {
-    out[0] = (float)(shd[0] / n);
-    out[1] = (float)(shd[256] / n);
+  if (threadIdx.x == 0) {
+    out[0] = (float)(sh_loss[0] / n);
+    out[1] = (float)(sh_hit[0] / n);
   }
 }
 
@@ -368,23 +351,15 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
   }
 }
 
-// Both sweeps AND their reductions in ONE launch: blockIdx.z = 0 query-fixed (gradient wrt the local rows + the entropy
-// term), blockIdx.z = 1 key-fixed (gradient wrt the gathered rows); they are independent, so they share the chip.  The last
-// of a row tile's splits to arrive (arrive_is_last) adds the splits of its 64 rows in split order and scales them --
-// dz_local = scale * sum_split gq, dz_all = scale * sum_split gk: the arithmetic of the former ntxent_combine_all launch --
-// and, on the query side, the entropy terms of its rows; the last query tile adds the per-tile entropy sums in tile order:
-// out[2] = contrast entropy (tf2/metrics.py:33-35).
+// Both sweeps in ONE launch: blockIdx.z = 0 query-fixed (gradient wrt the local rows + the entropy term),
+// blockIdx.z = 1 key-fixed (gradient wrt the gathered rows).  They are independent, so they share the chip.
 template <int D>
 __global__ __launch_bounds__(256) void ntxent_bwd_sweeps(
     const float* __restrict__ z_local, const float* __restrict__ z_all, int n, int N, int rank, float scale2,
     const float* __restrict__ row_stats, int tiles_k, int tiles_q, float* __restrict__ gq, int rows_pad_q,
-    float* __restrict__ gk, int rows_pad_k, float* __restrict__ epart, int gxq, int gyq, int gxk, int gyk,
-    float scale, float* __restrict__ dz_local, float* __restrict__ dz_all, double* __restrict__ etile,
-    float* __restrict__ out, unsigned* __restrict__ tickets) {
+    float* __restrict__ gk, int rows_pad_k, float* __restrict__ epart, int gxq, int gyq, int gxk, int gyk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int sh_last;
-  const bool isq = blockIdx.z == 0;
-  if (isq) {
+  if (blockIdx.z == 0) {
     if ((int)blockIdx.x >= gxq || (int)blockIdx.y >= gyq) return;
     ntxent_bwd_sweep_body<D, true>(lds, z_local, 2 * n, z_all, 2 * N, n, N, rank, scale2, row_stats, tiles_k, gq,
                                    rows_pad_q, epart);
@@ -393,44 +368,44 @@ __global__ __launch_bounds__(256) void ntxent_bwd_sweeps(
     ntxent_bwd_sweep_body<D, false>(lds, z_all, 2 * N, z_local, 2 * n, n, N, rank, scale2, row_stats, tiles_q, gk,
                                     rows_pad_k, (float*)nullptr);
   }
-  const int nsplit = isq ? gyq : gyk;
-  if (!arrive_is_last(tickets + (isq ? 0 : gxq) + blockIdx.x, nsplit, &sh_last)) return;
-  const int tid = threadIdx.x;
-  const float* gp = isq ? gq : gk;
-  const int rows_pad = isq ? rows_pad_q : rows_pad_k, rows = isq ? 2 * n : 2 * N;
-  float* dst = isq ? dz_local : dz_all;
-  const int r0 = blockIdx.x * kTile;
-  for (int idx = tid; idx < kTile * (D / 4); idx += 256) {
-    const int r = r0 + idx / (D / 4), c = idx % (D / 4);
-    if (r >= rows) continue;
+}
+
+// One launch for the three tail reductions of the backward: dz_local = scale * sum_split gq, dz_all = scale * sum_split gk
+// (fixed split order), and -- last workgroup -- out[2] = contrast entropy = (1/n) sum over a-rows and splits of epart.
+__global__ __launch_bounds__(256) void ntxent_combine_all(const float* __restrict__ gq, int ksplit, int rows_pad_q, int rows_q,
+                                                          const float* __restrict__ gk, int qsplit, int rows_pad_k, int rows_k,
+                                                          int D, float scale, float* __restrict__ dz_local,
+                                                          float* __restrict__ dz_all, const float* __restrict__ epart,
+                                                          int n, float* __restrict__ out, int blocks_q, int blocks_k) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x;
+  if (b < blocks_q + blocks_k) {
+    const bool isq = b < blocks_q;
+    const float* gp = isq ? gq : gk;
+    const int nsplit = isq ? ksplit : qsplit, rows_pad = isq ? rows_pad_q : rows_pad_k, rows = isq ? rows_q : rows_k;
+    float* dst = isq ? dz_local : dz_all;
+    const int i = (isq ? b : b - blocks_q) * 256 + threadIdx.x;
+    if (i >= rows * (D / 4)) return;
+    const int r = i / (D / 4), c = i % (D / 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sp = 0; sp < nsplit; ++sp) {
-      const float4 v = *(const float4*)(gp + ((size_t)sp * rows_pad + r) * D + c * 4);
+    for (int s = 0; s < nsplit; ++s) {
+      const float4 v = *(const float4*)(gp + ((size_t)s * rows_pad + r) * D + c * 4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
     *(float4*)(dst + (size_t)r * D + c * 4) = acc;
+    return;
   }
-  if (!isq) return;
-  // entropy of this tile's a-rows (q < n), splits in order per row, rows by a fixed tree
-  double* shd = (double*)lds;
   double e = 0.0;
-  if (tid < kTile && r0 + tid < n)
-    for (int sp = 0; sp < nsplit; ++sp) e += (double)epart[(size_t)sp * rows_pad_q + r0 + tid];
-  __syncthreads();                                    // every wave is done with the key tile in lds
-  shd[tid] = e;
+  for (int q = threadIdx.x; q < n; q += 256)
+    for (int s = 0; s < ksplit; ++s) e += (double)epart[(size_t)s * rows_pad_q + q];
+  sh[threadIdx.x] = e;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (tid < st) shd[tid] += shd[tid + st];
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
     __syncthreads();
   }
-  if (tid == 0) etile[blockIdx.x] = shd[0];
-  if (!arrive_is_last(tickets + gxq + gxk, gxq, &sh_last)) return;
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int t = 0; t < gxq; ++t) tot += etile[t];
-    out[2] = (float)(tot / n);
-  }
+  if (threadIdx.x == 0) out[2] = (float)(sh[0] / n);
 }
 
 // ---- l2 normalise (tf.math.l2_normalize, tf2/objective.py:53-54) -------------
@@ -497,28 +472,7 @@ size_t ws_floats(int n, int N, int D) {
   size_t gk = (size_t)p.qsplit * p.rows_pad_k * D;
   size_t ep = (size_t)p.ksplit * p.rows_pad_q;
   size_t rowterm = (size_t)2 * p.rows_pad_q;
-  size_t etile = (size_t)2 * (p.rows_pad_q / kTile) + 2;        // one double per query tile (8-byte aligned below)
-  return part + gq + gk + ep + rowterm + etile;
-}
-
-// Ticket counters of the in-launch reductions: library-owned, one zeroed buffer per stream (launches of a stream are
-// ordered; every launch leaves its counters at zero), created on first use.
-constexpr int kTickets = 16384;
-struct TicketBuf { hipStream_t stream; unsigned* buf; };
-TicketBuf g_tickets[8];
-int g_tickets_n = 0;
-unsigned* tickets_for(hipStream_t stream) {
-  for (int i = 0; i < g_tickets_n; ++i)
-    if (g_tickets[i].stream == stream) return g_tickets[i].buf;
-  if (g_tickets_n == 8) return nullptr;
-  unsigned* b = nullptr;
-  if (hipMalloc((void**)&b, kTickets * sizeof(unsigned)) != hipSuccess || hipMemset(b, 0, kTickets * sizeof(unsigned)) != hipSuccess ||
-      hipDeviceSynchronize() != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  g_tickets[g_tickets_n++] = TicketBuf{stream, b};
-  return b;
+  return part + gq + gk + ep + rowterm;
 }
 
 }  // namespace
@@ -554,18 +508,17 @@ int simclr_ntxent_fwd(const float* z_local, const float* z_all, int n, int N, in
   const float scale2 = kLog2e / temperature;
   dim3 grid(p.rows_pad_q / kTile, p.ksplit);
   const size_t lds = (size_t)kTile * D * sizeof(float);
-  float* rowterm = part + (size_t)p.ksplit * p.rows_pad_q * kPartStride + (size_t)p.ksplit * p.rows_pad_q * D +
-                   (size_t)p.qsplit * p.rows_pad_k * D + (size_t)p.ksplit * p.rows_pad_q;
-  unsigned* tickets = tickets_for(stream);
-  SIMCLR_CHECK_ARG(tickets != nullptr, "ntxent_fwd: cannot create the ticket buffer of this stream");
-  SIMCLR_CHECK_ARG((int)grid.x + 1 <= kTickets, "ntxent_fwd: 2n = %d needs more than %d ticket counters", 2 * n, kTickets);
-  // ONE launch: the sweep, the per-row merge of the key splits (last split of a row tile) and the loss / accuracy sums
-  // (last row tile)
 #define LAUNCH_FWD(DD)                                                                          \
   hipLaunchKernelGGL((ntxent_fwd_partial<DD>), grid, dim3(256), lds, stream, z_local, z_all, n, \
-                     N, rank, scale2, p.tiles_k, part, p.rows_pad_q, row_stats, rowterm, out, tickets)
+                     N, rank, scale2, p.tiles_k, part, p.rows_pad_q)
   if (D == 64) LAUNCH_FWD(64); else if (D == 128) LAUNCH_FWD(128); else LAUNCH_FWD(256);
 #undef LAUNCH_FWD
+  SIMCLR_CHECK_LAUNCH();
+  float* rowterm = part + (size_t)p.ksplit * p.rows_pad_q * kPartStride + (size_t)p.ksplit * p.rows_pad_q * D +
+                   (size_t)p.qsplit * p.rows_pad_k * D + (size_t)p.ksplit * p.rows_pad_q;
+  hipLaunchKernelGGL(ntxent_finalize_rows, dim3(ceil_div(2 * n, 16)), dim3(256), 0, stream, part, p.ksplit, p.rows_pad_q,
+                     n, N, rank, row_stats, rowterm);
+  hipLaunchKernelGGL(ntxent_reduce_out, dim3(1), dim3(256), 0, stream, rowterm, n, out);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -588,20 +541,17 @@ int simclr_ntxent_bwd(const float* z_local, const float* z_all, int n, int N, in
   const size_t lds = (size_t)(kTile * D + 2 * kTile) * sizeof(float);
   dim3 gridq(p.rows_pad_q / kTile, p.ksplit), gridk(p.rows_pad_k / kTile, p.qsplit);
   dim3 gridb(max(gridq.x, gridk.x), max(gridq.y, gridk.y), 2);
-  const float scale = grad_scale / (temperature * (float)n);
-  // per-tile entropy sums (double): behind the row terms of the forward, 8-byte aligned
-  float* rowterm = ep + (size_t)p.ksplit * p.rows_pad_q;
-  double* etile = (double*)(((uintptr_t)(rowterm + (size_t)2 * p.rows_pad_q) + 7) & ~(uintptr_t)7);
-  unsigned* tickets = tickets_for(stream);
-  SIMCLR_CHECK_ARG(tickets != nullptr, "ntxent_bwd: cannot create the ticket buffer of this stream");
-  SIMCLR_CHECK_ARG((int)(gridq.x + gridk.x) + 1 <= kTickets, "ntxent_bwd: 2N = %d needs more than %d ticket counters", 2 * N, kTickets);
-  // ONE launch: both sweeps, the split sums of every row tile (its last split) and the entropy (last query tile)
 #define LAUNCH_BWD(DD)                                                                                       \
   hipLaunchKernelGGL((ntxent_bwd_sweeps<DD>), gridb, dim3(256), lds, stream, z_local, z_all, n, N, rank, scale2, \
                      row_stats, p.tiles_k, p.tiles_q, gq, p.rows_pad_q, gk, p.rows_pad_k, ep, (int)gridq.x,    \
-                     (int)gridq.y, (int)gridk.x, (int)gridk.y, scale, dz_local, dz_all, etile, out, tickets)
+                     (int)gridq.y, (int)gridk.x, (int)gridk.y)
   if (D == 64) LAUNCH_BWD(64); else if (D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(256);
 #undef LAUNCH_BWD
+  SIMCLR_CHECK_LAUNCH();
+  const float scale = grad_scale / (temperature * (float)n);
+  const int blocks_q = ceil_div(2 * n * (D / 4), 256), blocks_k = ceil_div(2 * N * (D / 4), 256);
+  hipLaunchKernelGGL(ntxent_combine_all, dim3(blocks_q + blocks_k + 1), dim3(256), 0, stream, gq, p.ksplit, p.rows_pad_q,
+                     2 * n, gk, p.qsplit, p.rows_pad_k, 2 * N, D, scale, dz_local, dz_all, ep, n, out, blocks_q, blocks_k);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
