@@ -49,7 +49,8 @@ import torch.distributed as dist
 PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 # parity_mode vs the float64 oracle; filled in from the GPU measurement of the round (profiles/r04_notes.md)
-PARITY_NOTE_SPLIT = 'pending measurement'
+PARITY_NOTE_SPLIT = ('north_star met: loss 9.9e-8 rel, embeddings 1.8e-6 abs, every fp32 gate as the exact mode '
+                     '(profiles/r04_step_modes_f32_matmul.json; three terms alone miss the embedding tolerance: 1.5e-5)')
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 FLOP_PER_IMAGE = 49.15e9    # 2 views x (fwd+dgrad+wgrad), encoder + head
 # (depth, width, SK) -> FLOP per image at 224 px (SURVEY 8(d) / BASELINE.md section 3: cfg2/3, cfg4, cfg5)

@@ -42,4 +42,8 @@ if [ "$MODE" = "full" ]; then
   # cfg5 at its real per-GPU share (global 2048 / 8 = 256 images): peaks at 192 GB of the 288 GB (104 GB at 128 images, r03_call5)
   timeout 700 python bench.py --resnet_depth 152 --width_multiplier 3 --sk_ratio 0.0625 --per_gpu_batch 256 --steps 4 --warmup 2 --no_cpu_baseline --no_f32 --no_pmc --prof_steps 1 > "$OUT/bench_cfg5_b256.json" 2> "$OUT/bench_cfg5_b256.err"; cut -c1-260 "$OUT/bench_cfg5_b256.json" | tail -1
 fi
+if [ "$MODE" = "full" ]; then
+  # collective C on one GPU: two ranks over gloo sharing cuda:0, with and without the peer-mapped statistics exchange
+  SIMCLR_PEER_STATS=1 timeout 400 python bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 --per_gpu_batch 64 --no_cpu_baseline --no_f32 --no_pmc --no_kernel_events > "$OUT/bench_2rank_peer.json" 2> "$OUT/bench_2rank_peer.err"; cut -c1-200 "$OUT/bench_2rank_peer.json" | tail -1
+fi
 ls "$OUT"
