@@ -114,9 +114,10 @@ int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype);
 
 /* y[V,OH,OW,Cout] = conv(x[V,IH,IW,Cin], w), explicit symmetric padding `pad` (resnet.py:167-180).
  * stats (nullable) float[nslot][2][Cout], zeroed by caller: per-channel partial (sum, sum sq) of y
- * for BatchNorm (resnet.py:50-78) -- of the fp32 accumulators on the 128-wide tiles, of the bf16-ROUNDED outputs (the tensor
- * the reference's moments see) on the 256-wide tiles of the bf16 path (which tile runs depends on shape and environment:
- * the two differ by the output rounding, <= 2^-9 relative per element, ~1e-5 sigma on the mean).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0.
+ * for BatchNorm (resnet.py:50-78) -- of the fp32 accumulators (128-wide tiles, eight-phase 256-wide tile); the 256 x 256
+ * instantiation of the persistent kernel (SIMCLR_IGEMM_TILE=256 / K-extended dgrad classes) takes them over the bf16-ROUNDED
+ * outputs, the tensor the reference's moments see: the two differ by the output rounding (<= 2^-9 relative per element,
+ * ~1e-5 sigma on the mean at 10^5 rows).  Cin % 64 == 0 (bf16) / 32 (f32); Cout % 4 == 0.
  * y == NULL (bf16, stats required): statistics-only pass -- the convolution is computed, nothing is stored. */
 int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V, int IH,
                       int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,

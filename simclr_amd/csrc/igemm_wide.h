@@ -379,6 +379,40 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide(const ConvP p) {
     float e_s[8], e_q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { e_s[e] = 0.f; e_q[e] = 0.f; }
+    if (STATS && !BNEPI) {
+      // Forward statistics from the fp32 ACCUMULATORS (the source the 128-wide tiles use: the BatchNorm moments do not
+      // depend on which tile ran): per (column half, 16-channel fragment) sum the eight row fragments in registers, the 16
+      // row lanes by xor-shuffles, and lane fl == 0 of every 4-channel group adds into this wave's LDS slot.
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          float ss[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = acc[qm * 2 + qn][mi][ni][r];
+                ss[r] += v;
+                sq[r] = fmaf(v, v, sq[r]);
+              }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ss[r] += __shfl_xor(ss[r], o, 64); sq[r] += __shfl_xor(sq[r], o, 64); }
+          if (fl_e == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float2* slot = wred + wave * BN + qn * 128 + wc * 32 + ni * 16 + g_e * 4 + r;
+              float2 o2 = *slot;
+              o2.x += ss[r]; o2.y += sq[r];
+              *slot = o2;
+            }
+          }
+        }
+    }
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       __syncthreads();                          // ring reads / the previous pass's staging reads are done (rowoff visible)
@@ -441,10 +475,6 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide(const ConvP p) {
           const u32x4 cv = *(const u32x4*)(Cs + r * 512 + (((e_cc * 2) ^ ((r & 7) << 1)) << 3));
           float v[8];
           chunk_to_f32<uint16_t>(cv, v);
-          if (STATS && !BNEPI) {                // rows >= M hold exact zeros (their operands were zero-filled)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { e_s[e] += v[e]; e_q[e] = fmaf(v[e], v[e], e_q[e]); }
-          }
           if (!erok[i]) continue;
           uint16_t* dst = (uint16_t*)Y + eoff[i];
           if (p.accumulate) {
@@ -490,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide(const ConvP p) {
         }
       }
     }
-    if (STATS) {
+    if (STATS && BNEPI) {
       // lanes l and l + 32 of a wave own the same channel chunk: fold into this wave's LDS slot (plain read-modify-write,
       // the slot belongs to one wave: deterministic)
 #pragma unroll
