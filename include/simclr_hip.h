@@ -88,6 +88,12 @@ int simclr_get_f32_matmul(int which);
  * deterministic (fixed summation order).  Environment SIMCLR_IGEMM_SPLIT=0 disables it.  The hook below returns the
  * number of parts the most recent launch used (0 = whole tiles only); tests use it to prove the path ran. */
 int simclr_conv2d_last_split_parts(void);
+/* Three-term data gradient of the SIMCLR_DT_F32 launches (simclr_set_f32_matmul(*, 3)): the weight operand is rewritten once per
+ * launch into (hi, lo) bf16 planes in a library-owned per-stream buffer (the second exception to "never allocates": the
+ * largest weight matrix, >= 16 MB, hipMalloc'ed on first use), so the k-loop does no splitting work for it; bitwise the
+ * same result as the in-register split.  Environment SIMCLR_F32_PRESPLIT=0 disables it.  The hook returns 1 if the most
+ * recent fp32 data-gradient launch took that path. */
+int simclr_conv2d_last_presplit(void);
 /* master HWIO fp32 -> compute copies.  mode 0: [Cout][KH*KW*Cin] (fwd), 1: [Cin][KH*KW*Cout]
  * (dgrad), 2: stem [Cout][KHP][KWP][4] zero padded.  CinP/CoutP (0 = none): zero-padded channel dims. */
 int simclr_prep_weights(const float* w_hwio, void* dst, int KH, int KW, int Cin, int Cout, int mode,

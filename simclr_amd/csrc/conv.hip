@@ -146,9 +146,13 @@ __device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, f32x4 
 // term-major so that consecutive MFMAs write different accumulators).  The B operand is split once, the A operand one
 // fragment at a time (register pressure: NB x 12 + 12 split registers instead of (NA + NB) x 12).
 // TR: the accumulator array is indexed [j][i] (acc[NB][NA]) instead of [i][j].
-template <int NA, int NB, bool TR, int terms, typename LA, typename LB>
+// PSA (terms == 3 only): the A operand arrives PRE-SPLIT (presplit_rows below): chunk 0 of a fragment row is this lane's
+// eight hi values, chunk 1 its eight lo values -- the same two 16-byte reads, no VALU work for that operand.  Bitwise the
+// same products as the in-register split (same rounding instruction, same MFMA order).
+template <int NA, int NB, bool TR, int terms, bool PSA = false, typename LA, typename LB>
 __device__ __forceinline__ void mma_f32_chunks(f32x4* __restrict__ accp, LA lda, LB ldb) {
   static_assert(terms == 0 || terms == 3 || terms == 6, "0 = exact fp32, 3 / 6 = split-bf16 terms");
+  static_assert(!PSA || terms == 3, "pre-split operand: two planes (hi, lo) = the three-term product only");
 #define acc_(i, j) accp[TR ? (j) * NA + (i) : (i) * NB + (j)]
   if constexpr (terms == 0) {
 #pragma unroll
@@ -173,7 +177,8 @@ __device__ __forceinline__ void mma_f32_chunks(f32x4* __restrict__ accp, LA lda,
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       u32x4 ah, al;
-      split_terms2(lda(i, 0), lda(i, 1), ah, al);
+      if constexpr (PSA) { ah = lda(i, 0); al = lda(i, 1); }
+      else split_terms2(lda(i, 0), lda(i, 1), ah, al);
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(al, bh[j], acc_(i, j));
 #pragma unroll
@@ -532,8 +537,11 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false>
+          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
+  // PSB (fp32 storage, three split-bf16 terms): the weight matrix p.w was rewritten by presplit_rows into (hi, lo) bf16
+  // planes per 128-byte k-block -- same bytes, same LDS-DMA stream, no splitting work for that operand in the k-loop
+  static_assert(!PSB || (SPL == 3 && sizeof(T) == 4), "pre-split weights: fp32 storage, three terms");
   static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
   // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
   // before it is stored -- y = act(bf16(conv) * scale + shift + res) with exactly the arithmetic of bn_apply (csrc/bn.hip),
@@ -891,7 +899,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       if (issued < total) issue_next();
       if constexpr (sizeof(T) == 4) {
         if (!DIAG(1))
-          mma_f32_chunks<NI, MI, false, SPL>(&acc[0][0],
+          mma_f32_chunks<NI, MI, false, SPL, PSB>(&acc[0][0],
               [&](int i, int ks) { const int r = wn * 64 + i * 16 + fl; return Bs[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))]; },
               [&](int i, int ks) { const int r = wm * (MI * 16) + i * 16 + fl; return As[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))]; });
       } else
@@ -2182,6 +2190,22 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ sla
   }
 }
 
+// Pre-split copy of an fp32 matrix [rows][K] (K a multiple of 32) for the three-term split-bf16 product (PSB / PSA
+// instantiations): every 128-byte k-block (32 floats = eight 16-byte chunks c0..c7) becomes eight 16-byte chunks of bf16:
+// chunk g (g < 4) = hi of the eight values lane group g reads in a k-step (c_g, then c_{4+g}); chunk 4 + g = their lo
+// = bf16(x - hi).  Same bytes, same addresses per block, so the LDS-DMA stream and the swizzle of the consumer do not change;
+// its two fragment reads (chunks g and 4 + g) return the operands split_terms2 would have produced -- bit for bit.
+__global__ __launch_bounds__(256) void presplit_rows(const float* __restrict__ src, uint32_t* __restrict__ dst, long long nblocks) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;       // one output chunk per thread
+  if (i >= nblocks * 8) return;
+  const long long blk = i >> 3;
+  const int c = (int)(i & 7), gq = c & 3;
+  const u32x4 c0 = *(const u32x4*)(src + blk * 32 + gq * 4), c1 = *(const u32x4*)(src + blk * 32 + 16 + gq * 4);
+  u32x4 hi, lo;
+  split_terms2(c0, c1, hi, lo);
+  *(u32x4*)(dst + i * 4) = (c < 4) ? hi : lo;
+}
+
 // ------------------------------------------------------------------------------------
 // Stem convolution (Cin=3): tf2/resnet.py:593-599 (7x7 s2) and :551-556 (CIFAR 3x3 s1).
 // The input is pre-packed (simclr_pack_views) as [V][HP][WP][4] with physical zero
@@ -2622,6 +2646,40 @@ static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size
   return true;
 }
 
+// Pre-split weights of the fp32 data gradient under three split-bf16 terms (simclr_set_f32_matmul(*, 3)): the weight
+// operand of a launch is rewritten by presplit_rows into a library-owned per-stream buffer (launches of one stream are
+// ordered, so the buffer is free again when the next launch's copy starts) and the PSB instantiation reads it without any
+// splitting work -- the k-loop of the three-term kernels carried ~4 VALU instructions per MFMA, half of them for the
+// weights.  SIMCLR_F32_PRESPLIT=0 keeps the in-register split (read per launch: A/B runs and the bitwise test).
+struct PresplitScratch { hipStream_t stream; void* buf; size_t bytes; };
+static PresplitScratch g_presplit[8];
+static int g_presplit_n = 0;
+static int g_last_presplit = 0;          // simclr_conv2d_last_presplit (tests): 1 if the most recent dgrad launch ran PSB
+static const void* presplit_weights(const void* w, long long rows, int K, hipStream_t stream) {
+  const char* e = getenv("SIMCLR_F32_PRESPLIT");
+  if ((e && atoi(e) == 0) || K % 32 != 0 || rows <= 0) return nullptr;
+  PresplitScratch* sc = nullptr;
+  for (int i = 0; i < g_presplit_n; ++i)
+    if (g_presplit[i].stream == stream) sc = &g_presplit[i];
+  if (!sc) {
+    if (g_presplit_n == 8) return nullptr;
+    sc = &g_presplit[g_presplit_n++];
+    *sc = PresplitScratch{stream, nullptr, 0};
+  }
+  const size_t need = (size_t)rows * K * sizeof(float);
+  if (sc->bytes < need) {
+    if (sc->buf) (void)hipFree(sc->buf);          // synchronises with the device: earlier readers have finished
+    sc->buf = nullptr; sc->bytes = 0;
+    const size_t want = need < (16u << 20) ? (16u << 20) : need;
+    if (hipMalloc(&sc->buf, want) != hipSuccess) { (void)hipGetLastError(); sc->buf = nullptr; return nullptr; }
+    sc->bytes = want;
+  }
+  const long long nblocks = rows * (K / 32);
+  hipLaunchKernelGGL(presplit_rows, dim3((unsigned)ceil_div(nblocks * 8, 256)), dim3(256), 0, stream,
+                     (const float*)w, (uint32_t*)sc->buf, nblocks);
+  return sc->buf;
+}
+
 template <typename T, int MODE>
 void launch_igemm_one(ConvP p, hipStream_t stream) {
   const bool narrow = igemm_narrow(p, sizeof(T));
@@ -2720,10 +2778,20 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
                        win3 ? 9 : 1, (size_t)128 * BN, stream);
     else { p.rem_parts = 0; g_last_split_parts = 0; }
     // fp32 storage: one instantiation per matrix arithmetic (exact fp32 MFMA, 3 or 6 split-bf16 terms)
+    // three-term data gradient: weights pre-split once per launch (PSB)
+    bool psb = false;
+    if constexpr (sizeof(T) == 4 && MODE == MODE_DGRAD) {
+      g_last_presplit = 0;
+      if (p.split == 3) {
+        const void* ws = presplit_weights(p.w, p.N, p.K, stream);
+        if (ws) { p.w = ws; psb = true; g_last_presplit = 1; }
+      }
+    }
 #define LPX(BNv, STv, BEv, EXv)                                                                                              \
     do {                                                                                                                     \
       if constexpr (sizeof(T) == 4) {                                                                                        \
-        if (p.split == 3) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3>), dim3(pg), dim3(256), plds, stream, p); \
+        if (psb) { if constexpr (MODE == MODE_DGRAD) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3, false, true>), dim3(pg), dim3(256), plds, stream, p); } \
+        else if (p.split == 3) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3>), dim3(pg), dim3(256), plds, stream, p); \
         else if (p.split == 6) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 6>), dim3(pg), dim3(256), plds, stream, p); \
         else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
       } else if ((BNv) == 128 && p.rem_parts >= 2) {                                                                         \
@@ -2844,6 +2912,8 @@ int simclr_get_f32_matmul(int which) { return which == 0 ? g_f32_terms_fwd : g_f
 // Test hook: into how many parts the most recent forward / dgrad launch of this process split each left-over tile
 // (0 = the launch ran whole tiles only).  See "split tail" above.
 int simclr_conv2d_last_split_parts(void) { return g_last_split_parts; }
+// Test hook: 1 if the most recent fp32 data-gradient launch read pre-split weights (three split-bf16 terms, see presplit_weights).
+int simclr_conv2d_last_presplit(void) { return g_last_presplit; }
 
 // Number of partial-statistics slots that makes the statistics of simclr_conv2d_fwd / simclr_conv2d_dgrad_bn
 // deterministic for an output of M rows x C channels (one slot per persistent workgroup of an N-tile).

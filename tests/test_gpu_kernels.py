@@ -118,6 +118,34 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case):
     _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, F32, bn_case=bn_case, bwd_tol_scale=2.0))
 
 
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s', [(64, 28, 256, 128, 1, 1), (64, 28, 128, 128, 3, 1), (64, 28, 128, 256, 3, 2), (32, 14, 64, 96, 1, 1)])
+def test_conv_f32_presplit_weights_bitwise(V, H, Cin, Cout, k, s):
+    """Three-term data gradient with the weight operand pre-split into (hi, lo) bf16 planes once per launch
+    (presplit_rows, PSB instantiations) must be BIT-identical to the in-register split, and the path must have run."""
+    from simclr_amd import ops
+    from simclr_amd._lib import lib
+    pad = (k - 1) // 2
+    OH = (H + (k - 1) - k) // s + 1
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(V, OH, OH, Cout, generator=g).cuda()
+    w_d = ops.prep_weights((torch.randn(k, k, Cin, Cout, generator=g) * (k * k * Cin) ** -0.5).cuda(), 1, F32)
+    ops.set_f32_matmul('bf16x3')
+    try:
+        os.environ['SIMCLR_F32_PRESPLIT'] = '0'
+        ref = ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H)
+        assert lib().conv2d_last_presplit() == 0
+        os.environ.pop('SIMCLR_F32_PRESPLIT')
+        out = ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H)
+        assert lib().conv2d_last_presplit() == 1, 'the pre-split path did not run'
+        out2 = ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H)          # scratch reused by the next launch
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and torch.equal(out2, ref)
+        assert float(ref.abs().max()) > 0
+    finally:
+        os.environ.pop('SIMCLR_F32_PRESPLIT', None)
+        ops.set_f32_matmul('exact')
+
+
 # (V, H, Cin, Cout, k, stride, bn_case, dtype, tile): shapes with one full round of the persistent grid plus a remainder
 SPLIT_TAIL_CASES = [
     (24, 56, 1024, 128, 1, 1, (2, 0), BF, None),     # 1x1, 16 k-steps: 588 M-tiles on 512 workgroups -> 76 left-over tiles in 2 parts
