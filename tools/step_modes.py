@@ -28,8 +28,17 @@ def main():
     for mode in args.modes.split(','):
         t = time.time()
         kw = dict(depth=args.depth, image_size=args.size, batch=args.batch, inputs=args.inputs, pretrain_steps=args.pretrain_steps)
-        if mode == 'bf16':
-            res = gc.check_train_step_fixed(compute_dtype='bf16', **kw)
+        if mode.startswith('bf16') and not mode.startswith('bf16x'):
+            # 'bf16' | 'bf16@preapply' (SIMCLR_CONV3_EPI=preapply: BatchNorm applied to conv3's fp32 accumulators before the
+            # bf16 staging of the fused tail) | 'bf16@unfused' (SIMCLR_CONV3_FUSED=0)
+            env = {'bf16@preapply': ('SIMCLR_CONV3_EPI', 'preapply'), 'bf16@unfused': ('SIMCLR_CONV3_FUSED', '0')}.get(mode)
+            if env:
+                os.environ[env[0]] = env[1]
+            try:
+                res = gc.check_train_step_fixed(compute_dtype='bf16', **kw)
+            finally:
+                if env:
+                    os.environ.pop(env[0], None)
         else:
             res = gc.check_train_step_fixed(compute_dtype='f32', f32_matmul=mode, **kw)
         for r in res:
