@@ -1013,18 +1013,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           }
           const int q = wn * 16 + ni * 4 + g;                    // 8-byte granule (4 channels) in the row
           u32x2 pk;
-          if (FAPPLY && p.fapply == 2) {
-            // SIMCLR_CONV3_EPI=preapply: scale / shift applied to the fp32 ACCUMULATORS, the staged bf16 value is the
-            // BatchNorm output (one rounding after the affine map instead of one before it; not bitwise the unfused path)
-            float t[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = fmaf(acc[ni][mi][r], bnp[q * 4 + r], bnp[BN + q * 4 + r]);
-            pk[0] = pack_bf16x2(t[0], t[1]);
-            pk[1] = pack_bf16x2(t[2], t[3]);
-          } else {
           pk[0] = pack_bf16x2(acc[ni][mi][0], acc[ni][mi][1]);
           pk[1] = pack_bf16x2(acc[ni][mi][2], acc[ni][mi][3]);
-          }
           *(u32x2*)(Cs + ml * (BN * 2) + ((q ^ ((ml & 7) << 1)) << 3)) = pk;
         }
       }
@@ -1094,7 +1084,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           if (p.bn_x) chunk_to_f32<uint16_t>(e_xv[i], qv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float o = p.fapply == 2 ? v[e] : fmaf(v[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
+            float o = fmaf(v[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
             if (p.bn_x) o += p.bn_mean ? fmaf(qv[e], bnp[2 * BN + e_cc * 8 + e], bnp[3 * BN + e_cc * 8 + e]) : qv[e];
             v[e] = p.bn_mode ? fmaxf(o, 0.f) : o;          // bn_mode doubles as the ReLU flag here
           }
@@ -1601,22 +1591,11 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
 // MT (multi-tap k-tile, the stem: KW = 1, IC = 32 packed elements per kernel row, all 7 kernel rows in ONE 256-row k-tile so
 // that the gradient tensor is read once): every 16-byte chunk of a tile row has its OWN tap, so the tap offset is per lane
 // instead of per workgroup.  Needs 16-byte aligned sources (stride 2 on an even-width packed image: every pixel index even).
-// LSP (fp32 storage, three split-bf16 terms): both operands are split ONCE per chunk IN LDS -- after its own LDS-DMA loads have
-// landed, every lane rewrites the 16-byte slots it loaded (four floats -> four bf16 hi | four bf16 lo, same 16 bytes; no extra
-// barrier: a lane only touches its own slots before the chunk's barrier) -- and the MFMA stage reads hi / lo fragments with the
-// transposing ds_read_b64_tr_b16 of the bf16 kernel: 32 LDS reads and no splitting VALU per 48 MFMA instead of 64
-// ds_read_b32 + ~180 VALU (every fragment used to be split by each of the two waves that read it).  Rows with bit 3 of the
-// pixel index set store [lo | hi] instead of [hi | lo] and the 32-byte block key is (px & 3) << 1: the eight pixel rows of a
-// half-wave's transposing read then cover all 64 banks exactly once.
-template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false, bool MT = false, int SPL = 0,
-          bool LSP = false>
+template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false, bool MT = false, int SPL = 0>
 __global__ __launch_bounds__(WK * WNN * 64,
                              WK * WNN == 8 ? 1 : ((SPL == 0 && STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
 void conv_wgrad_dma(const WgradP p) {
-  static_assert(!LSP || (SPL == 3 && sizeof(T) == 4 && !GRAM && !MT), "in-LDS split: fp32 storage, three terms");
   constexpr int EPC = Elem<T>::EPC;
-  // 32-byte block permutation key of a pixel row
-  auto pkey = [](int px) __attribute__((always_inline)) { return LSP ? ((px & 3) << 1) : px_key<T>(px); };
   constexpr int BR = BRM * 4 * EPC;           // pixels per reduction chunk
   constexpr int NW = WK * WNN;
   constexpr int KI = BKW / WK / 16;           // 16-row fragments per wave along k
@@ -1691,7 +1670,7 @@ void conv_wgrad_dma(const WgradP p) {
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int px = (wave * AJ + j) * A_RPI + lane / A_CPR, pc = lane % A_CPR;
-    const int lc = (((pc >> 1) ^ (pkey(px) & (A_BLK - 1))) << 1) | (pc & 1);   // logical chunk held by this slot
+    const int lc = (((pc >> 1) ^ (px_key<T>(px) & (A_BLK - 1))) << 1) | (pc & 1);   // logical chunk held by this slot
     const int m = c_begin * BR + px;
     a_m[j] = m;
     if (flat) {
@@ -1712,7 +1691,7 @@ void conv_wgrad_dma(const WgradP p) {
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int px = (wave * BJ + j) * B_RPI + lane / B_CPR, pc = lane % B_CPR;
-    const int lc = (((pc >> 1) ^ (pkey(px) & (B_BLK - 1))) << 1) | (pc & 1);
+    const int lc = (((pc >> 1) ^ (px_key<T>(px) & (B_BLK - 1))) << 1) | (pc & 1);
     const int m = c_begin * BR + px;
     b_m[j] = m;
     b_cok[j] = n0 + lc * EPC < p.N;
@@ -1776,7 +1755,7 @@ void conv_wgrad_dma(const WgradP p) {
   };
   auto elem_off = [&](int RB, int NBLK, int px, int ch) -> int {
     const int byte = ch * (int)sizeof(T);
-    return px * RB + (((byte >> 5) ^ (pkey(px) & (NBLK - 1))) << 5) + (byte & 31);
+    return px * RB + (((byte >> 5) ^ (px_key<T>(px) & (NBLK - 1))) << 5) + (byte & 31);
   };
   auto compute = [&](int stage) __attribute__((always_inline)) {
     if (DIAG(1)) return;
@@ -1815,40 +1794,6 @@ void conv_wgrad_dma(const WgradP p) {
           for (int ki = 0; ki < KI; ++ki)
             acs[ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
                                                               __builtin_bit_cast(bf16x8, af[ki]), acs[ki], 0, 0, 0);
-        }
-      }
-    } else if constexpr (LSP) {
-      // operands already split in LDS (lsp_convert below): hi / lo fragments by transposing reads, pixels 8g..8g+7 per lane group
-#pragma unroll
-      for (int ks = 0; ks < BR / 32; ++ks) {
-        const int px0 = ks * 32 + g * 8 + (fl >> 2);
-        const int swp = g & 1;                                  // bit 3 of the pixel index: [lo | hi] rows
-        // fragment of the 16 channels from c0 on, plane 0 = hi, 1 = lo; the second read is four pixel rows further (same key, same order)
-        auto frag = [&](const unsigned char* base, int RB, int NBLK, int c0, int plane) __attribute__((always_inline)) {
-          const int q = (c0 >> 2) + (fl & 3);                   // logical 16-byte chunk = four channels
-          const int off = px0 * RB + ((((q >> 1) ^ (pkey(px0) & (NBLK - 1))) << 5) | ((q & 1) << 4)) + ((swp ^ plane) << 3);
-          const s16x4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off));
-          const s16x4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off + 4 * RB));
-          const u32x2 l2 = __builtin_bit_cast(u32x2, r0), h2 = __builtin_bit_cast(u32x2, r1);
-          return (u32x4){l2[0], l2[1], h2[0], h2[1]};
-        };
-        u32x4 xh[KI], xl[KI];
-#pragma unroll
-        for (int i = 0; i < KI; ++i) {
-          xh[i] = frag(As, A_RB, A_BLK, wk * (KI * 16) + i * 16, 0);
-          xl[i] = frag(As, A_RB, A_BLK, wk * (KI * 16) + i * 16, 1);
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const u32x4 dh = frag(Bs, B_RB, B_BLK, wn * (NI * 16) + ni * 16, 0);
-          const u32x4 dl = frag(Bs, B_RB, B_BLK, wn * (NI * 16) + ni * 16, 1);
-          // small terms first, as mma_f32_chunks<..., 3>
-#pragma unroll
-          for (int ki = 0; ki < KI; ++ki) acc[ki][ni] = mma_bf16(dl, xh[ki], acc[ki][ni]);
-#pragma unroll
-          for (int ki = 0; ki < KI; ++ki) acc[ki][ni] = mma_bf16(dh, xl[ki], acc[ki][ni]);
-#pragma unroll
-          for (int ki = 0; ki < KI; ++ki) acc[ki][ni] = mma_bf16(dh, xh[ki], acc[ki][ni]);
         }
       }
     } else if constexpr (SPL != 0) {
@@ -1896,25 +1841,6 @@ void conv_wgrad_dma(const WgradP p) {
     }
   };
 
-  // LSP: this lane's own slots of the chunk that has just landed, four floats -> [hi x 4 | lo x 4] bf16 in place ([lo | hi] on
-  // rows with bit 3 of the pixel index set).  Slots filled from the zero page stay zero.
-  auto lsp_convert = [&](int stage) __attribute__((always_inline)) {
-    auto conv = [&](unsigned char* q, int px) __attribute__((always_inline)) {
-      const u32x4 v = *(const u32x4*)q;
-      const float x0 = __uint_as_float(v[0]), x1 = __uint_as_float(v[1]), x2 = __uint_as_float(v[2]), x3 = __uint_as_float(v[3]);
-      const uint32_t h0 = pack_bf16x2(x0, x1), h1 = pack_bf16x2(x2, x3);
-      const uint32_t l0 = pack_bf16x2(x0 - __uint_as_float(h0 << 16), x1 - __uint_as_float(h0 & 0xffff0000u));
-      const uint32_t l1 = pack_bf16x2(x2 - __uint_as_float(h1 << 16), x3 - __uint_as_float(h1 & 0xffff0000u));
-      const bool sw = (px >> 3) & 1;
-      *(u32x4*)q = sw ? (u32x4){l0, l1, h0, h1} : (u32x4){h0, h1, l0, l1};
-    };
-    unsigned char* a_own = smem + stage * BUF + wave * (AJ * 1024) + lane * 16;
-    unsigned char* b_own = smem + stage * BUF + BR * A_RB + wave * (BJ * 1024) + lane * 16;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) conv(a_own + j * 1024, (wave * AJ + j) * A_RPI + lane / A_CPR);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) conv(b_own + j * 1024, (wave * BJ + j) * B_RPI + lane / B_CPR);
-  };
   // ring: chunk c lives in stage (c - c_begin) % STAGES; STAGES-1 chunks are in flight ahead of the math
   int issued = c_begin;
 #pragma unroll
@@ -1927,7 +1853,6 @@ void conv_wgrad_dma(const WgradP p) {
     if (STAGES >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPC) : "memory");
     else if (STAGES >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (LSP) lsp_convert(cs);
     __syncthreads();
     if (issued < c_end) { issue(is); ++issued; is = (is + 1 == STAGES) ? 0 : is + 1; }
     compute(cs);
@@ -3057,9 +2982,7 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
   p.M = V * OH * OW; p.K = KH * KW * Cin;
-  // SIMCLR_CONV3_EPI=preapply (read per launch): BatchNorm applied to the fp32 accumulators before the bf16 staging
-  { const char* e = getenv("SIMCLR_CONV3_EPI"); p.fapply = (e && e[0] == 'p') ? 2 : 1; }
-  p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
+  p.fapply = 1; p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
   p.bn_mean = rscale; p.bn_rstd = rshift;
   launch_igemm<uint16_t, MODE_FWD>(p, stream);
   SIMCLR_CHECK_LAUNCH();
@@ -3369,12 +3292,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
       else LW(float, 32, 64);
     }
   } else if (dtype != SIMCLR_DT_BF16) {
-    // three terms: both operands split once per chunk in LDS (LSP); SIMCLR_F32_PRESPLIT=0 keeps the in-register split
-    const bool lsp = [] { const char* e = getenv("SIMCLR_F32_PRESPLIT"); return !(e && atoi(e) == 0); }();
 #define LDS_(A, B)                                                                                                          \
     do {                                                                                                                     \
-      if (p.split == 3 && lsp) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3, true>), dim3(grid), dim3(256), lds, stream, p); \
-      else if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
+      if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
       else if (p.split == 6) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 6>), dim3(grid), dim3(256), lds, stream, p); \
       else LD(float, A, B, 2, 2);                                                                                            \
     } while (0)

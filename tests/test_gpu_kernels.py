@@ -141,15 +141,6 @@ def test_conv_f32_presplit_weights_bitwise(V, H, Cin, Cout, k, s):
         torch.cuda.synchronize()
         assert torch.equal(out, ref) and torch.equal(out2, ref)
         assert float(ref.abs().max()) > 0
-        # weight gradient: operands split once per chunk in LDS (LSP) vs in registers -- the same three terms per product,
-        # summed in another order (MFMA k layout: pixels 8g..8g+7 instead of 4j+g), so equal to fp32 rounding, not bitwise
-        x = torch.randn(V, H, H, Cin, generator=g).cuda()
-        dw = ops.conv2d_wgrad(x, dy, k, k, s, pad)
-        os.environ['SIMCLR_F32_PRESPLIT'] = '0'
-        dw_ref = ops.conv2d_wgrad(x, dy, k, k, s, pad)
-        torch.cuda.synchronize()
-        scale = float(dw_ref.abs().max())
-        assert scale > 0 and float((dw - dw_ref).abs().max()) <= 2e-6 * scale * (V * OH * OH) ** 0.5 / 16, (float((dw - dw_ref).abs().max()), scale)
     finally:
         os.environ.pop('SIMCLR_F32_PRESPLIT', None)
         ops.set_f32_matmul('exact')

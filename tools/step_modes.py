@@ -28,17 +28,14 @@ def main():
     for mode in args.modes.split(','):
         t = time.time()
         kw = dict(depth=args.depth, image_size=args.size, batch=args.batch, inputs=args.inputs, pretrain_steps=args.pretrain_steps)
-        if mode.startswith('bf16') and not mode.startswith('bf16x'):
-            # 'bf16' | 'bf16@preapply' (SIMCLR_CONV3_EPI=preapply: BatchNorm applied to conv3's fp32 accumulators before the
-            # bf16 staging of the fused tail) | 'bf16@unfused' (SIMCLR_CONV3_FUSED=0)
-            env = {'bf16@preapply': ('SIMCLR_CONV3_EPI', 'preapply'), 'bf16@unfused': ('SIMCLR_CONV3_FUSED', '0')}.get(mode)
-            if env:
-                os.environ[env[0]] = env[1]
+        if mode in ('bf16', 'bf16@unfused'):
+            # 'bf16@unfused': SIMCLR_CONV3_FUSED=0 (every bottleneck tail as conv3 -> HBM -> bn_apply)
+            if mode == 'bf16@unfused':
+                os.environ['SIMCLR_CONV3_FUSED'] = '0'
             try:
                 res = gc.check_train_step_fixed(compute_dtype='bf16', **kw)
             finally:
-                if env:
-                    os.environ.pop(env[0], None)
+                os.environ.pop('SIMCLR_CONV3_FUSED', None)
         else:
             res = gc.check_train_step_fixed(compute_dtype='f32', f32_matmul=mode, **kw)
         for r in res:
