@@ -128,6 +128,14 @@ int simclr_bn_bwd_reduce_slots(long long rows, int C, int dtype);
 int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V, int IH,
                       int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
                       int dtype, simclr_stream_t stream);
+/* simclr_conv2d_fwd for SIMCLR_DT_F32 with PIVOTED BatchNorm statistics (resnet.py:50-78: the moments of the convolution
+ * output).  pivot float[Cout] (out): the convolution output at one interior pixel (image 0, OH/2, OW/2); the slots receive
+ * sum(y - pivot[n]) and sum((y - pivot[n])^2) over the valid rows, and simclr_bn_reduce_slots_pivoted(count = V*OH*OW) turns
+ * them into the raw fp64 moments simclr_bn_finalize(sums) takes.  Raw fp32 moments lose (mean / sigma)^2 * 2^-24 of the
+ * variance; about a pivot the sums stay at the scale of the spread.  y, stats and pivot are required. */
+int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* stats, int nslot, float* pivot, int V,
+                              int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
+                              int dtype, simclr_stream_t stream);
 /* The same convolution with its consumer's BatchNorm apply in the epilogue (bf16 only; resnet.py:470-487, conv3 -> bn3 ->
  * + shortcut -> relu):  y = act(bf16(conv(x)) * scale + shift + r), r = res or res * rscale + rshift (projection shortcut
  * whose BatchNorm is applied here too, resnet.py:411-421);  relu_bits[i] bit e = (y[8 i + e] > 0).
@@ -171,6 +179,9 @@ int simclr_unpack_stem_dw(const float* src, float* dst, int KH, int KW, int Cin,
 
 /* ---- BatchNorm: tf2/resnet.py:31-78 (BatchNormRelu), residual tail :382/:487 ------------------- */
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, simclr_stream_t stream);
+/* slots of simclr_conv2d_fwd_pivoted -> raw moments: sums[c] = S1 + count p, sums[C + c] = S2 + 2 p S1 + count p^2 (fp64) */
+int simclr_bn_reduce_slots_pivoted(const float* partial, int nslot, int C, const float* pivot, double count, double* sums,
+                                   simclr_stream_t stream);
 /* BatchNorm statistics of c = h W (1x1 convolution, tf2/resnet.py:470-474 conv3 -> bn3) without forming c:
  * sums[0][n] = sum_k colsum(h)[k] W[k][n], sums[1][n] = sum_k GW[k][n] W[k][n] with GW = (h^T h) W [K][N] (fp32, from
  * simclr_conv2d_gram + simclr_small_gemm_nt_f32), w_kn = the weights as multiplied, fp32 [K][N]; colsum(h) as fp64

@@ -67,6 +67,23 @@ __global__ __launch_bounds__(kSlotThreads) void bn_reduce_slots(const float* __r
   if (threadIdx.x < 32 && c < C) { sums[c] = s1; sums[C + c] = s2; }
 }
 
+// Slots that hold PIVOTED moments (simclr_conv2d_fwd_pivoted): S1 = sum(y - p), S2 = sum((y - p)^2) over `count` rows, p = pivot[c]
+//   sum(y) = S1 + count p,   sum(y^2) = S2 + 2 p S1 + count p^2      (fp64: the cancellation of the finalize happens at 2^-53)
+__global__ __launch_bounds__(kSlotThreads) void bn_reduce_slots_pivoted(const float* __restrict__ partial, int nslot, int C,
+                                                               const float* __restrict__ pivot, double count,
+                                                               double* __restrict__ sums) {
+  __shared__ double sh[2 * kSlotThreads];
+  const int c0 = blockIdx.x * kSlotCh;
+  double s1, s2;
+  slot_sums(partial, nslot, C, c0, sh, s1, s2);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x < 32 && c < C) {
+    const double p = (double)pivot[c];
+    sums[c] = s1 + count * p;
+    sums[C + c] = s2 + 2.0 * p * s1 + count * p * p;
+  }
+}
+
 // BatchNorm statistics of c = h W (a 1x1 convolution, M rows) WITHOUT forming c: per output channel n
 //   sum_m c[m][n]   = sum_k colsum(h)[k] W[k][n]
 //   sum_m c[m][n]^2 = w_n^T (h^T h) w_n = sum_k GW[k][n] W[k][n],   GW = (h^T h) W
@@ -492,6 +509,17 @@ int simclr_bn_sums_from_gram(const float* gw, const float* w_kn, const double* c
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, hipStream_t stream) {
   SIMCLR_CHECK_ARG(nslot > 0 && C > 0, "bn_reduce_slots: bad shape");
   hipLaunchKernelGGL(bn_reduce_slots, dim3(ceil_div(C, kSlotCh)), dim3(kSlotThreads), 0, stream, partial, nslot, C, sums);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// the pivoted slots of simclr_conv2d_fwd_pivoted -> raw fp64 moments; count = rows this replica accumulated (V*OH*OW)
+int simclr_bn_reduce_slots_pivoted(const float* partial, int nslot, int C, const float* pivot, double count, double* sums,
+                                   hipStream_t stream) {
+  SIMCLR_CHECK_ARG(nslot > 0 && C > 0 && count > 0, "bn_reduce_slots_pivoted: bad shape");
+  SIMCLR_CHECK_ARG(partial && pivot && sums, "bn_reduce_slots_pivoted: null argument");
+  hipLaunchKernelGGL(bn_reduce_slots_pivoted, dim3(ceil_div(C, kSlotCh)), dim3(kSlotThreads), 0, stream, partial, nslot, C, pivot,
+                     count, sums);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -70,6 +70,11 @@ struct ConvP {
                      // a kernel argument stays in SGPRs; &g_zero16 would be re-fetched from the GOT every k-tile
   int diag;        // diagnostic build only (-DSIMCLR_DIAG): bit mask of pipeline parts to skip
   int split;       // fp32 instantiations: 0 = exact fp32 MFMA, 3 / 6 = split-bf16 terms (simclr_set_f32_matmul)
+  // fp32 forward with statistics (simclr_conv2d_fwd_pivoted): the epilogue accumulates sum(y - pivot[n]) and sum((y - pivot[n])^2)
+  // over the VALID rows instead of the raw moments -- pivot[n] = the convolution output at one interior pixel (conv_pivot_row),
+  // so the sums stay at the scale of the channel's spread even when |mean| >> sigma (raw fp32 moments lose (mean/sigma)^2 * 2^-24
+  // of the variance); simclr_bn_reduce_slots_pivoted turns them back into raw fp64 moments.  nullptr: raw moments.
+  const float* pivot;
   // Split tail (tile-quantisation fix of the persistent grid): every workgroup walks `rem_full` whole M-tiles; the
   // rem_tiles M-tiles left over (fewer than there are workgroups per N-tile) are each shared by rem_parts consecutive
   // workgroups along the REDUCTION (k-steps [j*KT/P, (j+1)*KT/P) for part j).  Parts j > 0 store their fp32 accumulators
@@ -1191,8 +1196,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * 64 + ni * 16 + g * 4;
         if (STATS && !BNEPI) {
+          if (sizeof(T) == 4 && MODE == MODE_FWD && p.pivot) {
+            if (off >= 0 && n < p.N) {          // padding rows / columns hold zeros, which are NOT zero about the pivot
+              const float4 pv = *(const float4*)(p.pivot + n);
+              const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r] - pa[r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
+            }
+          } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
+          }
         }
         if (off >= 0 && n < p.N) {
           T* dst = Y + off + n;
@@ -2190,6 +2204,27 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ sla
   }
 }
 
+// pivot[n] = the convolution output at output pixel (image 0, OH / 2, OW / 2) -- an interior pixel, so that every tap of a
+// padded 3x3 convolution contributes -- for the fp32 forward's pivoted statistics (ConvP::pivot).  One wave per output
+// channel, lanes stride the K = KH * KW * Cin reduction (w_t rows are K-contiguous: coalesced), fixed-order combine.
+__global__ __launch_bounds__(256) void conv_pivot_row(const float* __restrict__ x, const float* __restrict__ w_t, float* __restrict__ pivot,
+                                                      int IH, int IW, int Cin, int pixpitch, int OH, int OW, int Cout, int KH, int KW,
+                                                      int stride, int pad) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= Cout) return;
+  const int oy = OH / 2, ox = OW / 2, K = KH * KW * Cin;
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const int tap = k / Cin, ci = k - tap * Cin;
+    const int iy = oy * stride - pad + tap / KW, ix = ox * stride - pad + tap % KW;
+    if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
+      a = fmaf(x[((long long)iy * IW + ix) * pixpitch + ci], w_t[(long long)n * K + k], a);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) pivot[n] = a;
+}
+
 // Pre-split copy of an fp32 matrix [rows][K] (K a multiple of 32) for the three-term split-bf16 product (PSB / PSA
 // instantiations): every 128-byte k-block (32 floats = eight 16-byte chunks c0..c7) becomes eight 16-byte chunks of bf16:
 // chunk g (g < 4) = hi of the eight values lane group g reads in a k-step (c_g, then c_{4+g}); chunk 4 + g = their lo
@@ -2951,6 +2986,43 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   p.M = V * OH * OW; p.K = KH * KW * Cin;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_FWD>(p, stream);
   else launch_igemm<float, MODE_FWD>(p, stream);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// simclr_conv2d_fwd for SIMCLR_DT_F32 with PIVOTED statistics: pivot [Cout] (out) receives the convolution output at one
+// interior pixel and the slots receive sum(y - pivot), sum((y - pivot)^2) per channel; simclr_bn_reduce_slots_pivoted
+// converts them into the raw fp64 moments the BatchNorm finalize expects.  Why: BatchNorm variance from raw fp32 moments loses
+// (mean / sigma)^2 * 2^-24 (tf2/resnet.py:50-60 computes the moments in one fp32 pass too, but on TPU/GPU reductions in a
+// tree; a channel with |mean| >> sigma is where the two drift apart).  A launch that does not take the persistent fp32
+// kernel writes zeros into pivot and raw moments into the slots (the conversion is then the identity).
+int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* stats, int nslot, float* pivot, int V,
+                              int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
+                              int pad, int dtype, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_F32, "conv2d_fwd_pivoted: fp32 only (dtype %d)", dtype);
+  SIMCLR_CHECK_ARG(Cin % 32 == 0, "conv2d_fwd_pivoted: Cin=%d must be a multiple of 32", Cin);
+  SIMCLR_CHECK_ARG(Cout % 4 == 0, "conv2d_fwd_pivoted: Cout=%d must be a multiple of 4", Cout);
+  SIMCLR_CHECK_ARG(V > 0 && OH > 0 && OW > 0 && stride >= 1, "conv2d_fwd_pivoted: bad geometry");
+  SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd_pivoted: M overflows int32");
+  SIMCLR_CHECK_ARG(x && w_t && y && stats && pivot && nslot > 0, "conv2d_fwd_pivoted: null argument");
+  SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd_pivoted: at most 9 taps (got %dx%d)", KH, KW);
+  ConvP p = {};
+  p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
+  p.x = x; p.w = w_t; p.y = y; p.stats = stats; p.nslot = nslot;
+  p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
+  p.M = V * OH * OW; p.K = KH * KW * Cin;
+  // the persistent fp32 kernel is the one that knows about the pivot (launch_igemm_one: n_tiles <= 64, no A/B switches)
+  const bool persistent = Cout <= 64 * 64 && !getenv("SIMCLR_NO_GLDS") && !getenv("SIMCLR_NO_PERSISTENT");
+  if (persistent) {
+    hipLaunchKernelGGL(conv_pivot_row, dim3(ceil_div(Cout, 4)), dim3(256), 0, stream, (const float*)x, (const float*)w_t, pivot,
+                       IH, IW, Cin, Cin, OH, OW, Cout, KH, KW, stride, pad);
+    p.pivot = pivot;
+  } else {
+    if (hipMemsetAsync(pivot, 0, (size_t)Cout * sizeof(float), stream) != hipSuccess) { simclr_set_error("conv2d_fwd_pivoted: memset failed"); return 2; }
+  }
+  launch_igemm<float, MODE_FWD>(p, stream);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -141,10 +141,11 @@ class LinearLayer(Layer):  # tf2/model.py:119-154
         self._refresh(inputs.dtype)
         x4 = inputs.view(V, 1, 1, cin)
         stats = ops.conv_stats(V, self.npad, RT.device) if (self.use_bn and training) else None
-        y = ops.conv2d_fwd(x4, self.w_t, 1, 1, 1, 0, 1, 1, stats=stats).view(V, self.npad)
+        y, stats, sums = ops.conv2d_fwd_with_stats(x4, self.w_t, 1, 1, 1, 0, 1, 1, stats)
+        y = y.view(V, self.npad)
         self.saved = dict(x=x4)
         if self.use_bn:
-            return self.bn_relu(Act(y, stats), training, relu=relu).t
+            return self.bn_relu(Act(y, stats, sums=sums), training, relu=relu).t
         return y
 
     def backward(self, dy, need_dx=True):

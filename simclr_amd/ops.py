@@ -5,6 +5,7 @@ below only validates shapes and forwards raw device pointers to libsimclr_hip.so
 All tensors must be CUDA (ROCm) tensors, contiguous.
 """
 import ctypes
+import os
 
 import torch
 
@@ -228,6 +229,30 @@ def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None, store=
             lambda: lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0] if stats is not None else 0, V,
                                      IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
     return out
+
+
+def bn_pivot_enabled(dtype):
+    """Pivoted BatchNorm statistics of the fp32 convolutions (simclr_conv2d_fwd_pivoted); SIMCLR_BN_PIVOT=0: raw moments."""
+    return dtype == torch.float32 and os.environ.get('SIMCLR_BN_PIVOT', '1') != '0'
+
+
+def conv2d_fwd_with_stats(x, w_t, KH, KW, stride, pad, OH, OW, stats):
+    """The forward convolution of a conv -> BatchNorm pair (tf2/resnet.py:183-208 followed by :31-78).  Returns (y, stats, sums):
+    bf16 (and fp32 with SIMCLR_BN_PIVOT=0): the partial slots as conv2d_fwd fills them, sums None; fp32: the statistics are
+    accumulated about a per-channel pivot and come back as this replica's raw fp64 moments `sums` [2, C] (stats None)."""
+    if stats is None or not bn_pivot_enabled(x.dtype):
+        return conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=stats), stats, None
+    V, IH, IW, Cin = x.shape
+    Cout = w_t.shape[0]
+    out = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
+    pivot = torch.empty(Cout, device=x.device, dtype=torch.float32)
+    M, K = V * OH * OW, KH * KW * Cin
+    _launch('conv_igemm_fwd', 2.0 * M * K * Cout, 4 * (V * IH * IW * Cin + M * Cout + K * Cout),
+            lambda: lib().conv2d_fwd_pivoted(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0], _p(pivot), V, IH, IW, Cin, OH, OW,
+                                             Cout, KH, KW, stride, pad, dt(x), _s()))
+    sums = torch.empty(2, Cout, device=x.device, dtype=torch.float64)
+    lib().bn_reduce_slots_pivoted(_p(stats), stats.shape[0], Cout, _p(pivot), float(M), _p(sums), _s())
+    return out, None, sums
 
 
 def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=None, relu=True, want_bits=False,

@@ -467,9 +467,10 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         OH = (H + (k - 1) - k) // s + 1
         OW = (W + (k - 1) - k) // s + 1
         stats = ops.conv_stats(V * OH * OW, self.cout_p, RT.device) if (want_stats and training) else None
-        y = ops.conv2d_fwd(x, self.w_t, k, k, s, pad, OH, OW, stats=stats)
+        # fp32: statistics about a per-channel pivot, handed on as this replica's fp64 moments (Act.sums)
+        y, stats, sums = ops.conv2d_fwd_with_stats(x, self.w_t, k, k, s, pad, OH, OW, stats)
         self.saved = dict(x=x, H=H, W=W, pad=pad)
-        return Act(y, stats, c=self.filters)
+        return Act(y, stats, c=self.filters, sums=sums)
 
     def _store_wgrad(self, tmp4):
         """tmp4: [k, k, cin_p, cout_p] fp32 -> logical slice into the gradient buffer."""

@@ -5,6 +5,8 @@ oracle (`oracle/`, float64) for the loss / LARS and plain torch-CPU float64 ops
 for conv / BN / pooling.  Used by tests/test_gpu_kernels.py (pytest -m gpu) and
 tools/run_gpu_checks.py (prints everything; first-contact diagnostics).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -1512,6 +1514,46 @@ def check_conv_fwd_bn_apply(V, H, Cin, Cout, k=1, stride=1, with_res=True, relu=
     sc_ = float(ref.abs().max())
     res_l.append(dict(name='fwd_bn_apply_value ' + tag, err=err, tol=2.0 ** -7 * sc_, scale=sc_, ok=bool(err <= 2.0 ** -7 * sc_), nbad=0, numel=y.numel()))
     return res_l
+
+
+def check_conv_pivoted_stats(V, H, Cin, Cout, k, stride, offset=300.0, seed=0, matmul='exact'):
+    """fp32 convolution whose output has |mean| >> sigma per channel (input = offset + noise): BatchNorm mean / variance from
+    simclr_conv2d_fwd_pivoted + simclr_bn_reduce_slots_pivoted + simclr_bn_finalize against float64 moments OF THE STORED OUTPUT
+    (isolates the statistics from the convolution's own rounding).  Raw fp32 moments (SIMCLR_BN_PIVOT=0) lose about
+    (mean / sigma)^2 * 2^-24 of the variance: reported next to the pivoted error, not gated."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    pad = (k - 1) // 2
+    OH = (H + (k - 1) - k) // stride + 1
+    x = offset + torch.randn(V, H, H, Cin, device=DEV, generator=g)
+    w = torch.randn(k, k, Cin, Cout, device=DEV, generator=g) * (k * k * Cin) ** -0.5
+    w_t = ops.prep_weights(w, 0, torch.float32)
+    M = V * OH * OH
+    gamma, beta = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+    ops.set_f32_matmul(matmul)
+    out = {}
+    try:
+        for mode in ('1', '0'):
+            os.environ['SIMCLR_BN_PIVOT'] = mode
+            stats = ops.conv_stats(M, Cout, DEV)
+            y, st, sums = ops.conv2d_fwd_with_stats(x, w_t, k, k, stride, pad, OH, OH, stats)
+            assert (sums is not None) == (mode == '1')
+            mm, mv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+            mean, rstd, _, _ = ops.bn_finalize(sums, M, gamma, beta, mm, mv, 0.9, partial=st)
+            torch.cuda.synchronize()
+            y64 = y.double().view(M, Cout)
+            m64 = y64.mean(0)
+            v64 = (y64 - m64).pow(2).mean(0)
+            var = rstd.double().pow(-2) - 1e-5
+            out[mode] = (float(((mean.double() - m64).abs() / v64.sqrt()).max()), float(((var - v64).abs() / v64).max()),
+                         float((m64.abs() / v64.sqrt()).median()))
+    finally:
+        os.environ.pop('SIMCLR_BN_PIVOT', None)
+        ops.set_f32_matmul('exact')
+    tag = 'V%d %dx%d %d->%d k%d s%d offset %g %s (median |mean|/sigma %.0f)' % (V, H, H, Cin, Cout, k, stride, offset, matmul, out['1'][2])
+    return [dict(name='pivoted_bn_mean_over_sigma ' + tag, err=out['1'][0], tol=2e-5, scale=1.0, ok=bool(out['1'][0] <= 2e-5), nbad=0,
+                 numel=Cout, raw_moments_err=out['0'][0]),
+            dict(name='pivoted_bn_var_rel ' + tag, err=out['1'][1], tol=2e-5, scale=1.0, ok=bool(out['1'][1] <= 2e-5), nbad=0,
+                 numel=Cout, raw_moments_err=out['0'][1])]
 
 
 def check_gram_stats(V, H, K, N, seed=0):

@@ -118,6 +118,19 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case):
     _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, F32, bn_case=bn_case, bwd_tol_scale=2.0))
 
 
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s,matmul', [(64, 28, 256, 128, 1, 1, 'exact'), (64, 28, 128, 128, 3, 1, 'exact'),
+                                                         (96, 28, 128, 256, 3, 2, 'bf16x6_3'), (37, 14, 64, 1000, 1, 1, 'exact'),
+                                                         (512, 1, 2048, 128, 1, 1, 'exact')])
+def test_conv_f32_pivoted_bn_statistics(V, H, Cin, Cout, k, s, matmul):
+    """BatchNorm moments of an fp32 convolution output with |mean| ~ 100 ... 1000 sigma: accumulated about a per-channel pivot
+    they match float64 to 2e-5 of sigma / of the variance (raw fp32 moments: percent-level variance errors, reported)."""
+    from tests import gpu_checks as gc
+    res = gc.check_conv_pivoted_stats(V, H, Cin, Cout, k, s, matmul=matmul)
+    for r in res:
+        print(r['name'], 'pivoted %.2e raw %.2e' % (r['err'], r['raw_moments_err']))
+    _assert(res)
+
+
 @pytest.mark.parametrize('V,H,Cin,Cout,k,s', [(64, 28, 256, 128, 1, 1), (64, 28, 128, 128, 3, 1), (64, 28, 128, 256, 3, 2), (32, 14, 64, 96, 1, 1)])
 def test_conv_f32_presplit_weights_bitwise(V, H, Cin, Cout, k, s):
     """Three-term data gradient with the weight operand pre-split into (hi, lo) bf16 planes once per launch
