@@ -1180,6 +1180,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       }   // eh
     } else {
     // ---- fp32 parity mode: registers -> NHWC (4 consecutive channels per lane), no LDS, no barrier
+    float4 pvt[NI];                                   // pivoted statistics: this lane's 4 x NI pivots, once per tile
+    if (sizeof(T) == 4 && MODE == MODE_FWD && STATS && !BNEPI && p.pivot) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + g * 4;
+        pvt[ni] = n < p.N ? *(const float4*)(p.pivot + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = m0 + wm * (MI * 16) + mi * 16 + fl;
@@ -1198,8 +1206,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         if (STATS && !BNEPI) {
           if (sizeof(T) == 4 && MODE == MODE_FWD && p.pivot) {
             if (off >= 0 && n < p.N) {          // padding rows / columns hold zeros, which are NOT zero about the pivot
-              const float4 pv = *(const float4*)(p.pivot + n);
-              const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+              const float pa[4] = {pvt[ni].x, pvt[ni].y, pvt[ni].z, pvt[ni].w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) { const float v = acc[ni][mi][r] - pa[r]; st_s[ni][r] += v; st_q[ni][r] += v * v; }
             }

@@ -699,8 +699,11 @@ def test_train_step_resnet152_3x_sk_f32():
     tf2/resnet.py:217-277, 702-747) at a small size: one full step in the fp32 parity mode vs the float64 oracle (variable
     names included: the comparison is by name), and the parameter count of the encoder against the reference's model zoo."""
     from tests import gpu_checks as gc
+    # i.i.d.-noise images: 152 layers map them to one feature and every BatchNorm then normalises a mean hundreds of standard
+    # deviations from zero -- the case raw fp32 moments fail (per-tensor median gradient error 1.6e-2) and the pivoted
+    # statistics of simclr_conv2d_fwd_pivoted pass (2.0e-5; profiles/r04_pivot_report.json)
     res = gc.check_train_step(depth=152, image_size=64, batch=4, compute_dtype='f32', num_classes=10, randomize_bn=False,
-                              sk_ratio=0.0625, width_multiplier=3, inputs='structured')
+                              sk_ratio=0.0625, width_multiplier=3, inputs='iid')
     _assert(res)
     # README.md:33 model-zoo "Param (M)" of R152 3x + SK: 795 (encoder, trainable + BatchNorm moving statistics)
     from simclr_amd import model as model_lib
