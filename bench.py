@@ -467,8 +467,10 @@ def main():
                 f, l = next(d32); s32(f, l)
             torch.cuda.synchronize()
             e32 = time.perf_counter() - t1
+            from simclr_amd import ops as _o
             out = dict(value=round(global_batch * k32 / e32, 2), unit='images/s', ms_per_step=round(e32 / k32 * 1e3, 2),
-                       steps=k32, warmup=w32, dtype='f32', f32_matmul=matmul)
+                       steps=k32, warmup=w32, dtype='f32', f32_matmul=matmul,
+                       bn_statistics='pivoted' if _o.bn_pivot_enabled(torch.float32) else 'raw moments')
             del s32, d32, m32
             gc.collect()
             torch.cuda.empty_cache()
