@@ -542,8 +542,17 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false>
+          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false, int FAS = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
+  // FAS (FAPPLY only): the run-time options of the fused BatchNorm-apply epilogue as compile-time constants for the two shapes every
+  // fused bottleneck tail of a ResNet has -- 1: residual + ReLU + ReLU bit mask, Cout a multiple of 32; 2: the same with the
+  // residual's own BatchNorm (projection blocks).  0: options read from the kernel arguments.  Same arithmetic, same order.
+  static_assert(FAS == 0 || FAPPLY, "FAS specialises the FAPPLY epilogue");
+  const bool fa_res = FAS ? true : p.bn_x != nullptr;
+  const bool fa_rbn = FAS ? FAS == 2 : p.bn_mean != nullptr;
+  const bool fa_relu = FAS ? true : p.bn_mode != 0;
+  const bool fa_mask = FAS ? true : p.bn_mask != nullptr;
+  const bool fa_n32 = FAS ? true : (p.N & 31) == 0;
   // PSB (fp32 storage, three split-bf16 terms): the weight matrix p.w was rewritten by presplit_rows into (hi, lo) bf16
   // planes per 128-byte k-block -- same bytes, same LDS-DMA stream, no splitting work for that operand in the k-loop
   static_assert(!PSB || (SPL == 3 && sizeof(T) == 4), "pre-split weights: fp32 storage, three terms");
@@ -1049,7 +1058,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
 #pragma unroll
         for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
       }
-      if (FAPPLY && p.bn_x) {          // residual operand of the fused BatchNorm apply
+      if (FAPPLY && fa_res) {          // residual operand of the fused BatchNorm apply
 #pragma unroll
         for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
       }
@@ -1086,23 +1095,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           // the arithmetic of bn_apply<RES = 0 | 1> on the bf16-rounded convolution result: bitwise the same output as
           // conv -> HBM -> bn_apply
           float qv[8];
-          if (p.bn_x) chunk_to_f32<uint16_t>(e_xv[i], qv);
+          if (fa_res) chunk_to_f32<uint16_t>(e_xv[i], qv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float o = fmaf(v[e], bnp[e_cc * 8 + e], bnp[BN + e_cc * 8 + e]);
-            if (p.bn_x) o += p.bn_mean ? fmaf(qv[e], bnp[2 * BN + e_cc * 8 + e], bnp[3 * BN + e_cc * 8 + e]) : qv[e];
-            v[e] = p.bn_mode ? fmaxf(o, 0.f) : o;          // bn_mode doubles as the ReLU flag here
+            if (fa_res) o += fa_rbn ? fmaf(qv[e], bnp[2 * BN + e_cc * 8 + e], bnp[3 * BN + e_cc * 8 + e]) : qv[e];
+            v[e] = fa_relu ? fmaxf(o, 0.f) : o;             // bn_mode doubles as the ReLU flag here
           }
           const u32x4 packed = f32_to_chunk<uint16_t>(v);
           const bool ok = erok[i];                          // invalid rows run along (wave-wide shuffles below), store nothing
           if (ok) *(u32x4*)dst = packed;
-          if (p.bn_mask) {                                  // bit e = (stored y[e] > 0), one byte per 16-byte chunk
+          if (fa_mask) {                                    // bit e = (stored y[e] > 0), one byte per 16-byte chunk
             float w8[8];
             chunk_to_f32<uint16_t>(packed, w8);
             unsigned bits = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) bits |= (w8[e] > 0.f ? 1u : 0u) << e;
-            if ((p.N & 31) == 0) {
+            if (fa_n32) {
               // four neighbouring lanes hold four consecutive mask bytes of one row (validity is uniform over such a
               // group when N is a multiple of 32): one aligned 4-byte store instead of four 1-byte stores
               const unsigned b1 = __shfl_down(bits, 1, 64), b2 = __shfl_down(bits, 2, 64), b3 = __shfl_down(bits, 3, 64);
@@ -2844,8 +2853,19 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     } while (0)
 #define LP(BNv, STv, BEv) LPX(BNv, STv, BEv, false)
     if (p.fapply) {
-      if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, 64, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
-      else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, 128, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p);
+      // the two option sets every fused bottleneck tail uses get instantiations with the options compiled in (FAS);
+      // SIMCLR_FAPPLY_SPECIAL=0 (read per launch: A/B runs, bitwise test) keeps the generic epilogue
+      int fas = 0;
+      if (p.bn_x && p.bn_mode && p.bn_mask && (p.N & 31) == 0) fas = p.bn_mean ? 2 : 1;
+      { const char* e = getenv("SIMCLR_FAPPLY_SPECIAL"); if (e && atoi(e) == 0) fas = 0; }
+#define LF(BNv)                                                                                                                \
+      do {                                                                                                                     \
+        if (fas == 1) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 0, false, false, 1>), dim3(pg), dim3(256), plds, stream, p); \
+        else if (fas == 2) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 0, false, false, 2>), dim3(pg), dim3(256), plds, stream, p); \
+        else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p); \
+      } while (0)
+      if (BN == 64) LF(64); else LF(128);
+#undef LF
       return;
     }
     // 3x3 stride-1 bf16: halo-window operand path (one window load per 64-channel chunk instead of nine gathers)
