@@ -542,8 +542,14 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false, int FAS = 0>
+          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false, int FAS = 0, int EPS = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
+  // EPS (bf16 BNEPI only): the mask mode and the accumulate flag of the fused BatchNorm-backward-reduce epilogue as compile-time
+  // constants -- EPS - 1 = 2 * (mode == 4) + accumulate for the modes a ResNet step uses (2: mask recomputed from the BatchNorm
+  // input, 4: mask bits, sum(dm) only).  0: read from the kernel arguments.
+  static_assert(EPS == 0 || (BNEPI && sizeof(T) == 2 && EPS <= 4), "EPS specialises the bf16 BNEPI epilogue");
+  const int bnm = EPS ? (((EPS - 1) >> 1) ? 4 : 2) : p.bn_mode;
+  const bool accu = EPS ? ((EPS - 1) & 1) != 0 : p.accumulate != 0;
   // FAS (FAPPLY only): the run-time options of the fused BatchNorm-apply epilogue as compile-time constants for the two shapes every
   // fused bottleneck tail of a ResNet has -- 1: residual + ReLU + ReLU bit mask, Cout a multiple of 32; 2: the same with the
   // residual's own BatchNorm (projection blocks).  0: options read from the kernel arguments.  Same arithmetic, same order.
@@ -729,8 +735,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         bnp[3 * BN + i] = (ok && p.bn_rstd) ? p.bn_rstd[n] : 0.f;      // scale / shift travel in bn_mean / bn_rstd
       }
       if (BNEPI) {
-        bnp[i] = (ok && p.bn_mode == 2) ? p.bn_scale[n] : 0.f;
-        bnp[BN + i] = (ok && p.bn_mode == 2) ? p.bn_shift[n] : 0.f;
+        bnp[i] = (ok && bnm == 2) ? p.bn_scale[n] : 0.f;
+        bnp[BN + i] = (ok && bnm == 2) ? p.bn_shift[n] : 0.f;
         bnp[2 * BN + i] = (ok && p.bn_mean) ? p.bn_mean[n] : 0.f;
         bnp[3 * BN + i] = (ok && p.bn_rstd) ? p.bn_rstd[n] : 0.f;
       }
@@ -1054,7 +1060,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
 #pragma unroll
       for (int i = 0; i < ER; ++i) eld[i] = DIAG(8) ? 0 : eoff[i];
       u32x4 e_ov[ER], e_xv[ER], e_mv[ER];
-      if (p.accumulate) {
+      if (accu) {
 #pragma unroll
         for (int i = 0; i < ER; ++i) e_ov[i] = *(const u32x4*)((const uint16_t*)Y + eld[i]);
       }
@@ -1063,17 +1069,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
       }
       if (BNEPI) {
-        if (p.bn_mode != 4) {
+        if (bnm != 4) {
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_xv[i] = *(const u32x4*)((const uint16_t*)p.bn_x + eld[i]);
         } else {
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_xv[i] = zero16();
         }
-        if (p.bn_mode == 1) {
+        if (bnm == 1) {
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_mv[i] = *(const u32x4*)((const uint16_t*)p.bn_mask + eld[i]);
-        } else if (p.bn_mode >= 3) {       // one mask byte per 8-channel chunk (written by simclr_bn_apply)
+        } else if (bnm >= 3) {       // one mask byte per 8-channel chunk (written by simclr_bn_apply)
 #pragma unroll
           for (int i = 0; i < ER; ++i) e_mv[i][0] = ((const unsigned char*)p.bn_mask)[eld[i] >> 3];
         }
@@ -1127,7 +1133,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bnp[4 * BN + e_cc * 8 + e];
         }
-        if (p.accumulate) {
+        if (accu) {
           float o[8];
           chunk_to_f32<uint16_t>(e_ov[i], o);
 #pragma unroll
@@ -1137,7 +1143,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           // This pass is VALU-bound (profiles/r02_notes.md), so it accumulates the RAW moment sum(dm * x) -- one fma per
           // element -- and the flush turns it into sum(dm * x^) = rstd * (sum(dm * x) - mean * sum(dm)) once per
           // workgroup; mode 4 (sums only) touches neither x nor the second moment.
-          if (p.bn_mode == 4) {
+          if (bnm == 4) {
             const unsigned mb = e_mv[i][0];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -1147,12 +1153,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           } else {
             float xf[8];
             chunk_to_f32<uint16_t>(e_xv[i], xf);
-            if (p.bn_mode == 1) {
+            if (bnm == 1) {
               float mk[8];
               chunk_to_f32<uint16_t>(e_mv[i], mk);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
-            } else if (p.bn_mode == 3) {
+            } else if (bnm == 3) {
               const unsigned mb = e_mv[i][0];
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
@@ -1169,7 +1175,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           }
         }
         if (DIAG(16)) continue;
-        if (p.accumulate || BNEPI || EXT) *(u32x4*)dst = f32_to_chunk<uint16_t>(v);
+        if (accu || BNEPI || EXT) *(u32x4*)dst = f32_to_chunk<uint16_t>(v);
         else *(u32x4*)dst = cv;
       }
       }   // eb
@@ -2838,6 +2844,16 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         if (ws) { p.w = ws; psb = true; g_last_presplit = 1; }
       }
     }
+    // fused BatchNorm-backward-reduce epilogue with its mask mode / accumulate flag compiled in (EPS instantiations, bf16):
+    // 1 = (mode 2, store), 3 = (mode 4, store), 4 = (mode 4, accumulate); SIMCLR_BNEPI_SPECIAL=0 (read per launch) = generic
+    int eps = 0;
+    if (sizeof(T) == 2 && MODE == MODE_DGRAD && p.bn_mode) {
+      if (p.bn_mode == 2 && !p.accumulate) eps = 1;
+      else if (p.bn_mode == 4) eps = p.accumulate ? 4 : 3;
+      const char* e = getenv("SIMCLR_BNEPI_SPECIAL");
+      if (e && atoi(e) == 0) eps = 0;
+    }
+#define LPE(BNv, EXv, EPSv) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, true, true, EXv, false, false, 0, false, false, 0, EPSv>), dim3(pg), dim3(256), plds, stream, p)
 #define LPX(BNv, STv, BEv, EXv)                                                                                              \
     do {                                                                                                                     \
       if constexpr (sizeof(T) == 4) {                                                                                        \
@@ -2879,7 +2895,11 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         if ((BNv) == 128 && p.rem_parts >= 2) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, STv, BEv, false, true, false, 0, true>), dim3(pg), dim3(256), wlds, stream, p); \
         else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, BNv, 4, 2, STv, BEv, false, true>), dim3(pg), dim3(256), wlds, stream, p); \
       } while (0)
-      if (p.bn_mode) { if (BN == 64) LW(64, true, true); else LW(128, true, true); }
+      if (p.bn_mode && eps == 1 && p.rem_parts < 2) {
+        if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, 64, 4, 2, true, true, false, true, false, 0, false, false, 0, 1>), dim3(pg), dim3(256), wlds, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, true, true, false, true, false, 0, false, false, 0, 1>), dim3(pg), dim3(256), wlds, stream, p);
+      }
+      else if (p.bn_mode) { if (BN == 64) LW(64, true, true); else LW(128, true, true); }
       else if (BN == 64) { if (st) LW(64, true, false); else LW(64, false, false); }
       else { if (st) LW(128, true, false); else LW(128, false, false); }
 #undef LW
@@ -2888,13 +2908,22 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     if (!p.bn_mode && p.x2) {  // K-extended dgrad, plain epilogue (the conv input is not a BatchNorm output: block entry)
       if (BN == 64) LPX(64, false, false, true); else LPX(128, false, false, true);
     } else if (p.bn_mode && p.x2) {   // K-extended dgrad (folded BatchNorm backward of the consumer's output) + fused BN reduce
-      if (BN == 64) LPX(64, true, true, true); else LPX(128, true, true, true);
+      if (eps == 1 && p.rem_parts < 2) { if constexpr (sizeof(T) == 2) { if (BN == 64) LPE(64, true, 1); else LPE(128, true, 1); } }
+      else if (BN == 64) LPX(64, true, true, true); else LPX(128, true, true, true);
     } else if (p.bn_mode) {    // dgrad with fused BN-backward reduce (statistics = sum dm, sum dm*x^)
-      if (BN == 64) LP(64, true, true); else LP(128, true, true);
+      if ((eps == 1 || eps >= 3) && p.rem_parts < 2) {
+        if constexpr (sizeof(T) == 2) {
+          if (eps == 1) { if (BN == 64) LPE(64, false, 1); else LPE(128, false, 1); }
+          else if (eps == 3) { if (BN == 64) LPE(64, false, 3); else LPE(128, false, 3); }
+          else { if (BN == 64) LPE(64, false, 4); else LPE(128, false, 4); }
+        }
+      }
+      else if (BN == 64) LP(64, true, true); else LP(128, true, true);
     } else if (BN == 64) { if (st) LP(64, true, false); else LP(64, false, false); }
     else { if (st) LP(128, true, false); else LP(128, false, false); }
 #undef LP
 #undef LPX
+#undef LPE
     return;
   }
 #define L(BNv, STv)                                                                                    \
