@@ -3,7 +3,7 @@
 # smoke, per-layer microbench, cfg4 line
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r04_final3
+OUT=$R/gpurun_out/r04_final4
 mkdir -p "$OUT"
 cd "$R"
 timeout 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; cut -c1-300 "$OUT/bench.json" | tail -1
