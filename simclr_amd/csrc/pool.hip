@@ -114,7 +114,9 @@ __global__ void maxpool_bwd(const T* __restrict__ dy, const uint8_t* __restrict_
       // issues its loads one dependent round trip at a time.  Same order of additions: (hi,hi) (hi,lo) (lo,hi) (lo,lo).
       const int oy1 = ty >> 1, ox1 = tx >> 1;
       int oys[2] = {oy1, oy1 - 1}, oxs[2] = {ox1, ox1 - 1};
-      bool vy[2] = {oy1 <= OH - 1, oy1 >= 1 && (ty & 1) == 0}, vx[2] = {ox1 <= OW - 1, ox1 >= 1 && (tx & 1) == 0};
+      // (the second candidate carries the same upper bound as the generic loop's clamp: a caller-supplied OH / OW smaller than
+      // the pooled geometry excludes it here exactly as it does there)
+      bool vy[2] = {oy1 <= OH - 1, oy1 >= 1 && oy1 - 1 <= OH - 1 && (ty & 1) == 0}, vx[2] = {ox1 <= OW - 1, ox1 >= 1 && ox1 - 1 <= OW - 1 && (tx & 1) == 0};
       u32x4 dv[4];
       uint32_t av[4][EPC / 4];
 #pragma unroll

@@ -37,6 +37,14 @@ def test_bad_arguments_return_error_codes():
         L.ntxent_fwd(None, None, 4, 4, 100, 0, ctypes.c_float(0.1), None, None, None, None)
     with pytest.raises(_lib.SimclrHipError, match='multiple of'):
         L.conv2d_fwd(None, None, None, None, 0, 1, 8, 8, 3, 8, 8, 64, 3, 3, 1, 1, _lib.DT_BF16, None)
+    # round 4 entry points: pivoted BatchNorm statistics are an fp32 feature; the slot conversion needs a row count
+    with pytest.raises(_lib.SimclrHipError, match='fp32 only'):
+        L.conv2d_fwd_pivoted(None, None, None, None, 4, None, 1, 8, 8, 64, 8, 8, 64, 1, 1, 1, 0, _lib.DT_BF16, None)
+    with pytest.raises(_lib.SimclrHipError, match='null argument'):
+        L.conv2d_fwd_pivoted(None, None, None, None, 4, None, 1, 8, 8, 64, 8, 8, 64, 1, 1, 1, 0, _lib.DT_F32, None)
+    with pytest.raises(_lib.SimclrHipError, match='bad shape'):
+        L.bn_reduce_slots_pivoted(None, 4, 64, None, ctypes.c_double(0.0), None, None)
+    assert L.conv2d_last_presplit() == 0
     with pytest.raises(_lib.SimclrHipError, match='empty tensor list'):
         L.lars_multi_tensor(None, 0, None, 0, None, ctypes.c_float(0.1), ctypes.c_float(0.9),
                             ctypes.c_float(0.0), ctypes.c_float(0.001), 1, 0, None, None)
