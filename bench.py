@@ -536,7 +536,7 @@ def main():
         'parity_mode': parity_mode,
         # what each mode measures against the float64 oracle on a ResNet-50 / 224 px / batch-32 step (tests/gpu_checks.py
         # check_train_step_fixed): north_star asks loss 1e-3 relative, normalised embeddings 1e-5
-        'parity': {'oracle': 'unpinned (TensorFlow not installable here)',
+        'parity': {'oracle': "pinned to the reference's source executed on a numpy stand-in for TensorFlow (tests/golden/reference_pin.npz); TensorFlow's kernels unpinned",
                    'f32_mode': 'north_star met', 'parity_mode': PARITY_NOTE_SPLIT, 'bf16 (value)': 'loss 5e-4 / embeddings 1.1e-2: speed mode'},
         'allgather': coll,
         'augment': augment,

@@ -10,12 +10,20 @@ It is NOT part of the product.  Only `tests/`, `__graft_entry__.smoke()` and
 product path (`simclr_amd/`) never imports `oracle` and fails loudly when the
 HIP library is missing.
 
-PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
-this path and its arithmetic lives in TensorFlow, which
-is not installed in this image (no network).  The oracle is therefore pinned
-only by (a) closed-form known answers (tests/test_oracle_*.py), (b) the
-structural known answers the reference does publish (parameter counts in
-README.md:19-33, endpoint shapes in tf2/colabs/finetuning.ipynb:909), and
-(c) float64-vs-autograd self-consistency.  If `import tensorflow` ever
-succeeds, `oracle/check_against_tf.py` runs /root/reference/tf2 directly.
+PARITY STATUS -- pinned to the reference's SOURCE, not to TensorFlow's kernels.  The reference ships no tests, golden
+vectors or fixtures for this path and its arithmetic sits on TensorFlow, which cannot be installed in
+this image (no network).  Since round 4 the reference's own files -- /root/reference/tf2/{objective,lars_optimizer,metrics,
+resnet,data_util,model}.py, unmodified -- are executed in the build container on top of `oracle/tfshim.py`, a float64 numpy
+stand-in for the TensorFlow / Keras / absl calls they make, and their outputs are committed as tests/golden/reference_pin.npz
+(script: tests/golden/make_reference_golden.py; 190 arrays).  tests/test_reference_pin.py requires every one of them from the
+oracle: NT-Xent loss / logits / labels for one and for R emulated replicas (+ the loss gradient by central differences of the
+reference's function), the supervised loss, every LARS branch and name filter over two steps, the learning-rate schedule, the
+weight decay, the metrics, the blur filter, FixedPadding + Conv2dFixedPadding, BatchNormRelu (training / moving averages /
+inference), and the whole `Model` forward (ResNet-18 CIFAR stem, ResNet-50, ResNet-50 + SK / ResNet-D) with its variable
+NAMES, shapes, trainability and initial values -- agreement 1e-10 or better in float64.  What this does NOT pin is
+TensorFlow itself: the primitives under the reference's code (conv2d SAME/VALID, Keras BatchNormalization with the biased
+variance, avg-pool SAME counting valid elements, CosineDecay, softmax cross-entropy, l2_normalize's epsilon) are textbook
+numpy following the documented semantics, each named in tfshim.py.  `oracle/check_against_tf.py` still runs the same
+comparisons against a real TensorFlow wherever one is importable.  oracle/augment.py (four TensorFlow image kernels that are
+not under /root/reference) stays PARITY UNPINNED.
 """

@@ -1,6 +1,6 @@
 """Oracle: on-device Gaussian blur augmentation (numpy float64).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED TO THE REFERENCE'S SOURCE (tests/golden/reference_pin.npz: tf2/*.py executed on oracle/tfshim.py); TensorFlow's own kernels unpinned.
 Restates /root/reference/tf2/data_util.py:323-361 (gaussian_blur) and :413-440 (batch_random_blur)
 with the random draws (sigma per view, selector per image) passed in explicitly.
 """

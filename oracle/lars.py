@@ -1,6 +1,6 @@
 """Oracle: LARS update, LR schedule, weight-decay term (numpy float64).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED TO THE REFERENCE'S SOURCE (tests/golden/reference_pin.npz: tf2/*.py executed on oracle/tfshim.py); TensorFlow's own kernels unpinned.
 
 Restates /root/reference/tf2/lars_optimizer.py:83-157 and
 /root/reference/tf2/model.py:47-116.

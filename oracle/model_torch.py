@@ -1,6 +1,6 @@
 """Oracle: ResNet encoder + heads + pretraining step (torch-CPU, autograd).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED TO THE REFERENCE'S SOURCE (tests/golden/reference_pin.npz: tf2/*.py executed on oracle/tfshim.py); TensorFlow's own kernels unpinned.
 
 Restates /root/reference/tf2/resnet.py, /root/reference/tf2/model.py and the
 step body /root/reference/tf2/run.py:557-622 with TensorFlow's semantics

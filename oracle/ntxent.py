@@ -1,6 +1,6 @@
 """Oracle: NT-Xent contrastive loss + cross-replica concat (numpy float64).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED TO THE REFERENCE'S SOURCE (tests/golden/reference_pin.npz: tf2/*.py executed on oracle/tfshim.py); TensorFlow's own kernels unpinned.
 
 Restates /root/reference/tf2/objective.py:35-127 and the consumers of its
 outputs in /root/reference/tf2/metrics.py:23-36.

@@ -1,0 +1,352 @@
+"""Golden vectors produced by the REFERENCE'S OWN SOURCE FILES, executed in this container.  TEST INFRASTRUCTURE ONLY.
+
+    python tests/golden/make_reference_golden.py            # rewrites tests/golden/reference_pin.npz (+ reference_pin.json)
+
+TensorFlow is not installable here, so /root/reference/tf2/{objective,lars_optimizer,model,metrics,resnet,data_util}.py are
+imported UNMODIFIED on top of oracle/tfshim.py -- a float64 numpy stand-in for the TensorFlow / Keras / absl calls they make
+(each stand-in names the TensorFlow semantics it follows).  What these fixtures therefore pin: the reference's logic -- the
+NT-Xent masks / label layout / concatenation order / cross-replica concat, the LARS branches and name filters, the schedule
+and weight-decay arithmetic, the metrics, the blur filter, FixedPadding, and the wiring, variable names and initial values of
+`resnet()` / `Model` (ResNet-18 CIFAR stem, ResNet-50, ResNet-50 + SK / ResNet-D) -- executed from the reference's code, not
+restated.  What they do not pin: TensorFlow's own kernels.
+
+`reference_cases(ref_dir)` runs the reference; `oracle_cases()` computes the same keys with oracle/*.py.  The test
+(tests/test_reference_pin.py) compares oracle_cases() with the committed fixtures everywhere, and re-runs
+reference_cases() against them wherever /root/reference exists.
+"""
+import importlib
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REFERENCE = os.environ.get('SIMCLR_REFERENCE', '/root/reference')
+OUT_NPZ = os.path.join(HERE, 'reference_pin.npz')
+OUT_JSON = os.path.join(HERE, 'reference_pin.json')
+
+# tf2/run.py:37-238 defaults of the flags the imported modules read (run.py itself needs tensorflow_datasets)
+FLAG_DEFAULTS = dict(global_bn=True, batch_norm_decay=0.9, sk_ratio=0.0, se_ratio=0.0, train_mode='pretrain', fine_tune_after_block=-1,
+                     optimizer='lars', momentum=0.9, weight_decay=1e-6, warmup_epochs=10, train_batch_size=512,
+                     learning_rate_scaling='linear', train_steps=0, train_epochs=100, proj_out_dim=128, proj_head_mode='nonlinear',
+                     num_proj_layers=3, ft_proj_selector=0, resnet_depth=50, width_multiplier=1, image_size=224,
+                     lineareval_while_pretraining=True, use_blur=True, hidden_norm=True, temperature=0.1)
+
+# ---- the case table (shared by both sides) ----------------------------------------------------------------------------
+NTX = [dict(n=10, d=12, hidden_norm=True, temperature=0.1, seed=0), dict(n=7, d=9, hidden_norm=False, temperature=1.0, seed=1),
+       dict(n=16, d=8, hidden_norm=True, temperature=0.5, seed=2)]
+NTX_R = [dict(R=2, n=6, d=8, hidden_norm=True, temperature=0.1, seed=3), dict(R=3, n=4, d=6, hidden_norm=False, temperature=0.7, seed=4)]
+LARS_NAMES = [('conv2d/kernel', (3, 3, 4, 8)), ('sync_batch_normalization/gamma', (8,)), ('head_supervised/linear_layer/dense/bias', (5,)),
+              ('head_supervised/linear_layer/dense/kernel', (6, 5)), ('zero_weight/kernel', (6,)), ('zero_grad/kernel', (4, 3))]
+LARS_EXCL = ['batch_normalization', 'bias', 'head_supervised']          # tf2/model.py:39-41
+SCHED = [dict(scaling='linear', batch=512, warmup_epochs=10, train_epochs=100, train_steps=0, base_lr=0.3, num_examples=50000),
+         dict(scaling='sqrt', batch=4096, warmup_epochs=10, train_epochs=800, train_steps=0, base_lr=0.075, num_examples=1281167),
+         dict(scaling='linear', batch=256, warmup_epochs=0, train_epochs=5, train_steps=700, base_lr=1.0, num_examples=10000)]
+SCHED_STEPS = [0, 1, 17, 400, 976, 977, 978, 5000, 9765, 9766, 20000, 250000, 300000]
+CONV_CASES = [(9, 3, 2), (8, 3, 2), (7, 1, 2), (6, 3, 1), (10, 7, 2), (5, 1, 1)]
+MODELS = [dict(tag='r18_cifar', depth=18, size=32, sk=0.0, batch=4, classes=10),
+          dict(tag='r50', depth=50, size=48, sk=0.0, batch=3, classes=7),
+          dict(tag='r50_sk', depth=50, size=48, sk=0.0625, batch=3, classes=7)]
+
+
+def _rng(seed):
+    return np.random.default_rng(1000 + seed)
+
+
+def _lars_inputs():
+    rng = _rng(50)
+    out = []
+    for name, shp in LARS_NAMES:
+        w = rng.standard_normal(shp) * 0.05
+        g = rng.standard_normal(shp) * 1e-3
+        if name.startswith('zero_weight'):
+            w[:] = 0
+        if name.startswith('zero_grad'):
+            g[:] = 0
+        out.append((name, w, g))
+    return out
+
+
+def _model_inputs(m):
+    rng = _rng(70 + m['depth'] + int(m['sk'] > 0))
+    images = rng.random((m['batch'], m['size'], m['size'], 6))
+    labels = np.eye(m['classes'])[rng.integers(0, m['classes'], m['batch'])]
+    return images, labels
+
+
+def _oracle_model(m):
+    import torch
+    from oracle.model_torch import Config, init_model
+    cfg = Config(resnet_depth=m['depth'], image_size=m['size'], sk_ratio=m['sk'], num_classes=m['classes'])
+    params, state = init_model(cfg, seed=11, dtype=torch.float64)
+    # the zero-initialised gammas (init_zero) and biases would hide wiring mistakes behind zeros: perturb every variable
+    g = torch.Generator().manual_seed(12)
+    init = {k: v.clone() for k, v in list(params.items()) + list(state.items())}
+    for k in params:
+        if k.endswith('gamma:0'):
+            params[k] = params[k] + 0.5 + torch.rand(params[k].shape, generator=g, dtype=torch.float64)
+        elif k.endswith('beta:0') or k.endswith('bias:0'):
+            params[k] = params[k] + 0.2 * torch.randn(params[k].shape, generator=g, dtype=torch.float64)
+    return cfg, params, state, init
+
+
+# ---- reference side ---------------------------------------------------------------------------------------------------
+def reference_cases(ref_dir=REFERENCE):
+    from oracle import tfshim
+    tf, FLAGS = tfshim.install()
+    for k, v in FLAG_DEFAULTS.items():
+        setattr(FLAGS, k, v)
+    sys.path.insert(0, os.path.join(ref_dir, 'tf2'))
+    try:
+        for mname in ('objective', 'lars_optimizer', 'metrics', 'resnet', 'data_util', 'model'):
+            sys.modules.pop(mname, None)
+        objective, lars_optimizer, metrics, resnet, data_util, model = (
+            importlib.import_module(n) for n in ('objective', 'lars_optimizer', 'metrics', 'resnet', 'data_util', 'model'))
+    finally:
+        sys.path.pop(0)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')         # 0 / 0 in the un-selected branch of LARS' tf.where (lars_optimizer.py:108-111)
+        # objective.add_contrastive_loss, one replica (objective.py:35-89) + its gradient by central differences
+        for i, c in enumerate(NTX):
+            h = _rng(c['seed']).standard_normal((2 * c['n'], c['d']))
+            f = lambda x: float(objective.add_contrastive_loss(tf.constant(x), hidden_norm=c['hidden_norm'], temperature=c['temperature'])[0])   # noqa: E731
+            loss, logits_ab, labels = objective.add_contrastive_loss(tf.constant(h), hidden_norm=c['hidden_norm'], temperature=c['temperature'])
+            g = np.zeros_like(h)
+            for idx in np.ndindex(h.shape):
+                hp, hm = h.copy(), h.copy()
+                hp[idx] += 1e-6
+                hm[idx] -= 1e-6
+                g[idx] = (f(hp) - f(hm)) / 2e-6
+            out['ntx%d_loss' % i], out['ntx%d_logits_ab' % i], out['ntx%d_labels' % i], out['ntx%d_grad_fd' % i] = (
+                np.float64(loss), logits_ab.numpy(), labels.numpy(), g)
+            acc, ent = tfshim._Mean(), tfshim._Mean()
+            metrics.update_pretrain_metrics_train(tfshim._Mean(), acc, ent, loss, logits_ab, labels)       # metrics.py:22-35
+            out['ntx%d_acc' % i], out['ntx%d_entropy' % i] = acc.result().numpy(), ent.result().numpy()
+        # the strategy path (objective.py:58-68, 92-127) on R emulated replicas
+        for i, c in enumerate(NTX_R):
+            hs = [_rng(c['seed'] * 10 + r).standard_normal((2 * c['n'], c['d'])) for r in np.arange(c['R'])]
+            strategy = tfshim.Strategy(c['R'])
+            res = strategy.run(lambda x: objective.add_contrastive_loss(tf.constant(x), c['hidden_norm'], c['temperature'], strategy=strategy),
+                               [(h,) for h in hs])
+            cat = strategy.run(lambda x: objective.tpu_cross_replica_concat(tf.constant(x), strategy), [(h[:c['n']],) for h in hs])
+            for r, (loss, logits_ab, labels) in enumerate(res):
+                out['ntxr%d_%d_loss' % (i, r)], out['ntxr%d_%d_logits_ab' % (i, r)], out['ntxr%d_%d_labels' % (i, r)] = (
+                    np.float64(loss), logits_ab.numpy(), labels.numpy())
+            out['ntxr%d_concat' % i] = cat[0].numpy()
+            assert all(np.array_equal(cat[0], c_) for c_ in cat)
+        # objective.add_supervised_loss (objective.py:27-32) + metrics.update_finetune_metrics_train (metrics.py:48-55)
+        rng = _rng(20)
+        logits, lab = rng.standard_normal((9, 5)) * 3, np.eye(5)[rng.integers(0, 5, 9)]
+        sl = objective.add_supervised_loss(tf.constant(lab), tf.constant(logits))
+        acc = tfshim._Mean()
+        metrics.update_finetune_metrics_train(tfshim._Mean(), acc, sl, tf.constant(lab), tf.constant(logits))
+        out['sup_loss'], out['sup_acc'] = np.float64(sl), acc.result().numpy()
+        # lars_optimizer.LARSOptimizer (lars_optimizer.py:83-157): momentum variants x name filters x zero norms, two steps
+        for classic in (True, False):
+            for nest in (False, True):
+                vs = [tf.Variable(w, name=name) for name, w, _ in _lars_inputs()]
+                opt = lars_optimizer.LARSOptimizer(0.3, momentum=0.9, use_nesterov=nest, weight_decay=1e-4, classic_momentum=classic,
+                                                   exclude_from_weight_decay=LARS_EXCL)
+                for step in (0, 1):
+                    opt.apply_gradients([(g * (1 + step), v) for (_, _, g), v in zip(_lars_inputs(), vs)])
+                    for j, v in enumerate(vs):
+                        key = 'lars_c%d_n%d_s%d_v%d' % (classic, nest, step, j)
+                        out[key + '_w'], out[key + '_m'] = v.numpy(), opt.get_slot(v, 'Momentum').numpy()
+        # model.WarmUpAndCosineDecay / get_train_steps (model.py:72-110)
+        for i, s in enumerate(SCHED):
+            FLAGS.learning_rate_scaling, FLAGS.train_batch_size, FLAGS.warmup_epochs = s['scaling'], s['batch'], s['warmup_epochs']
+            FLAGS.train_epochs, FLAGS.train_steps = s['train_epochs'], s['train_steps']
+            sched = model.WarmUpAndCosineDecay(s['base_lr'], s['num_examples'])
+            out['sched%d_lr' % i] = np.array([float(sched(st)) for st in SCHED_STEPS])
+            out['sched%d_total_steps' % i] = np.int64(model.get_train_steps(s['num_examples']))
+        for k in ('learning_rate_scaling', 'train_batch_size', 'warmup_epochs', 'train_epochs', 'train_steps'):
+            setattr(FLAGS, k, FLAG_DEFAULTS[k])
+        # data_util.gaussian_blur (data_util.py:323-361), the filter random_blur applies (kernel_size = height // 10)
+        img = _rng(30).random((2, 40, 40, 3))
+        out['blur'] = data_util.gaussian_blur(tf.constant(img), kernel_size=40 // 10, sigma=1.3, padding='SAME').numpy()
+        out['blur_big'] = data_util.gaussian_blur(tf.constant(img), kernel_size=9, sigma=0.4, padding='SAME').numpy()
+        # resnet.Conv2dFixedPadding / FixedPadding (resnet.py:160-208)
+        for (hh, k, s) in CONV_CASES:
+            tfshim.reset_uids()
+            x = _rng(40 + hh + k).standard_normal((2, hh, hh, 4))
+            w = _rng(41 + hh + k).standard_normal((k, k, 4, 6))
+            layer = resnet.Conv2dFixedPadding(filters=6, kernel_size=k, strides=s)
+            layer(tf.constant(x), training=True)
+            layer.conv2d.kernel.assign(w)
+            out['conv_h%d_k%d_s%d' % (hh, k, s)] = layer(tf.constant(x), training=True).numpy()
+        # resnet.BatchNormRelu (resnet.py:31-78), local and "global" (one replica) statistics, training + inference
+        for gbn in (False, True):
+            FLAGS.global_bn = gbn
+            tfshim.reset_uids()
+            x = _rng(60).standard_normal((6, 5, 4, 8)) * 2 + 0.5
+            layer = resnet.BatchNormRelu(relu=True)
+            out['bn_g%d_train' % gbn] = layer(tf.constant(x), training=True).numpy()
+            out['bn_g%d_moving_mean' % gbn], out['bn_g%d_moving_var' % gbn] = layer.bn.moving_mean.numpy(), layer.bn.moving_variance.numpy()
+            out['bn_g%d_eval' % gbn] = layer(tf.constant(x), training=False).numpy()
+            out['bn_g%d_names' % gbn] = np.array(sorted(v.name for v in layer.variables))
+        FLAGS.global_bn = True
+        # model.Model (model.py:224-280) over resnet.resnet() (resnet.py:529-747): names, shapes, initial values, forward outputs,
+        # moving statistics, weight decay -- with the oracle's (perturbed) variables injected by NAME
+        FLAGS.use_blur = False
+        for m in MODELS:
+            FLAGS.resnet_depth, FLAGS.image_size, FLAGS.sk_ratio = m['depth'], m['size'], m['sk']
+            tfshim.reset_uids()
+            net = model.Model(m['classes'])
+            images, labels = _model_inputs(m)
+            net(tf.constant(images), training=False)                                  # builds the variables (inference: no moving-average update)
+            vs = sorted(tfshim.CREATED_VARIABLES, key=lambda v: v.name)      # per-variable tables are sorted by name on both sides
+            t = m['tag']
+            out[t + '_names'] = np.array([v.name for v in vs])
+            out[t + '_shapes'] = np.array([' '.join(str(d) for d in v.value.shape) for v in vs])
+            out[t + '_trainable'] = np.array([v.trainable for v in vs])
+            out[t + '_init_checksum'] = np.array([[float(v.numpy().sum()), float(np.abs(v.numpy()).sum())] if not v.name.endswith('kernel:0')
+                                                  else [0.0, 0.0] for v in vs])    # kernels are random in the reference: not compared
+            cfg, params, state, _ = _oracle_model(m)
+            allv = {**params, **state}
+            for v in vs:
+                v.assign(allv['model/' + v.name].numpy())
+            proj, sup = net(tf.constant(images), training=True)
+            out[t + '_proj'], out[t + '_sup'] = proj.numpy(), sup.numpy()
+            out[t + '_moving_checksum'] = np.array([[float(v.numpy().sum()), float(np.abs(v.numpy()).sum())] for v in vs
+                                                    if 'moving_' in v.name])
+            proj_e, sup_e = net(tf.constant(images), training=False)
+            out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy()
+            FLAGS.weight_decay = 1e-4
+            out[t + '_wd_lars'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=True))       # model.py:47-60
+            out[t + '_wd_all'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=False))       # model.py:62-69
+            FLAGS.weight_decay = FLAG_DEFAULTS['weight_decay']
+        for k in ('resnet_depth', 'image_size', 'sk_ratio', 'use_blur'):
+            setattr(FLAGS, k, FLAG_DEFAULTS[k])
+    return out
+
+
+# ---- oracle side ------------------------------------------------------------------------------------------------------
+def oracle_cases():
+    import torch
+    from oracle import blur as oblur
+    from oracle import lars as olars
+    from oracle import ntxent as ont
+    from oracle.model_torch import Builder, Config
+    out = {}
+    for i, c in enumerate(NTX):
+        h = _rng(c['seed']).standard_normal((2 * c['n'], c['d']))
+        loss, logits_ab, labels = ont.add_contrastive_loss(h, c['hidden_norm'], c['temperature'])
+        _, grads = ont.contrastive_loss_and_grad([h], c['hidden_norm'], c['temperature'])
+        acc, ent = ont.contrastive_metrics(logits_ab, labels)
+        out['ntx%d_loss' % i], out['ntx%d_logits_ab' % i], out['ntx%d_labels' % i], out['ntx%d_grad_fd' % i] = (
+            np.float64(loss), logits_ab, labels, grads[0])
+        out['ntx%d_acc' % i], out['ntx%d_entropy' % i] = np.float64(acc), np.float64(ent)
+    for i, c in enumerate(NTX_R):
+        hs = [_rng(c['seed'] * 10 + r).standard_normal((2 * c['n'], c['d'])) for r in range(c['R'])]
+        for r in range(c['R']):
+            loss, logits_ab, labels = ont.add_contrastive_loss(hs[r], c['hidden_norm'], c['temperature'], all_hiddens=hs, replica_id=r)
+            out['ntxr%d_%d_loss' % (i, r)], out['ntxr%d_%d_logits_ab' % (i, r)], out['ntxr%d_%d_labels' % (i, r)] = (
+                np.float64(loss), logits_ab, labels)
+        out['ntxr%d_concat' % i] = ont.tpu_cross_replica_concat([h[:c['n']] for h in hs])
+    rng = _rng(20)
+    logits, lab = rng.standard_normal((9, 5)) * 3, np.eye(5)[rng.integers(0, 5, 9)]
+    lt = torch.from_numpy(logits)
+    out['sup_loss'] = np.float64(-(torch.from_numpy(lab) * torch.log_softmax(lt, 1)).sum(1).mean())     # as model_torch.single_step_losses
+    out['sup_acc'] = np.float64(np.mean(lab.argmax(1) == logits.argmax(1)))
+    for classic in (True, False):
+        for nest in (False, True):
+            ws = [w.copy() for _, w, _ in _lars_inputs()]
+            ms = [np.zeros_like(w) for w in ws]
+            for step in (0, 1):
+                for j, (name, _, g) in enumerate(_lars_inputs()):
+                    ws[j], ms[j] = olars.lars_apply(name + ':0', ws[j], g * (1 + step), ms[j], 0.3, momentum=0.9, use_nesterov=nest,
+                                                    weight_decay=1e-4, classic_momentum=classic, exclude_from_weight_decay=LARS_EXCL)
+                    key = 'lars_c%d_n%d_s%d_v%d' % (classic, nest, step, j)
+                    out[key + '_w'], out[key + '_m'] = ws[j], ms[j]
+    for i, s in enumerate(SCHED):
+        kw = dict(warmup_epochs=s['warmup_epochs'], train_batch_size=s['batch'], learning_rate_scaling=s['scaling'],
+                  train_epochs=s['train_epochs'], train_steps=s['train_steps'])
+        out['sched%d_lr' % i] = np.array([olars.warmup_and_cosine_decay(st, s['base_lr'], s['num_examples'], **kw) for st in SCHED_STEPS])
+        out['sched%d_total_steps' % i] = np.int64(olars.get_train_steps(s['num_examples'], s['train_steps'], s['train_epochs'], s['batch']))
+    img = _rng(30).random((2, 40, 40, 3))
+    out['blur'] = oblur.gaussian_blur(img, 40 // 10, 1.3)
+    out['blur_big'] = oblur.gaussian_blur(img, 9, 0.4)
+    for (hh, k, s) in CONV_CASES:
+        x = _rng(40 + hh + k).standard_normal((2, hh, hh, 4))
+        w = _rng(41 + hh + k).standard_normal((k, k, 4, 6))
+        b = Builder(Config(), dtype=torch.float64)
+        b.init = False
+        b.params = {'conv2d_fixed_padding/conv2d/kernel:0': torch.from_numpy(w)}
+        out['conv_h%d_k%d_s%d' % (hh, k, s)] = b.conv2d_fixed_padding(torch.from_numpy(x).permute(0, 3, 1, 2), 6, k, s).permute(0, 2, 3, 1).numpy()
+    for gbn in (False, True):
+        x = _rng(60).standard_normal((6, 5, 4, 8)) * 2 + 0.5
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+        b = Builder(Config(global_bn=gbn), dtype=torch.float64)
+        out['bn_g%d_train' % gbn] = b.batch_norm_relu(xt).permute(0, 2, 3, 1).numpy()
+        st = {k.rsplit('/', 1)[1]: v.numpy() for k, v in b.new_state.items()}
+        out['bn_g%d_moving_mean' % gbn], out['bn_g%d_moving_var' % gbn] = st['moving_mean:0'], st['moving_variance:0']
+        b2 = Builder(Config(global_bn=gbn), params=b.params, dtype=torch.float64, state={k: v.double() for k, v in b.new_state.items()})
+        b2.training = False
+        out['bn_g%d_eval' % gbn] = b2.batch_norm_relu(xt).permute(0, 2, 3, 1).numpy()
+        out['bn_g%d_names' % gbn] = np.array(sorted(list(b.params.keys()) + list(b.state.keys())))
+    for m in MODELS:
+        cfg, params, state, init = _oracle_model(m)
+        images, labels = _model_inputs(m)
+        t = m['tag']
+        names = sorted(list(params.keys()) + list(state.keys()))
+        out[t + '_names'] = np.array([n[len('model/'):] for n in names])
+        out[t + '_shapes'] = np.array([' '.join(str(d) for d in init[n].shape) for n in names])
+        out[t + '_trainable'] = np.array([n in params for n in names])
+        out[t + '_init_checksum'] = np.array([[float(init[n].sum()), float(init[n].abs().sum())] if not n.endswith('kernel:0') else [0.0, 0.0]
+                                              for n in names])
+        b = Builder(cfg, params=params, state=state, dtype=torch.float64)
+        with torch.no_grad():
+            proj, sup = b.model(torch.from_numpy(images), training=True)
+        out[t + '_proj'], out[t + '_sup'] = proj.numpy(), sup.numpy()
+        out[t + '_moving_checksum'] = np.array([[float(b.new_state[n].sum()), float(b.new_state[n].abs().sum())] for n in names if 'moving_' in n])
+        b2 = Builder(cfg, params=params, state={k: v for k, v in b.new_state.items()}, dtype=torch.float64)
+        with torch.no_grad():
+            proj_e, sup_e = b2.model(torch.from_numpy(images), training=False)
+        out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy()
+        out[t + '_wd_lars'] = np.float64(olars.add_weight_decay_lars([(n, p.numpy()) for n, p in params.items()], 1e-4))
+        out[t + '_wd_all'] = np.float64(1e-4 * sum(0.5 * float((p * p).sum()) for n, p in params.items() if 'batch_normalization' not in n))
+    return out
+
+
+def compare(a, b, key):
+    """relative max-abs error of two fixture entries (0 / 1 for string and boolean tables); tolerance class by key"""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return float('inf')
+    if a.dtype.kind in 'US' or a.dtype == bool:
+        return 0.0 if bool(np.all(a == b)) else 1.0
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) / (np.max(np.abs(a.astype(np.float64))) + 1e-300))
+
+
+def tolerance(key):
+    if key.endswith('_grad_fd'):
+        return 1e-6          # the fixture is a central difference of the reference loss (step 1e-6 in float64)
+    if key.endswith('_acc'):
+        return 1e-6          # oracle/ntxent.py averages the hits in float32 as metrics.py:30 casts them
+    return 1e-8              # float64 on both sides; ~50-layer forward passes agree to 1e-10
+
+
+if __name__ == '__main__':
+    if '--check' in sys.argv:
+        # regenerate from the reference source and compare with the committed fixtures (exit 1 on any difference)
+        ref = reference_cases()
+        old = dict(np.load(OUT_NPZ))
+        bad = [k for k in sorted(set(ref) | set(old)) if k not in ref or k not in old or compare(old[k], ref[k], k) > 1e-12]
+        print('%d fixtures regenerated from %s, %d differ%s' % (len(ref), REFERENCE, len(bad), (': ' + ', '.join(bad[:8])) if bad else ''))
+        sys.exit(1 if bad else 0)
+    ref = reference_cases()
+    np.savez_compressed(OUT_NPZ, **ref)
+    meta = dict(reference=REFERENCE, files=['tf2/objective.py', 'tf2/lars_optimizer.py', 'tf2/metrics.py', 'tf2/resnet.py', 'tf2/data_util.py',
+                                            'tf2/model.py'], executed_on='oracle/tfshim.py (float64 numpy stand-in for the TensorFlow calls)',
+                keys=len(ref), flags=FLAG_DEFAULTS)
+    json.dump(meta, open(OUT_JSON, 'w'), indent=1)
+    print('wrote %d arrays to %s (%.1f KB)' % (len(ref), OUT_NPZ, os.path.getsize(OUT_NPZ) / 1024))
