@@ -118,6 +118,60 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case):
     _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, F32, bn_case=bn_case, bwd_tol_scale=2.0))
 
 
+def _reference_fixtures():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_reference_golden', os.path.join(os.path.dirname(__file__), 'golden', 'make_reference_golden.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m, dict(np.load(m.OUT_NPZ))
+
+
+def test_ntxent_kernels_match_the_reference_source_fixtures():
+    """simclr_amd.objective.add_contrastive_loss (fused NT-Xent kernels) against tests/golden/reference_pin.npz -- the outputs of
+    tf2/objective.py:35-89 itself, executed on oracle/tfshim.py: loss, logits_ab, labels, the metrics of tf2/metrics.py:28-35 and
+    d loss / d hidden (central differences of the reference function)."""
+    from simclr_amd import objective
+    m, ref = _reference_fixtures()
+    for i, c in enumerate(m.NTX):
+        h = m._rng(c['seed']).standard_normal((2 * c['n'], c['d']))
+        ht = torch.from_numpy(h.astype(np.float32)).cuda()
+        loss, logits, labels = objective.add_contrastive_loss(ht, hidden_norm=c['hidden_norm'], temperature=c['temperature'])
+        dh = loss.backward(1.0)
+        acc, ent = float(logits.contrast_acc), float(logits.contrast_entropy)
+        lg, lb = logits.dense().double().cpu().numpy(), labels.dense().double().cpu().numpy()
+        torch.cuda.synchronize()
+        tag = 'case %d %r' % (i, c)
+        assert abs(loss.item() - float(ref['ntx%d_loss' % i])) <= 2e-5 * max(1.0, abs(float(ref['ntx%d_loss' % i]))), tag
+        assert np.abs(lg - ref['ntx%d_logits_ab' % i]).max() <= 2e-5 * max(1.0, np.abs(ref['ntx%d_logits_ab' % i]).max()), tag
+        assert np.array_equal(lb, ref['ntx%d_labels' % i]), tag
+        g = ref['ntx%d_grad_fd' % i]
+        assert np.abs(dh.double().cpu().numpy() - g).max() <= 3e-4 * np.abs(g).max() + 1e-7, tag
+        assert abs(acc - float(ref['ntx%d_acc' % i])) <= 1e-6 and abs(ent - float(ref['ntx%d_entropy' % i])) <= 2e-4, (tag, acc, ent)
+
+
+def test_lars_kernels_match_the_reference_source_fixtures():
+    """simclr_amd.lars_optimizer.LARSOptimizer (two-launch multi-tensor kernels) against the parameters and Momentum slots that
+    tf2/lars_optimizer.py:83-157 itself produced over two steps (classic / popular momentum x Nesterov, excluded names, zero norms)."""
+    from simclr_amd.lars_optimizer import LARSOptimizer, Variable
+    m, ref = _reference_fixtures()
+    for classic in (True, False):
+        for nest in (False, True):
+            vs = [Variable(name + ':0', torch.from_numpy(w.astype(np.float32)).cuda()) for name, w, _ in m._lars_inputs()]
+            opt = LARSOptimizer(0.3, momentum=0.9, weight_decay=1e-4, use_nesterov=nest, classic_momentum=classic,
+                                exclude_from_weight_decay=m.LARS_EXCL)
+            grads = [torch.empty_like(v.value) for v in vs]          # fixed gradient buffers: the descriptor table is built once
+            for step in (0, 1):
+                for (_, _, g), gt in zip(m._lars_inputs(), grads):
+                    gt.copy_(torch.from_numpy((g * (1 + step)).astype(np.float32)))
+                opt.apply_gradients(list(zip(grads, vs)))
+                torch.cuda.synchronize()
+                for j, v in enumerate(vs):
+                    key = 'lars_c%d_n%d_s%d_v%d' % (classic, nest, step, j)
+                    for got, want in ((v.value, ref[key + '_w']), (opt.get_slot(v, 'Momentum'), ref[key + '_m'])):
+                        err = np.abs(got.double().cpu().numpy() - want).max()
+                        assert err <= 4e-6 * np.abs(want).max() + 1e-9, (key, v.name, err)
+
+
 @pytest.mark.parametrize('V,H,Cin,Cout,k,s,matmul', [(64, 28, 256, 128, 1, 1, 'exact'), (64, 28, 128, 128, 3, 1, 'exact'),
                                                          (96, 28, 128, 256, 3, 2, 'bf16x6_3'), (37, 14, 64, 1000, 1, 1, 'exact'),
                                                          (512, 1, 2048, 128, 1, 1, 'exact')])
