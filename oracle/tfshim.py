@@ -164,8 +164,9 @@ CREATED_VARIABLES = []          # every Variable in creation order (weight injec
 
 
 # ------------------------------------------------------------------------------------------------ tf.* functions
-def constant(x, dtype=None):
-    return cast(x, dtype) if dtype is not None else T(_f(x))
+def constant(x, dtype=None, shape=None):
+    t = cast(x, dtype) if dtype is not None else T(_f(x))
+    return T(np.reshape(_a(t), _ints(shape))) if shape is not None else t
 
 
 convert_to_tensor = constant
@@ -457,6 +458,89 @@ def _avg_pool(x, k, s, padding):
     """tf.nn.avg_pool: SAME padding divides by the number of VALID elements of each window"""
     win, msk = _windows(_f(x), int(k), int(k), int(s), int(s), padding)
     return T(win.sum(axis=(-1, -2)) / msk.sum(axis=(-1, -2)))
+
+
+# ------------------------------------------------------------------------------------------------ tf.random / tf.image (scripted)
+# data_util.py draws its randomness from TensorFlow.  Here every draw is SCRIPTED: the harness puts the outcomes into SCRIPT before it
+# calls preprocess_for_train, each stand-in hands out the scripted value and RECORDS the bounds / arguments the reference asked with
+# (SCRIPT['asked']), so that both the arithmetic given the draws and the ranges the reference draws from can be compared.  The pixel
+# kernels (bicubic resize, contrast / saturation / hue, grayscale) are oracle/augment.py's restatements of TensorFlow kernels that are
+# not under /root/reference: this part of the pin covers the reference's COMPOSITION (order, gates, clipping, strength scaling,
+# crop-shape arithmetic), not those kernels.
+SCRIPT = {}
+
+
+def _asked(kind, *args):
+    SCRIPT.setdefault('asked', []).append((kind,) + tuple(float(a) for a in args))
+
+
+def _random_uniform(shape, minval=0, maxval=1, dtype=None, **kw):
+    assert list(shape) == [], 'scripted draws are scalars'
+    lo, hi = float(_a(minval)), float(_a(maxval))
+    if (lo, hi) == (0.0, 1.0):
+        return T(np.float64(SCRIPT['unit'].pop(0)))            # the gates of random_apply, in call order
+    _asked('uniform', lo, hi)
+    return T(np.float64(SCRIPT['uniform'].pop(0)))              # brightness factor / blur sigma, in call order
+
+
+def _random_shuffle(x):
+    perm = [int(v) for v in SCRIPT['perm']]
+    assert sorted(perm) == sorted(int(v) for v in _a(x))
+    return T(np.array(perm))
+
+
+def cond(pred, true_fn, false_fn):
+    return true_fn() if bool(_a(pred)) else false_fn()
+
+
+def maximum(a, b):
+    return T(np.maximum(_f(a), _f(b)))
+
+
+def unstack(x, axis=0):
+    a = _a(x)
+    return [a[i] for i in np.arange(a.shape[int(axis)])] if int(axis) == 0 else [T(v) for v in np.moveaxis(a, int(axis), 0)]
+
+
+def _image_ns():
+    from oracle import augment as oa
+
+    def sample_distorted_bounding_box(image_size, bounding_boxes, min_object_covered=0.1, aspect_ratio_range=(0.75, 1.33),
+                                      area_range=(0.05, 1.0), max_attempts=100, use_image_if_no_bounding_boxes=False, **kw):
+        _asked('bbox', min_object_covered, aspect_ratio_range[0], aspect_ratio_range[1], area_range[0], area_range[1], max_attempts,
+               float(use_image_if_no_bounding_boxes), *np.ravel(_a(bounding_boxes)))
+        y, x, h, w = (int(v) for v in SCRIPT['crop'])
+        return T(np.array([y, x, 0])), T(np.array([h, w, -1])), None
+
+    def crop_to_bounding_box(image, oy, ox, th, tw):
+        return T(_a(image)[int(oy):int(oy) + int(th), int(ox):int(ox) + int(tw)])
+
+    def resize(images, size, method=None):
+        assert method == 'bicubic'
+        return [T(oa.resize_bicubic(_f(im), int(size[0]), int(size[1]))) for im in images]
+
+    def random_flip_left_right(image):
+        return T(_a(image)[:, ::-1]) if SCRIPT['flip'] else T(_a(image))
+
+    def _rand_op(kind, fn):
+        def op(image, lower, upper=None):
+            lo, hi = (-float(lower), float(lower)) if upper is None else (float(lower), float(upper))      # random_hue(max_delta)
+            _asked(kind, lo, hi)
+            return T(fn(_f(image), float(SCRIPT[kind])))
+        return op
+
+    def rgb_to_grayscale(image):
+        return T(oa.to_grayscale(_f(image))[..., :1])
+
+    def convert_image_dtype(image, dtype=None):
+        a = _a(image)
+        return T(a.astype(np.float64) * (1.0 / 255.0)) if a.dtype == np.uint8 else T(a.astype(np.float64))
+
+    return _ns('tensorflow.image', sample_distorted_bounding_box=sample_distorted_bounding_box, crop_to_bounding_box=crop_to_bounding_box,
+               resize=resize, ResizeMethod=types.SimpleNamespace(BICUBIC='bicubic'), random_flip_left_right=random_flip_left_right,
+               random_contrast=_rand_op('contrast', oa.adjust_contrast), random_saturation=_rand_op('saturation', oa.adjust_saturation),
+               random_hue=lambda image, max_delta: _rand_op('hue', oa.adjust_hue)(image, max_delta),
+               rgb_to_grayscale=rgb_to_grayscale, convert_image_dtype=convert_image_dtype)
 
 
 # ------------------------------------------------------------------------------------------------ tf.distribute (replica emulation)
@@ -818,6 +902,9 @@ def install():
                 conv2d=_conv2d, depthwise_conv2d=_depthwise_conv2d, max_pool=_max_pool)
     tf.distribute = _ns('tensorflow.distribute', get_replica_context=_get_replica_context, Strategy=Strategy,
                         ReduceOp=types.SimpleNamespace(SUM='SUM'))
+    tf.random = _ns('tensorflow.random', uniform=_random_uniform, shuffle=_random_shuffle)
+    tf.image = _image_ns()
+    tf.math.rint = lambda x: T(np.rint(_f(x)))                 # round half to even, like tf.math.rint
     tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None)
     tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None)
     layers = _ns('tensorflow.keras.layers', Layer=Layer, Conv2D=Conv2D, Dense=Dense, BatchNormalization=BatchNormalization,

@@ -52,11 +52,42 @@ SCHED_STEPS = [0, 1, 17, 400, 976, 977, 978, 5000, 9765, 9766, 20000, 250000, 30
 CONV_CASES = [(9, 3, 2), (8, 3, 2), (7, 1, 2), (6, 3, 1), (10, 7, 2), (5, 1, 1)]
 MODELS = [dict(tag='r18_cifar', depth=18, size=32, sk=0.0, batch=4, classes=10),
           dict(tag='r50', depth=50, size=48, sk=0.0, batch=3, classes=7),
-          dict(tag='r50_sk', depth=50, size=48, sk=0.0625, batch=3, classes=7)]
+          dict(tag='r50_sk', depth=50, size=48, sk=0.0625, batch=3, classes=7),
+          # other flag values of tf2/run.py: width multiplier, depth 34, a two-layer head whose linear-eval input is the first
+          # hidden layer (ft_proj_selector=1), a 64-wide projection, local BatchNorm, no linear-eval head
+          dict(tag='r34_w2', depth=34, size=32, sk=0.0, batch=3, classes=5, width=2, num_proj_layers=2, ft_proj_selector=1, proj_out_dim=64),
+          dict(tag='r18_localbn', depth=18, size=40, sk=0.0, batch=4, classes=6, global_bn=False, lineareval=False)]
+MODEL_FLAGS = dict(width='width_multiplier', num_proj_layers='num_proj_layers', ft_proj_selector='ft_proj_selector',
+                   proj_out_dim='proj_out_dim', global_bn='global_bn', lineareval='lineareval_while_pretraining')
+
+
+# two-view augmentation (data_util.py:443-499): (source h, w, output size, strength, flip, jitter gate, grayscale gate)
+AUG = [(61, 83, 32, 1.0, 1, 1, 0), (90, 70, 48, 1.0, 0, 1, 1), (64, 64, 40, 0.5, 1, 0, 1), (57, 120, 32, 1.0, 0, 0, 0), (100, 41, 24, 1.0, 1, 1, 1)]
+AUG_EVAL = [(61, 83, 32), (90, 70, 48), (64, 64, 40), (33, 97, 24), (97, 33, 24)]
+ASKED_KINDS = {'bbox': 0, 'uniform': 1, 'contrast': 2, 'saturation': 3, 'hue': 4}
 
 
 def _rng(seed):
     return np.random.default_rng(1000 + seed)
+
+
+def _aug_inputs(i):
+    """source image (uint8) and the draws of one view: oracle/augment.py draws them, the gates are then forced per case"""
+    from oracle import augment as oa
+    sh, sw, size, strength, flip, jit, gray = AUG[i]
+    rng = _rng(90 + i)
+    img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    p = oa.draw_train_params(rng, sh, sw, size, size, color_jitter_strength=strength)
+    p[4], p[5], p[14] = flip, jit, gray
+    return img, p
+
+
+def _asked_table(rows):
+    out = np.zeros((len(rows), 12))
+    for r, row in enumerate(rows):
+        out[r, 0] = ASKED_KINDS[row[0]]
+        out[r, 1:1 + len(row) - 1] = row[1:]
+    return out
 
 
 def _lars_inputs():
@@ -83,7 +114,8 @@ def _model_inputs(m):
 def _oracle_model(m):
     import torch
     from oracle.model_torch import Config, init_model
-    cfg = Config(resnet_depth=m['depth'], image_size=m['size'], sk_ratio=m['sk'], num_classes=m['classes'])
+    cfg = Config(resnet_depth=m['depth'], image_size=m['size'], sk_ratio=m['sk'], num_classes=m['classes'],
+                 **{flag: m[k] for k, flag in MODEL_FLAGS.items() if k in m})
     params, state = init_model(cfg, seed=11, dtype=torch.float64)
     # the zero-initialised gammas (init_zero) and biases would hide wiring mistakes behind zeros: perturb every variable
     g = torch.Generator().manual_seed(12)
@@ -172,6 +204,22 @@ def reference_cases(ref_dir=REFERENCE):
         img = _rng(30).random((2, 40, 40, 3))
         out['blur'] = data_util.gaussian_blur(tf.constant(img), kernel_size=40 // 10, sigma=1.3, padding='SAME').numpy()
         out['blur_big'] = data_util.gaussian_blur(tf.constant(img), kernel_size=9, sigma=0.4, padding='SAME').numpy()
+        # data_util.preprocess_image (data_util.py:443-520) with SCRIPTED draws: the reference's composition -- crop -> resize -> flip ->
+        # [0.8] colour jitter in shuffled order with a clip after every op -> [0.2] grayscale -> clip -- and the ranges it draws from;
+        # the pixel kernels underneath are oracle/augment.py's (tfshim.py, "tf.random / tf.image (scripted)")
+        for i in np.arange(len(AUG)):
+            img, p = _aug_inputs(int(i))
+            size, strength = AUG[i][2], AUG[i][3]
+            tfshim.SCRIPT.clear()
+            tfshim.SCRIPT.update(crop=p[0:4], flip=bool(p[4]), perm=p[6:10], contrast=p[11], saturation=p[12], hue=p[13],
+                                 uniform=[p[10]], unit=[0.5, 0.5, 0.1 if p[5] else 0.9, 0.1 if p[14] else 0.9], asked=[])
+            y = data_util.preprocess_image(img, size, size, is_training=True, color_jitter_strength=strength)
+            out['aug%d_params' % i], out['aug%d_out' % i] = p, y.numpy()
+            out['aug%d_asked' % i] = _asked_table(tfshim.SCRIPT['asked'])
+            assert not tfshim.SCRIPT['unit'], 'a gate of random_apply was not drawn'
+        for i, (sh, sw, size) in enumerate(AUG_EVAL):
+            img = _rng(95 + i).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+            out['augeval%d_out' % i] = data_util.preprocess_image(img, size, size, is_training=False, test_crop=True).numpy()
         # resnet.Conv2dFixedPadding / FixedPadding (resnet.py:160-208)
         for (hh, k, s) in CONV_CASES:
             tfshim.reset_uids()
@@ -197,6 +245,8 @@ def reference_cases(ref_dir=REFERENCE):
         FLAGS.use_blur = False
         for m in MODELS:
             FLAGS.resnet_depth, FLAGS.image_size, FLAGS.sk_ratio = m['depth'], m['size'], m['sk']
+            for k, flag in MODEL_FLAGS.items():
+                setattr(FLAGS, flag, m.get(k, FLAG_DEFAULTS[flag]))
             tfshim.reset_uids()
             net = model.Model(m['classes'])
             images, labels = _model_inputs(m)
@@ -213,16 +263,17 @@ def reference_cases(ref_dir=REFERENCE):
             for v in vs:
                 v.assign(allv['model/' + v.name].numpy())
             proj, sup = net(tf.constant(images), training=True)
-            out[t + '_proj'], out[t + '_sup'] = proj.numpy(), sup.numpy()
+            none = np.zeros((0,))
+            out[t + '_proj'], out[t + '_sup'] = proj.numpy(), sup.numpy() if sup is not None else none
             out[t + '_moving_checksum'] = np.array([[float(v.numpy().sum()), float(np.abs(v.numpy()).sum())] for v in vs
                                                     if 'moving_' in v.name])
             proj_e, sup_e = net(tf.constant(images), training=False)
-            out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy()
+            out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy() if sup_e is not None else none
             FLAGS.weight_decay = 1e-4
             out[t + '_wd_lars'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=True))       # model.py:47-60
             out[t + '_wd_all'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=False))       # model.py:62-69
             FLAGS.weight_decay = FLAG_DEFAULTS['weight_decay']
-        for k in ('resnet_depth', 'image_size', 'sk_ratio', 'use_blur'):
+        for k in ('resnet_depth', 'image_size', 'sk_ratio', 'use_blur') + tuple(MODEL_FLAGS.values()):
             setattr(FLAGS, k, FLAG_DEFAULTS[k])
     return out
 
@@ -273,6 +324,22 @@ def oracle_cases():
     img = _rng(30).random((2, 40, 40, 3))
     out['blur'] = oblur.gaussian_blur(img, 40 // 10, 1.3)
     out['blur_big'] = oblur.gaussian_blur(img, 9, 0.4)
+    from oracle import augment as oa
+    for i in range(len(AUG)):
+        img, p = _aug_inputs(i)
+        size, strength = AUG[i][2], AUG[i][3]
+        out['aug%d_params' % i], out['aug%d_out' % i] = p, oa.apply_train_params(img, p, size, size)
+        # what oracle/augment.py::draw_train_params draws from (augment.py:225-247), in the order the reference asks
+        ar = size / size
+        rows = [('bbox', 0.1, 3. / 4 * ar, 4. / 3. * ar, 0.08, 1.0, 100, 1.0, 0.0, 0.0, 1.0, 1.0)]
+        if p[5] > 0:
+            b_, c_, s_, h_ = 0.8 * strength, 0.8 * strength, 0.8 * strength, 0.2 * strength
+            ops = {0: ('uniform', max(1.0 - b_, 0.0), 1.0 + b_), 1: ('contrast', 1 - c_, 1 + c_), 2: ('saturation', 1 - s_, 1 + s_), 3: ('hue', -h_, h_)}
+            rows += [ops[int(v)] for v in p[6:10]]
+        out['aug%d_asked' % i] = _asked_table(rows)
+    for i, (sh, sw, size) in enumerate(AUG_EVAL):
+        img = _rng(95 + i).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        out['augeval%d_out' % i] = oa.preprocess_for_eval(img, size, size)
     for (hh, k, s) in CONV_CASES:
         x = _rng(40 + hh + k).standard_normal((2, hh, hh, 4))
         w = _rng(41 + hh + k).standard_normal((k, k, 4, 6))
@@ -304,12 +371,13 @@ def oracle_cases():
         b = Builder(cfg, params=params, state=state, dtype=torch.float64)
         with torch.no_grad():
             proj, sup = b.model(torch.from_numpy(images), training=True)
-        out[t + '_proj'], out[t + '_sup'] = proj.numpy(), sup.numpy()
+        none = np.zeros((0,))
+        out[t + '_proj'], out[t + '_sup'] = proj.numpy(), sup.numpy() if sup is not None else none
         out[t + '_moving_checksum'] = np.array([[float(b.new_state[n].sum()), float(b.new_state[n].abs().sum())] for n in names if 'moving_' in n])
         b2 = Builder(cfg, params=params, state={k: v for k, v in b.new_state.items()}, dtype=torch.float64)
         with torch.no_grad():
             proj_e, sup_e = b2.model(torch.from_numpy(images), training=False)
-        out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy()
+        out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy() if sup_e is not None else none
         out[t + '_wd_lars'] = np.float64(olars.add_weight_decay_lars([(n, p.numpy()) for n, p in params.items()], 1e-4))
         out[t + '_wd_all'] = np.float64(1e-4 * sum(0.5 * float((p * p).sum()) for n, p in params.items() if 'batch_normalization' not in n))
     return out
