@@ -15,12 +15,13 @@ vectors or fixtures for this path and its arithmetic sits 
 this image (no network).  Since round 4 the reference's own files -- /root/reference/tf2/{objective,lars_optimizer,metrics,
 resnet,data_util,model}.py, unmodified -- are executed in the build container on top of `oracle/tfshim.py`, a float64 numpy
 stand-in for the TensorFlow / Keras / absl calls they make, and their outputs are committed as tests/golden/reference_pin.npz
-(script: tests/golden/make_reference_golden.py; 232 arrays).  tests/test_reference_pin.py requires every one of them from the
+(script: tests/golden/make_reference_golden.py; 241 arrays).  tests/test_reference_pin.py requires every one of them from the
 oracle: NT-Xent loss / logits / labels for one and for R emulated replicas (+ the loss gradient by central differences of the
 reference's function), the supervised loss, every LARS branch and name filter over two steps, the learning-rate schedule, the
 weight decay, the metrics, the blur filter, FixedPadding + Conv2dFixedPadding, BatchNormRelu (training / moving averages /
 inference), the composition of the two-view augmentation with scripted draws (data_util.preprocess_image: gates, order, clips,
-ranges; NOT its pixel kernels), and the whole `Model` forward (ResNet-18 CIFAR stem, ResNet-50, ResNet-50 + SK / ResNet-D,
+ranges; NOT its pixel kernels), the training step `single_step` of tf2/run.py:557-622 (compiled from main()'s own source; loss
+composition, 1/R, metrics, on 1 and 2 emulated replicas), and the whole `Model` forward (ResNet-18 CIFAR stem, ResNet-50, ResNet-50 + SK / ResNet-D,
 ResNet-34 x2 with a two-layer head, local BatchNorm without the linear-eval head) with its variable NAMES, shapes, trainability
 and initial values -- agreement 1e-10 or better in float64.  What this does NOT pin is
 TensorFlow itself: the primitives under the reference's code (conv2d SAME/VALID, Keras BatchNormalization with the biased

@@ -853,17 +853,52 @@ class _CategoricalCrossentropy:
 
 
 class _Mean:
-    """tf.keras.metrics.Mean as run.py uses it"""
+    """tf.keras.metrics.Mean as run.py uses it (one object shared by the emulated replicas, hence the lock)"""
 
     def __init__(self, name=None):
-        self.name, self.total, self.count = name, 0.0, 0
+        self.name, self.total, self.count, self._lock = name, 0.0, 0, threading.Lock()
 
     def update_state(self, v):
-        self.total += float(np.mean(_f(v)))
-        self.count += 1
+        with self._lock:
+            self.total += float(np.mean(_f(v)))
+            self.count += 1
 
     def result(self):
         return T(np.float64(self.total / max(self.count, 1)))
+
+
+class GradientTape:
+    """tf.GradientTape for the one thing numpy can do with it: it cannot differentiate, so `gradient(loss, variables)` RECORDS the
+    loss it was asked to differentiate (per emulated replica) and returns None gradients.  What tf2/run.py:557-622 composes into that
+    loss, and which variables it hands to the optimizer, is thereby observable; the gradient values are the oracle's (torch autograd
+    of the pinned forward)."""
+    recorded = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def gradient(self, loss, variables):
+        with _TAPE_LOCK:
+            GradientTape.recorded[int(_get_replica_context().replica_id_in_sync_group)] = (float(_a(loss)), [v.name for v in variables])
+        return [None for _ in variables]
+
+
+_TAPE_LOCK = threading.Lock()
+
+
+class RecordingOptimizer:
+    """stands where tf2/run.py has its optimizer inside single_step: counts the call and keeps the variable order"""
+
+    def __init__(self):
+        self.iterations = 0
+        self.applied = []
+
+    def apply_gradients(self, grads_and_vars):
+        with _TAPE_LOCK:
+            self.applied.append([v.name for _, v in grads_and_vars])
 
 
 # ------------------------------------------------------------------------------------------------ absl.flags
@@ -905,7 +940,8 @@ def install():
     tf.random = _ns('tensorflow.random', uniform=_random_uniform, shuffle=_random_shuffle)
     tf.image = _image_ns()
     tf.math.rint = lambda x: T(np.rint(_f(x)))                 # round half to even, like tf.math.rint
-    tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None)
+    tf.summary = _ns('tensorflow.summary', scalar=lambda *a, **k: None, image=lambda *a, **k: None,
+                     record_if=lambda cond_: contextlib.nullcontext())
     tf.logging = _ns('tensorflow.logging', info=lambda *a, **k: None)
     layers = _ns('tensorflow.keras.layers', Layer=Layer, Conv2D=Conv2D, Dense=Dense, BatchNormalization=BatchNormalization,
                  MaxPooling2D=MaxPooling2D, AveragePooling2D=AveragePooling2D,

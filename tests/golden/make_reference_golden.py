@@ -57,6 +57,8 @@ MODELS = [dict(tag='r18_cifar', depth=18, size=32, sk=0.0, batch=4, classes=10),
           # hidden layer (ft_proj_selector=1), a 64-wide projection, local BatchNorm, no linear-eval head
           dict(tag='r34_w2', depth=34, size=32, sk=0.0, batch=3, classes=5, width=2, num_proj_layers=2, ft_proj_selector=1, proj_out_dim=64),
           dict(tag='r18_localbn', depth=18, size=40, sk=0.0, batch=4, classes=6, global_bn=False, lineareval=False)]
+# the training step of tf2/run.py:557-622 (extracted from `main` by ast, see _single_step): (model tag, replicas)
+STEPS = [('r18_cifar', 1), ('r18_cifar', 2), ('r50_sk', 1)]
 MODEL_FLAGS = dict(width='width_multiplier', num_proj_layers='num_proj_layers', ft_proj_selector='ft_proj_selector',
                    proj_out_dim='proj_out_dim', global_bn='global_bn', lineareval='lineareval_while_pretraining')
 
@@ -126,6 +128,21 @@ def _oracle_model(m):
         elif k.endswith('beta:0') or k.endswith('bias:0'):
             params[k] = params[k] + 0.2 * torch.randn(params[k].shape, generator=g, dtype=torch.float64)
     return cfg, params, state, init
+
+
+def _single_step(ref_dir, namespace):
+    """tf2/run.py defines its training step as a function nested in main(); this compiles exactly that FunctionDef (line numbers kept)
+    into `namespace`, which supplies what the closure supplied (model, optimizer, strategy, the metric objects, steps_per_loop)."""
+    import ast
+    path = os.path.join(ref_dir, 'tf2', 'run.py')
+    tree = ast.parse(open(path).read(), filename=path)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'main')      # (perform_evaluation has a single_step too)
+    node = next(n for n in ast.walk(main) if isinstance(n, ast.FunctionDef) and n.name == 'single_step')
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, 'exec'), namespace)
+    return namespace['single_step']
+
+
+STEP_METRICS = ['contrast_loss', 'contrast_acc', 'contrast_entropy', 'supervised_loss', 'supervised_acc', 'weight_decay', 'total_loss']
 
 
 # ---- reference side ---------------------------------------------------------------------------------------------------
@@ -273,6 +290,44 @@ def reference_cases(ref_dir=REFERENCE):
             out[t + '_wd_lars'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=True))       # model.py:47-60
             out[t + '_wd_all'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=False))       # model.py:62-69
             FLAGS.weight_decay = FLAG_DEFAULTS['weight_decay']
+        # run.py:557-622 single_step itself: loss composition, the division by the replica count, the metric updates, the variables handed
+        # to the optimizer -- on one replica and on two emulated replicas (SyncBatchNormalization + cross-replica concat in lock step)
+        for tag, R in STEPS:
+            m = next(mm for mm in MODELS if mm['tag'] == tag)
+            FLAGS.resnet_depth, FLAGS.image_size, FLAGS.sk_ratio = m['depth'], m['size'], m['sk']
+            for k, flag in MODEL_FLAGS.items():
+                setattr(FLAGS, flag, m.get(k, FLAG_DEFAULTS[flag]))
+            FLAGS.weight_decay = 1e-4
+            tfshim.reset_uids()
+            net = model.Model(m['classes'])
+            images, labels = _model_inputs(m)
+            net(tf.constant(images), training=False)
+            cfg, params, state, _ = _oracle_model(m)
+            allv = {**params, **state}
+            for v in tfshim.CREATED_VARIABLES:
+                v.assign(allv['model/' + v.name].numpy())
+            strategy = tfshim.Strategy(R)
+            opt = tfshim.RecordingOptimizer()
+            mets = {k: tfshim._Mean('train/' + k) for k in STEP_METRICS}
+            ns = dict(tf=tf, FLAGS=FLAGS, logging=sys.modules['absl.logging'], metrics=metrics, obj_lib=objective, model_lib=model,
+                      optimizer=opt, steps_per_loop=100, model=net, strategy=strategy, contrast_loss_metric=mets['contrast_loss'],
+                      contrast_acc_metric=mets['contrast_acc'], contrast_entropy_metric=mets['contrast_entropy'],
+                      supervised_loss_metric=mets['supervised_loss'], supervised_acc_metric=mets['supervised_acc'],
+                      weight_decay_metric=mets['weight_decay'], total_loss_metric=mets['total_loss'])
+            step = _single_step(ref_dir, ns)
+            per = m['batch'] // R
+            assert per * R == m['batch'] or R == 1
+            shards = [(tf.constant(images[r * per:(r + 1) * per] if R > 1 else images),
+                       {'labels': tf.constant(labels[r * per:(r + 1) * per] if R > 1 else labels)}) for r in np.arange(R)]
+            tfshim.GradientTape.recorded.clear()
+            strategy.run(step, shards)
+            key = 'step_%s_R%d' % (tag, R)
+            out[key + '_scaled_loss'] = np.array([tfshim.GradientTape.recorded[r][0] for r in np.arange(R)])
+            out[key + '_metrics'] = np.array([float(mets[k].result()) for k in STEP_METRICS])
+            out[key + '_applied_names'] = np.array(sorted(opt.applied[0]))
+            assert all(a == opt.applied[0] for a in opt.applied) and len(opt.applied) == R
+            assert tfshim.GradientTape.recorded[0][1] == opt.applied[0]
+        FLAGS.weight_decay = FLAG_DEFAULTS['weight_decay']
         for k in ('resnet_depth', 'image_size', 'sk_ratio', 'use_blur') + tuple(MODEL_FLAGS.values()):
             setattr(FLAGS, k, FLAG_DEFAULTS[k])
     return out
@@ -380,6 +435,43 @@ def oracle_cases():
         out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy() if sup_e is not None else none
         out[t + '_wd_lars'] = np.float64(olars.add_weight_decay_lars([(n, p.numpy()) for n, p in params.items()], 1e-4))
         out[t + '_wd_all'] = np.float64(1e-4 * sum(0.5 * float((p * p).sum()) for n, p in params.items() if 'batch_normalization' not in n))
+    # run.py:557-622: R replicas with SyncBatchNormalization, the differentiable concat and loss / R are ONE replica on the global batch
+    # (tests/test_oracle.py::test_sharded_equals_global_batch) -- the oracle's single_step_losses on the whole batch gives every number
+    import dataclasses
+    from oracle.model_torch import single_step_losses
+    for tag, R in STEPS:
+        m = next(mm for mm in MODELS if mm['tag'] == tag)
+        cfg, params, state, _ = _oracle_model(m)
+        cfg = dataclasses.replace(cfg, weight_decay=1e-4)
+        images, labels = _model_inputs(m)
+        if R > 1:
+            per = m['batch'] // R
+            images, labels = images[:per * R], labels[:per * R]
+        with torch.no_grad():
+            o = single_step_losses(cfg, params, state, torch.from_numpy(images), torch.from_numpy(labels))
+        acc, ent = ont.contrastive_metrics(o['logits_con'].numpy(), o['labels_con'].numpy())
+        l2 = np.concatenate([labels, labels], 0)
+        sup_acc = float(np.mean(l2.argmax(1) == o['sup_logits'].numpy().argmax(1)))
+        key = 'step_%s_R%d' % (tag, R)
+        # replica r's own loss (objective.py:58-87 with the gathered hiddens; its rows of the linear-eval logits), divided by R
+        N = images.shape[0]
+        per = N // R
+        proj, sup = o['proj'].numpy(), o['sup_logits'].numpy()
+        rows = [np.concatenate([np.arange(r * per, (r + 1) * per), N + np.arange(r * per, (r + 1) * per)]) for r in range(R)]
+        hs = [proj[ix] for ix in rows]
+        scaled = []
+        for r in range(R):
+            con_r, _, _ = ont.add_contrastive_loss(hs[r], cfg.hidden_norm, cfg.temperature, all_hiddens=hs if R > 1 else None, replica_id=r)
+            lr_ = np.concatenate([labels[r * per:(r + 1) * per]] * 2, 0)
+            z = sup[rows[r]]
+            zmax = z.max(1, keepdims=True)
+            sup_r = float(np.mean(np.log(np.exp(z - zmax).sum(1)) + zmax[:, 0] - (lr_ * z).sum(1)))
+            scaled.append((float(con_r) + sup_r + float(o['weight_decay'])) / R)
+        out[key + '_scaled_loss'] = np.array(scaled)
+        assert abs(sum(scaled) - float(o['total_loss'])) <= 1e-9 * abs(float(o['total_loss']))      # sharded == global batch
+        out[key + '_metrics'] = np.array([float(o['con_loss']), acc, ent, float(o['sup_loss']), sup_acc, float(o['weight_decay']),
+                                          float(o['total_loss'])])
+        out[key + '_applied_names'] = np.array(sorted(n[len('model/'):] for n in params))
     return out
 
 
