@@ -1,7 +1,8 @@
 """Pins the oracle against the reference ITSELF when TensorFlow is importable.  TEST INFRASTRUCTURE ONLY.
 
 TensorFlow is not installed in the build image (no network), so in this repository's CI every check
-below is skipped and the oracle stays "parity unpinned" (oracle/__init__.py).  On a machine that has
+below is skipped; what runs instead is the reference's own source on a numpy stand-in for TensorFlow
+(oracle/tfshim.py, tests/golden/make_reference_golden.py, tests/test_reference_pin.py -- see oracle/__init__.py).  On a machine that has
 `tensorflow` (a Keras-2-era release: needs tf.keras.optimizers.legacy and
 tf.keras.layers.experimental.SyncBatchNormalization) and `absl-py`, and the reference checkout at
 REFERENCE (default /root/reference), run
@@ -178,7 +179,7 @@ def run_all(tol=1e-5):
 
 if __name__ == '__main__':
     if not available():
-        print('tensorflow / absl / %s not available: the reference cannot be executed here (oracle stays unpinned)' % REFERENCE)
+        print('tensorflow / absl / %s not available: the reference cannot be executed here (see tests/test_reference_pin.py for the stand-in run)' % REFERENCE)
         sys.exit(0)
     ok, res = run_all()
     for name, d in res.items():

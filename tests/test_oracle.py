@@ -277,7 +277,7 @@ def test_oracle_matches_tensorflow_reference():
     """Runs /root/reference/tf2 itself against the oracle when TensorFlow is importable (it is not in this image)."""
     from oracle import check_against_tf as chk
     if not chk.available():
-        pytest.skip('tensorflow / absl / reference checkout not available here: oracle stays unpinned (DESIGN.md section 5)')
+        pytest.skip('a real tensorflow is not importable here: the oracle is pinned to the reference SOURCE on a numpy stand-in instead (tests/test_reference_pin.py, DESIGN.md section 5)')
     ok, res = chk.run_all()
     assert ok, res
 
