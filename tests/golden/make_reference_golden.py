@@ -289,6 +289,13 @@ def reference_cases(ref_dir=REFERENCE):
             FLAGS.weight_decay = 1e-4
             out[t + '_wd_lars'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=True))       # model.py:47-60
             out[t + '_wd_all'] = np.float64(model.add_weight_decay(net, adjust_per_optimizer=False))       # model.py:62-69
+            # which variables model.build_optimizer's LARSOptimizer decays / adapts (lars_optimizer.py:139-157 on the reference's own names)
+            FLAGS.optimizer, FLAGS.momentum = 'lars', 0.9
+            lopt = model.build_optimizer(0.1)
+            tv = sorted(v.name for v in net.trainable_variables)
+            out[t + '_lars_names'] = np.array(tv)
+            out[t + '_lars_decays'] = np.array([bool(lopt._use_weight_decay(n)) for n in tv])
+            out[t + '_lars_adapts'] = np.array([bool(lopt._do_layer_adaptation(n)) for n in tv])
             FLAGS.weight_decay = FLAG_DEFAULTS['weight_decay']
         # run.py:557-622 single_step itself: loss composition, the division by the replica count, the metric updates, the variables handed
         # to the optimizer -- on one replica and on two emulated replicas (SyncBatchNormalization + cross-replica concat in lock step)
@@ -435,6 +442,10 @@ def oracle_cases():
         out[t + '_proj_eval'], out[t + '_sup_eval'] = proj_e.numpy(), sup_e.numpy() if sup_e is not None else none
         out[t + '_wd_lars'] = np.float64(olars.add_weight_decay_lars([(n, p.numpy()) for n, p in params.items()], 1e-4))
         out[t + '_wd_all'] = np.float64(1e-4 * sum(0.5 * float((p * p).sum()) for n, p in params.items() if 'batch_normalization' not in n))
+        tv = sorted(n[len('model/'):] for n in params)
+        out[t + '_lars_names'] = np.array(tv)
+        out[t + '_lars_decays'] = np.array([olars.use_weight_decay(n, 1e-4, LARS_EXCL) for n in tv])
+        out[t + '_lars_adapts'] = np.array([olars.do_layer_adaptation(n, LARS_EXCL) for n in tv])
     # run.py:557-622: R replicas with SyncBatchNormalization, the differentiable concat and loss / R are ONE replica on the global batch
     # (tests/test_oracle.py::test_sharded_equals_global_batch) -- the oracle's single_step_losses on the whole batch gives every number
     import dataclasses
