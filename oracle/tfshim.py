@@ -513,6 +513,7 @@ def _image_ns():
         return T(np.array([y, x, 0])), T(np.array([h, w, -1])), None
 
     def crop_to_bounding_box(image, oy, ox, th, tw):
+        _asked('cropbox', int(oy), int(ox), int(th), int(tw))
         return T(_a(image)[int(oy):int(oy) + int(th), int(ox):int(ox) + int(tw)])
 
     def resize(images, size, method=None):

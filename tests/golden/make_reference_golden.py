@@ -66,7 +66,7 @@ MODEL_FLAGS = dict(width='width_multiplier', num_proj_layers='num_proj_layers', 
 # two-view augmentation (data_util.py:443-499): (source h, w, output size, strength, flip, jitter gate, grayscale gate)
 AUG = [(61, 83, 32, 1.0, 1, 1, 0), (90, 70, 48, 1.0, 0, 1, 1), (64, 64, 40, 0.5, 1, 0, 1), (57, 120, 32, 1.0, 0, 0, 0), (100, 41, 24, 1.0, 1, 1, 1)]
 AUG_EVAL = [(61, 83, 32), (90, 70, 48), (64, 64, 40), (33, 97, 24), (97, 33, 24)]
-ASKED_KINDS = {'bbox': 0, 'uniform': 1, 'contrast': 2, 'saturation': 3, 'hue': 4}
+ASKED_KINDS = {'bbox': 0, 'uniform': 1, 'contrast': 2, 'saturation': 3, 'hue': 4, 'cropbox': 5}
 
 
 def _rng(seed):
@@ -236,7 +236,10 @@ def reference_cases(ref_dir=REFERENCE):
             assert not tfshim.SCRIPT['unit'], 'a gate of random_apply was not drawn'
         for i, (sh, sw, size) in enumerate(AUG_EVAL):
             img = _rng(95 + i).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+            tfshim.SCRIPT.clear()
+            tfshim.SCRIPT.update(asked=[])
             out['augeval%d_out' % i] = data_util.preprocess_image(img, size, size, is_training=False, test_crop=True).numpy()
+            out['augeval%d_box' % i] = _asked_table(tfshim.SCRIPT['asked'])        # the centre-crop box of _compute_crop_shape (:175-243)
         # resnet.Conv2dFixedPadding / FixedPadding (resnet.py:160-208)
         for (hh, k, s) in CONV_CASES:
             tfshim.reset_uids()
@@ -393,7 +396,7 @@ def oracle_cases():
         out['aug%d_params' % i], out['aug%d_out' % i] = p, oa.apply_train_params(img, p, size, size)
         # what oracle/augment.py::draw_train_params draws from (augment.py:225-247), in the order the reference asks
         ar = size / size
-        rows = [('bbox', 0.1, 3. / 4 * ar, 4. / 3. * ar, 0.08, 1.0, 100, 1.0, 0.0, 0.0, 1.0, 1.0)]
+        rows = [('bbox', 0.1, 3. / 4 * ar, 4. / 3. * ar, 0.08, 1.0, 100, 1.0, 0.0, 0.0, 1.0, 1.0), ('cropbox',) + tuple(p[0:4])]
         if p[5] > 0:
             b_, c_, s_, h_ = 0.8 * strength, 0.8 * strength, 0.8 * strength, 0.2 * strength
             ops = {0: ('uniform', max(1.0 - b_, 0.0), 1.0 + b_), 1: ('contrast', 1 - c_, 1 + c_), 2: ('saturation', 1 - s_, 1 + s_), 3: ('hue', -h_, h_)}
@@ -402,6 +405,7 @@ def oracle_cases():
     for i, (sh, sw, size) in enumerate(AUG_EVAL):
         img = _rng(95 + i).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
         out['augeval%d_out' % i] = oa.preprocess_for_eval(img, size, size)
+        out['augeval%d_box' % i] = _asked_table([('cropbox',) + tuple(oa.center_crop_box(sh, sw, size, size, 0.875))])
     for (hh, k, s) in CONV_CASES:
         x = _rng(40 + hh + k).standard_normal((2, hh, hh, 4))
         w = _rng(41 + hh + k).standard_normal((k, k, 4, 6))

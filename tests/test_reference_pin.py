@@ -28,7 +28,7 @@ def test_oracle_reproduces_the_reference_source_fixtures():
     ref = dict(np.load(m.OUT_NPZ))
     orc = m.oracle_cases()
     assert set(ref) == set(orc), (sorted(set(ref) - set(orc))[:5], sorted(set(orc) - set(ref))[:5])
-    assert len(ref) >= 256
+    assert len(ref) >= 261
     bad = [(k, m.compare(ref[k], orc[k], k)) for k in sorted(ref) if m.compare(ref[k], orc[k], k) > m.tolerance(k)]
     assert not bad, bad[:10]
     # what the table covers (a fixture file that silently lost a family would pass the loop above)
@@ -146,3 +146,16 @@ def test_product_model_names_match_the_reference_source():
     finally:
         FLAGS.reset()
         RT.reset()
+
+
+def test_product_centre_crop_boxes_match_the_reference_source():
+    """simclr_amd.data_util.center_crop_boxes (the host side of the evaluation preprocessing) vs the box tf2/data_util.py:175-243
+    (_compute_crop_shape + center_crop) itself handed to crop_to_bounding_box, for landscape / portrait / square / extreme sources"""
+    from simclr_amd import data_util as pdu
+    m = _script()
+    ref = dict(np.load(m.OUT_NPZ))
+    for i, (sh, sw, size) in enumerate(m.AUG_EVAL):
+        box = ref['augeval%d_box' % i]
+        assert box.shape[0] == 1 and int(box[0, 0]) == m.ASKED_KINDS['cropbox']
+        got = pdu.center_crop_boxes([sh], [sw], size, size)[0]
+        assert [int(v) for v in got] == [int(v) for v in box[0, 1:5]], (sh, sw, size, got, box[0, 1:5])
