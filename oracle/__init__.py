@@ -15,7 +15,7 @@ vectors or fixtures for this path and its arithmetic sits 
 this image (no network).  Since round 4 the reference's own files -- /root/reference/tf2/{objective,lars_optimizer,metrics,
 resnet,data_util,model}.py, unmodified -- are executed in the build container on top of `oracle/tfshim.py`, a float64 numpy
 stand-in for the TensorFlow / Keras / absl calls they make, and their outputs are committed as tests/golden/reference_pin.npz
-(script: tests/golden/make_reference_golden.py; 261 arrays).  tests/test_reference_pin.py requires every one of them from the
+(script: tests/golden/make_reference_golden.py; 265 arrays).  tests/test_reference_pin.py requires every one of them from the
 oracle: NT-Xent loss / logits / labels for one and for R emulated replicas (+ the loss gradient by central differences of the
 reference's function), the supervised loss, every LARS branch and name filter over two steps, the learning-rate schedule, the
 weight decay, the metrics, the blur filter, FixedPadding + Conv2dFixedPadding, BatchNormRelu (training / moving averages /

@@ -15,6 +15,8 @@ restated.  What they do not pin: TensorFlow's own kernels.
 reference_cases() against them wherever /root/reference exists.
 """
 import importlib
+import importlib.machinery
+import importlib.util
 import json
 import os
 import sys
@@ -36,7 +38,7 @@ FLAG_DEFAULTS = dict(global_bn=True, batch_norm_decay=0.9, sk_ratio=0.0, se_rati
                      optimizer='lars', momentum=0.9, weight_decay=1e-6, warmup_epochs=10, train_batch_size=512,
                      learning_rate_scaling='linear', train_steps=0, train_epochs=100, proj_out_dim=128, proj_head_mode='nonlinear',
                      num_proj_layers=3, ft_proj_selector=0, resnet_depth=50, width_multiplier=1, image_size=224,
-                     lineareval_while_pretraining=True, use_blur=True, hidden_norm=True, temperature=0.1)
+                     lineareval_while_pretraining=True, use_blur=True, hidden_norm=True, temperature=0.1, color_jitter_strength=1.0)
 
 # ---- the case table (shared by both sides) ----------------------------------------------------------------------------
 NTX = [dict(n=10, d=12, hidden_norm=True, temperature=0.1, seed=0), dict(n=7, d=9, hidden_norm=False, temperature=1.0, seed=1),
@@ -82,6 +84,13 @@ def _aug_inputs(i):
     p = oa.draw_train_params(rng, sh, sw, size, size, color_jitter_strength=strength)
     p[4], p[5], p[14] = flip, jit, gray
     return img, p
+
+
+def _clip_box(box, shape):
+    """a crop box drawn for another source size, moved inside this image (the two views of data.map_fn share ONE source image)"""
+    y, x, h, w = (int(v) for v in box)
+    h, w = min(h, shape[0]), min(w, shape[1])
+    return np.array([min(y, shape[0] - h), min(x, shape[1] - w), h, w], dtype=np.float64)
 
 
 def _asked_table(rows):
@@ -234,6 +243,37 @@ def reference_cases(ref_dir=REFERENCE):
             out['aug%d_params' % i], out['aug%d_out' % i] = p, y.numpy()
             out['aug%d_asked' % i] = _asked_table(tfshim.SCRIPT['asked'])
             assert not tfshim.SCRIPT['unit'], 'a gate of random_apply was not drawn'
+        # data.map_fn (data.py:52-62, nested in build_input_fn: compiled from its own source like run.py's step): two transformations
+        # of one image concatenated on the channel axis + the one-hot label, through data.get_preprocess_fn (data.py:101-117)
+        sys.modules.setdefault('tensorflow_datasets', importlib.util.module_from_spec(importlib.machinery.ModuleSpec('tensorflow_datasets', None)))
+        sys.path.insert(0, os.path.join(ref_dir, 'tf2'))
+        try:
+            sys.modules.pop('data', None)
+            data = importlib.import_module('data')
+        finally:
+            sys.path.pop(0)
+        import ast
+        dpath = os.path.join(ref_dir, 'tf2', 'data.py')
+        dnode = next(n for n in ast.walk(ast.parse(open(dpath).read(), filename=dpath)) if isinstance(n, ast.FunctionDef) and n.name == 'map_fn')
+        for i in (0, 1):
+            views = [_aug_inputs(i), _aug_inputs(i + 2)]          # the draws of view 0 / view 1 (the source image is view 0's)
+            img = views[0][0]
+            FLAGS.image_size, FLAGS.color_jitter_strength = AUG[i][2], AUG[i][3]
+            ref_fn = data.get_preprocess_fn(True, is_pretrain=True)
+            calls = []
+
+            def scripted(image, _fn=ref_fn, _views=views, _calls=calls):
+                p = _views[len(_calls)][1]
+                _calls.append(1)
+                tfshim.SCRIPT.clear()
+                tfshim.SCRIPT.update(crop=_clip_box(p[0:4], image.shape), flip=bool(p[4]), perm=p[6:10], contrast=p[11], saturation=p[12],
+                                     hue=p[13], uniform=[p[10]], unit=[0.5, 0.5, 0.1 if p[5] else 0.9, 0.1 if p[14] else 0.9], asked=[])
+                return _fn(image)
+            ns = dict(tf=tf, FLAGS=FLAGS, is_training=True, preprocess_fn_pretrain=scripted, preprocess_fn_finetune=None, num_classes=7)
+            exec(compile(ast.Module(body=[dnode], type_ignores=[]), dpath, 'exec'), ns)
+            image6, label = ns['map_fn'](img, 3)
+            out['twoview%d_image' % i], out['twoview%d_label' % i] = image6.numpy(), label.numpy()
+        FLAGS.image_size = FLAG_DEFAULTS['image_size']
         for i, (sh, sw, size) in enumerate(AUG_EVAL):
             img = _rng(95 + i).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
             tfshim.SCRIPT.clear()
@@ -402,6 +442,12 @@ def oracle_cases():
             ops = {0: ('uniform', max(1.0 - b_, 0.0), 1.0 + b_), 1: ('contrast', 1 - c_, 1 + c_), 2: ('saturation', 1 - s_, 1 + s_), 3: ('hue', -h_, h_)}
             rows += [ops[int(v)] for v in p[6:10]]
         out['aug%d_asked' % i] = _asked_table(rows)
+    for i in (0, 1):
+        views = [_aug_inputs(i), _aug_inputs(i + 2)]
+        img = views[0][0]
+        params = np.stack([np.concatenate([_clip_box(v[1][0:4], img.shape), v[1][4:]]) for v in views])[None]
+        out['twoview%d_image' % i] = oa.two_view_batch([img], params, AUG[i][2], AUG[i][2])[0]
+        out['twoview%d_label' % i] = np.eye(7)[3]
     for i, (sh, sw, size) in enumerate(AUG_EVAL):
         img = _rng(95 + i).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
         out['augeval%d_out' % i] = oa.preprocess_for_eval(img, size, size)

@@ -28,12 +28,12 @@ def test_oracle_reproduces_the_reference_source_fixtures():
     ref = dict(np.load(m.OUT_NPZ))
     orc = m.oracle_cases()
     assert set(ref) == set(orc), (sorted(set(ref) - set(orc))[:5], sorted(set(orc) - set(ref))[:5])
-    assert len(ref) >= 261
+    assert len(ref) >= 265
     bad = [(k, m.compare(ref[k], orc[k], k)) for k in sorted(ref) if m.compare(ref[k], orc[k], k) > m.tolerance(k)]
     assert not bad, bad[:10]
     # what the table covers (a fixture file that silently lost a family would pass the loop above)
     fam = {k.split('_')[0].rstrip('0123456789') for k in ref}
-    assert {'ntx', 'ntxr', 'sup', 'lars', 'sched', 'blur', 'conv', 'bn', 'r', 'aug', 'augeval', 'step'} <= fam, fam
+    assert {'ntx', 'ntxr', 'sup', 'lars', 'sched', 'blur', 'conv', 'bn', 'r', 'aug', 'augeval', 'step', 'twoview'} <= fam, fam
     for tag in ('r18_cifar', 'r50', 'r50_sk', 'r34_w2', 'r18_localbn'):
         assert len(ref[tag + '_names']) == {'r18_cifar': 121, 'r50': 281, 'r50_sk': 387, 'r34_w2': 196, 'r18_localbn': 119}[tag]
         assert list(ref[tag + '_names']) == list(orc[tag + '_names'])       # variable names as the reference's layer construction yields them
