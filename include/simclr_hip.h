@@ -88,6 +88,12 @@ int simclr_get_f32_matmul(int which);
  * deterministic (fixed summation order).  Environment SIMCLR_IGEMM_SPLIT=0 disables it.  The hook below returns the
  * number of parts the most recent launch used (0 = whole tiles only); tests use it to prove the path ran. */
 int simclr_conv2d_last_split_parts(void);
+/* The owner of a shared tile waits for its partners with a BOUNDED spin (a lost partner must not hang the device).  A partner
+ * that never arrives is counted in a sticky device word next to the flags; this call copies the counters back (synchronous --
+ * call it where the host synchronises anyway: simclr_amd/run.py does at every logging interval) and returns their sum in
+ * *host_total: 0 on a healthy device.  The flags are reset by the consumer inside the launch and carry no host-side sequence
+ * number, so a launch captured into a hipGraph replays correctly (the scratch must exist before the capture starts). */
+int simclr_conv2d_split_tail_timeouts(unsigned* host_total);
 /* Three-term data gradient of the SIMCLR_DT_F32 launches (simclr_set_f32_matmul(*, 3)): the weight operand is rewritten once per
  * launch into (hi, lo) bf16 planes in a library-owned per-stream buffer (the second exception to "never allocates": the
  * largest weight matrix, >= 16 MB, hipMalloc'ed on first use), so the k-loop does no splitting work for it; bitwise the
@@ -333,7 +339,9 @@ int simclr_comm_open(const void* ipc_handle_64, void** mapped);
 int simclr_comm_close(void* mapped);
 int simclr_comm_destroy(void* mailbox);
 /* out[i] = sum_r in_r[i] (rank order), count <= max_doubles fp64 values; peers: HOST array of `world` mapped mailboxes
- * (peers[rank] = own); seq = 1, 2, ... identical on all ranks per exchange; status (nullable device int) = peers missing */
+ * (peers[rank] = own); seq = 1, 2, ... identical on all ranks per exchange; status (nullable device int, zeroed once by the
+ * caller) = STICKY count of peer arrivals that timed out (never cleared by the library); an exchange that timed out returns NaN
+ * in `out`.  Refuses a capturing stream (seq is a kernel argument: a hipGraph replay would carry a stale sequence number). */
 int simclr_comm_stats_allreduce(const double* in, double* out, int count, void* const* peers, int rank, int world,
                                 int max_doubles, unsigned seq, int* status, simclr_stream_t stream);
 

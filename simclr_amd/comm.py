@@ -16,11 +16,26 @@ import torch
 import torch.distributed as dist
 
 
+class PeerUnavailable(RuntimeError):
+    """Raised on EVERY rank (the decision is taken collectively) when the peer-mapped exchange cannot be set up or fails its
+    self-test; the caller then keeps the collective library for collective C."""
+
+
 class PeerStats:
     """Collective C over peer-mapped memory (csrc/comm.hip, simclr_comm_*): every rank's mailbox is mapped into every
     process through hipIpc, an all-reduce of <= max_doubles fp64 values is ONE single-workgroup launch per rank, summed in
-    rank order (bit-identical on all replicas).  Opt-in: SIMCLR_PEER_STATS=1 (RCCL / gloo stay the default transport until
-    the path has run on a multi-GPU node; two or four processes on one GPU exercise it: tests/test_gpu_distributed.py)."""
+    rank order (bit-identical on all replicas).  Default transport of collective C for world > 1 on the 'nccl' backend
+    (SIMCLR_PEER_STATS=0 keeps RCCL; =1 forces it on, e.g. for gloo ranks sharing one GPU: tests/test_gpu_distributed.py).
+
+    Failure handling:
+      * set-up is agreed COLLECTIVELY: create / open results are exchanged with all_gather_object, and a short self-test
+        (known values, checked on the host) runs before the first real exchange; if any rank fails any stage, every rank
+        raises PeerUnavailable and the Strategy falls back to the collective library -- no rank is left waiting;
+      * at run time a peer that misses the (bounded) wait turns the result of that exchange into NaN and bumps a STICKY
+        device counter; `check_health()` -- called once per step by run.make_single_step -- reads the counter of the
+        PREVIOUS step without a device synchronisation and raises."""
+
+    SELF_TEST_EXCHANGES = 6
 
     def __init__(self, group, rank, world, device, max_doubles=16384):
         import ctypes
@@ -28,25 +43,84 @@ class PeerStats:
         L = lib()
         self.rank, self.world, self.max_doubles = rank, world, max_doubles
         torch.cuda.set_device(device)
+        self._mailbox = None
+        self._mapped = []
+        # stage 1: create + export the local mailbox (local failure -> reported to everybody, nobody hangs)
         mailbox = ctypes.c_void_p()
         handle = (ctypes.c_ubyte * 64)()
-        L.comm_create(world, max_doubles, ctypes.byref(mailbox), handle)
-        handles = [None] * world
-        dist.all_gather_object(handles, bytes(handle), group=group)
-        self._mailbox = mailbox.value
+        err = None
+        try:
+            L.comm_create(world, max_doubles, ctypes.byref(mailbox), handle)
+            self._mailbox = mailbox.value
+        except Exception as e:      # noqa: BLE001 -- any local failure must reach the collective decision below
+            err = repr(e)
+        infos = [None] * world
+        dist.all_gather_object(infos, (err, bytes(handle)), group=group)
+        self._agree([i[0] for i in infos], 'create')
+        # stage 2: map every peer's mailbox
         self._peers = (ctypes.c_void_p * world)()
-        for r in range(world):
-            if r == rank:
-                self._peers[r] = mailbox.value
-            else:
-                mapped = ctypes.c_void_p()
-                buf = (ctypes.c_ubyte * 64).from_buffer_copy(handles[r])
-                L.comm_open(buf, ctypes.byref(mapped))
-                self._peers[r] = mapped.value
+        err = None
+        try:
+            for r in range(world):
+                if r == rank:
+                    self._peers[r] = mailbox.value
+                else:
+                    mapped = ctypes.c_void_p()
+                    buf = (ctypes.c_ubyte * 64).from_buffer_copy(infos[r][1])
+                    L.comm_open(buf, ctypes.byref(mapped))
+                    self._peers[r] = mapped.value
+                    self._mapped.append(mapped.value)
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)       # doubles as the barrier: every mailbox is mapped everywhere
+        self._agree(errs, 'open')
         self._seq = 0
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)     # peers that never arrived (0 = healthy)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)     # STICKY count of missed peer arrivals (0 = healthy)
+        self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_event = None
         self.exchanges = 0
-        dist.barrier(group=group)            # every mailbox is mapped everywhere before the first exchange
+        # stage 3: self-test -- rank r contributes (r + 1) * (i + 1) at index i; the sum is known in closed form
+        err = None
+        try:
+            tri = world * (world + 1) // 2
+            for k in range(self.SELF_TEST_EXCHANGES):
+                n = [1, 130, min(4096, max_doubles), 2, min(2048, max_doubles), 777][k % 6]
+                n = min(n, max_doubles)
+                x = (torch.arange(1, n + 1, dtype=torch.float64, device=device) * float((rank + 1) * (k + 1)))
+                self.all_reduce_sum(x)
+                want = torch.arange(1, n + 1, dtype=torch.float64, device=device) * float(tri * (k + 1))
+                if not bool(torch.equal(x, want)):
+                    err = 'self-test exchange %d: wrong sum (missed arrivals: %d)' % (k, int(self.status.item()))
+                    break
+            self.exchanges = 0
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)
+        self._agree(errs, 'self-test')
+
+    def _agree(self, errs, stage):
+        bad = [(r, e) for r, e in enumerate(errs) if e]
+        if bad:
+            self.close()
+            raise PeerUnavailable('peer-mapped statistics exchange unavailable (%s failed on rank %s): %s' % (stage, bad[0][0], bad[0][1]))
+
+    def close(self):
+        from ._lib import lib
+        L = lib()
+        for m in self._mapped:
+            try:
+                L.comm_close(m)
+            except Exception:      # noqa: BLE001
+                pass
+        self._mapped = []
+        if self._mailbox:
+            try:
+                L.comm_destroy(self._mailbox)
+            except Exception:      # noqa: BLE001
+                pass
+            self._mailbox = None
 
     def usable(self, tensor):
         return tensor.is_cuda and tensor.dtype == torch.float64 and tensor.is_contiguous() and 0 < tensor.numel() <= self.max_doubles
@@ -60,6 +134,30 @@ class PeerStats:
                                    torch.cuda.current_stream(tensor.device).cuda_stream)
         self.exchanges += 1
         return tensor
+
+    def check_health(self, wait=False):
+        """Once per step: raise if an exchange of an EARLIER step timed out.  No device synchronisation: the sticky counter is
+        copied to pinned host memory asynchronously and the copy of the previous call is inspected (wait=True: synchronise and
+        inspect the current value -- end of training, tests)."""
+        if self._status_event is not None and (wait or self._status_event.query()):
+            if wait:
+                self._status_event.synchronize()
+            missed = int(self._status_host[0])
+            if missed:
+                raise RuntimeError('SyncBatchNormalization statistics exchange: %d peer arrival(s) timed out on rank %d; the affected '
+                                   'statistics were poisoned with NaN.  Re-run with SIMCLR_PEER_STATS=0 to use RCCL for collective C.'
+                                   % (missed, self.rank))
+            self._status_event = None
+        if self._status_event is None:
+            self._status_host.copy_(self.status, non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
+        if wait:
+            self._status_event.synchronize()
+            missed = int(self._status_host[0])
+            self._status_event = None
+            if missed:
+                raise RuntimeError('SyncBatchNormalization statistics exchange: %d peer arrival(s) timed out on rank %d' % (missed, self.rank))
 
 
 class Strategy:
@@ -89,11 +187,20 @@ class Strategy:
             self.grad_group = dist.new_group(ranks)
         self.stat_collectives = 0                          # counters (bench / tests): collectives issued so far
         self.hidden_collectives = 0
-        # collective C over peer-mapped memory instead of the collective library (opt-in, see PeerStats)
+        # collective C over peer-mapped memory instead of the collective library (see PeerStats): default for world > 1 on the
+        # 'nccl' backend (one GPU per rank over xGMI), SIMCLR_PEER_STATS=1 forces it (gloo ranks sharing a GPU), =0 disables it.
+        # Whether it is used is decided collectively: a failed set-up / self-test on ANY rank leaves RCCL in place on ALL ranks.
         self.peer_stats = None
-        if os.environ.get('SIMCLR_PEER_STATS') == '1' and self.num_replicas_in_sync > 1 and torch.cuda.is_available():
-            self.peer_stats = PeerStats(self.stat_group, self.replica_id_in_sync_group, self.num_replicas_in_sync,
-                                        torch.device('cuda', torch.cuda.current_device()))
+        self.peer_stats_fallback = None
+        want = os.environ.get('SIMCLR_PEER_STATS')
+        if want is None:
+            want = '1' if dist.get_backend(group) == 'nccl' else '0'
+        if want == '1' and 1 < self.num_replicas_in_sync <= 16 and torch.cuda.is_available():
+            try:
+                self.peer_stats = PeerStats(self.stat_group, self.replica_id_in_sync_group, self.num_replicas_in_sync,
+                                            torch.device('cuda', torch.cuda.current_device()))
+            except PeerUnavailable as e:
+                self.peer_stats_fallback = str(e)
 
     @property
     def rank(self):
@@ -133,6 +240,11 @@ class Strategy:
             return self.peer_stats.all_reduce_sum(tensor)
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.stat_group)
         return tensor
+
+    def check_health(self, wait=False):
+        """Once per step (run.make_single_step): a timed-out peer-mapped exchange of an earlier step raises here."""
+        if self.peer_stats is not None:
+            self.peer_stats.check_health(wait=wait)
 
     def all_reduce_sum_many(self, tensors):
         """ONE all-reduce for several small tensors of one dtype (statistics of BatchNorms whose inputs do not

@@ -64,15 +64,19 @@ __global__ __launch_bounds__(256) void stats_exchange(const CommP p, const doubl
   }
   __threadfence_system();
   __syncthreads();
-  if (tid == 0 && status) *status = bad;
-  // 4. fixed-order sum
+  // STICKY: the word only ever grows (number of peer arrivals missed since the mailbox was created); a healthy exchange never
+  // clears what an earlier one reported, so a host that looks once per step cannot miss a time-out
+  const int missed = bad;
+  if (tid == 0 && status && missed) atomicAdd(status, missed);
+  // 4. fixed-order sum.  After a time-out the slots hold stale or partial data: the result is POISONED with NaN instead, so the
+  // statistics -- and with them the loss -- of this replica fail loudly rather than drift apart from the other replicas'
   for (int i = tid; i < count; i += 256) {
     double s = 0.0;
     for (int r = 0; r < p.world; ++r) {
       const double* src = (const double*)(p.peer[p.rank] + ((size_t)gen * p.world + r) * sb + kFlagBytes);
       s += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    out[i] = s;
+    out[i] = missed ? __builtin_nan("") : s;
   }
 }
 
@@ -138,13 +142,18 @@ int simclr_comm_destroy(void* mailbox) { return hipFree(mailbox) == hipSuccess ?
 
 // out[i] = sum over ranks (in rank order) of in[i], i < count <= max_doubles.  peers: HOST array of `world` device
 // addresses (peers[rank] = this rank's own mailbox, the others as returned by simclr_comm_open); seq: 1, 2, 3, ... the
-// same on every rank for the same exchange; status (nullable, device int): number of peers that never arrived.
-// in / out may alias.  One launch, one workgroup; enqueued on `stream`.
+// same on every rank for the same exchange; status (nullable, device int, zeroed once by the caller): STICKY count of peer
+// arrivals that timed out so far -- never cleared here; an exchange that timed out returns NaN in `out`.
+// in / out may alias.  One launch, one workgroup; enqueued on `stream`.  `seq` is a kernel argument: a captured hipGraph would
+// replay a stale sequence number, so the call refuses a capturing stream (error 1).
 int simclr_comm_stats_allreduce(const double* in, double* out, int count, void* const* peers, int rank, int world,
                                 int max_doubles, unsigned seq, int* status, hipStream_t stream) {
   SIMCLR_CHECK_ARG(world >= 1 && world <= 16 && rank >= 0 && rank < world, "comm_stats_allreduce: rank %d / world %d", rank, world);
   SIMCLR_CHECK_ARG(count >= 1 && count <= max_doubles, "comm_stats_allreduce: count %d exceeds the slot capacity %d", count, max_doubles);
   SIMCLR_CHECK_ARG(seq != 0, "comm_stats_allreduce: sequence numbers start at 1");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess)
+    SIMCLR_CHECK_ARG(cap == hipStreamCaptureStatusNone, "comm_stats_allreduce: the sequence number is a kernel argument; not capturable in a hipGraph");
   CommP p = {};
   for (int r = 0; r < world; ++r) {
     SIMCLR_CHECK_ARG(peers[r] != nullptr, "comm_stats_allreduce: peer %d not mapped", r);

@@ -78,12 +78,15 @@ struct ConvP {
   // Split tail (tile-quantisation fix of the persistent grid): every workgroup walks `rem_full` whole M-tiles; the
   // rem_tiles M-tiles left over (fewer than there are workgroups per N-tile) are each shared by rem_parts consecutive
   // workgroups along the REDUCTION (k-steps [j*KT/P, (j+1)*KT/P) for part j).  Parts j > 0 store their fp32 accumulators
-  // into part_ws (slot (tile * n_tiles + nt) * (rem_parts - 1) + j - 1, lane-linear) and publish part_flags[slot] = seq
-  // (agent-scope release); part 0 acquires, adds the parts in the order j = 1, 2, ... (deterministic) and runs the epilogue.
+  // into part_ws (slot (tile * n_tiles + nt) * (rem_parts - 1) + j - 1, lane-linear) and publish part_flags[slot] = 1
+  // (agent-scope release); part 0 acquires, RESETS the flag to 0 (every slot has one producer and one consumer per launch, so the
+  // flags are all zero again when the launch ends: no host-side sequence number, a captured hipGraph can replay the launch),
+  // adds the parts in the order j = 1, 2, ... (deterministic) and runs the epilogue.  A partner that does not arrive within the
+  // bounded wait bumps *part_err (sticky; simclr_conv2d_split_tail_timeouts) -- the tile's result is then wrong AND reported.
   int rem_full, rem_tiles, rem_parts;
   float* part_ws;
   unsigned* part_flags;
-  unsigned seq;
+  unsigned* part_err;
   unsigned x_bytes;  // conv_igemm_wide: size of the gathered tensor in bytes (range check of its buffer descriptor)
   // conv_igemm_wide: (images, class rows, class columns) that 8, 128 and 136 consecutive GEMM rows advance an output pixel
   int rs_dq[3], rs_drow[3], rs_dcol[3];
@@ -979,15 +982,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
-          __hip_atomic_store(p.part_flags + slot0 + pj - 1, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.part_flags + slot0 + pj - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         continue;                                        // the last tile of this workgroup: on to the statistics flush
       }
       if (tid == 0) {
         for (int j = 1; j < p.rem_parts; ++j) {
           int spins = 0;                                 // bounded: a lost partner must not hang the GPU (~0.5 s)
-          while (__hip_atomic_load(p.part_flags + slot0 + j - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq &&
+          while (__hip_atomic_load(p.part_flags + slot0 + j - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
                  ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(8);
+          if (spins >= (1 << 22)) atomicAdd(p.part_err, 1u);          // reported, never silent
+          else __hip_atomic_store(p.part_flags + slot0 + j - 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
@@ -2638,7 +2643,7 @@ static bool igemm_narrow(const ConvP& p, size_t esz) {
 // workgroups each (at most 8, at least two k-steps per part), combined through an fp32 scratch owned by the library:
 // one buffer per stream (launches of one stream are ordered, so a slot is free again when the next launch starts),
 // allocated on first use, grown when a launch needs more.  SIMCLR_IGEMM_SPLIT=0 switches it off (A/B runs).
-struct SplitScratch { hipStream_t stream; float* ws; size_t floats; unsigned* flags; size_t nflags; unsigned seq; };
+struct SplitScratch { hipStream_t stream; float* ws; size_t floats; unsigned* flags; size_t nflags; };   // flags[nflags] = time-out counter
 static SplitScratch g_split_scratch[8];
 static int g_split_scratch_n = 0;
 
@@ -2651,7 +2656,7 @@ static int g_last_split_parts = 0;      // simclr_conv2d_last_split_parts (tests
 // SIMCLR_IGEMM_SPLIT=0: never, =1: every eligible launch, >= 2: every eligible launch with at most that many parts.
 static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size_t tile_floats, hipStream_t stream, bool wide = false) {
   g_last_split_parts = 0;
-  p.rem_parts = 0; p.rem_full = 0; p.rem_tiles = 0; p.part_ws = nullptr; p.part_flags = nullptr; p.seq = 0;
+  p.rem_parts = 0; p.rem_full = 0; p.rem_tiles = 0; p.part_ws = nullptr; p.part_flags = nullptr; p.part_err = nullptr;
   const char* e = getenv("SIMCLR_IGEMM_SPLIT");
   const int mode = e ? atoi(e) : (wide ? 1 : 0);
   if (mode == 0 || p.n_tiles <= 0 || grid % p.n_tiles != 0) return true;
@@ -2676,31 +2681,58 @@ static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size
   if (!sc) {
     if (g_split_scratch_n == 8) return true;        // more streams than scratch buffers: run without the split
     sc = &g_split_scratch[g_split_scratch_n++];
-    *sc = SplitScratch{stream, nullptr, 0, nullptr, 0, 0};
+    *sc = SplitScratch{stream, nullptr, 0, nullptr, 0};
   }
   if (sc->floats < slots * tile_floats || sc->nflags < slots) {
-    // grow (hipFree synchronises with the device: earlier launches that use the old buffers have finished)
+    // grow.  Not while the stream is being captured into a hipGraph (allocation is not a capturable operation): the un-split
+    // schedule is still correct.  hipFree synchronises with the device: earlier launches that use the old buffers have finished.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) {
+      (void)hipGetLastError();
+      return true;
+    }
+    unsigned lost = 0;                                 // the time-out count travels to the new allocation (sticky)
+    if (sc->flags) (void)hipMemcpy(&lost, sc->flags + sc->nflags, sizeof(unsigned), hipMemcpyDeviceToHost);
     if (sc->ws) (void)hipFree(sc->ws);
     if (sc->flags) (void)hipFree(sc->flags);
     sc->ws = nullptr; sc->flags = nullptr; sc->floats = 0; sc->nflags = 0;
     const size_t want_f = slots * tile_floats, want_n = slots < 1024 ? 1024 : slots;
+    // the flags are zeroed ON THE LAUNCH STREAM (ordered before the launch that follows, whatever kind of stream it is)
     if (hipMalloc((void**)&sc->ws, want_f * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&sc->flags, want_n * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(sc->flags, 0, want_n * sizeof(unsigned)) != hipSuccess) {
+        hipMalloc((void**)&sc->flags, (want_n + 1) * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(sc->flags, 0, (want_n + 1) * sizeof(unsigned), stream) != hipSuccess ||
+        (lost && hipMemcpyAsync(sc->flags + want_n, &lost, sizeof(unsigned), hipMemcpyHostToDevice, stream) != hipSuccess) ||
+        (lost && hipStreamSynchronize(stream) != hipSuccess)) {
       (void)hipGetLastError();
       if (sc->ws) (void)hipFree(sc->ws);
       if (sc->flags) (void)hipFree(sc->flags);
       sc->ws = nullptr; sc->flags = nullptr;
       return true;                                   // no scratch: the un-split schedule is still correct
     }
-    sc->floats = want_f; sc->nflags = want_n; sc->seq = 0;
+    sc->floats = want_f; sc->nflags = want_n;
   }
   p.rem_full = full; p.rem_tiles = R; p.rem_parts = P;
   g_last_split_parts = P;
-  p.part_ws = sc->ws; p.part_flags = sc->flags;
-  p.seq = ++sc->seq;
-  if (p.seq == 0) p.seq = ++sc->seq;                  // 0 is the "never written" value of a flag
+  p.part_ws = sc->ws; p.part_flags = sc->flags; p.part_err = sc->flags + sc->nflags;
   return true;
+}
+
+// Number of split-tail partners that never arrived (summed over every stream's scratch) since the library was loaded: 0 on a
+// healthy device.  Synchronous (copies the sticky counters back): call it where the host synchronises anyway.
+static int split_tail_timeouts(unsigned* host_total) {
+  SIMCLR_CHECK_ARG(host_total != nullptr, "conv2d_split_tail_timeouts: null argument");
+  unsigned total = 0;
+  for (int i = 0; i < g_split_scratch_n; ++i) {
+    if (!g_split_scratch[i].flags) continue;
+    unsigned v = 0;
+    if (hipMemcpy(&v, g_split_scratch[i].flags + g_split_scratch[i].nflags, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) {
+      simclr_set_error("conv2d_split_tail_timeouts: %s", hipGetErrorString(hipGetLastError()));
+      return 2;
+    }
+    total += v;
+  }
+  *host_total = total;
+  return 0;
 }
 
 // Pre-split weights of the fp32 data gradient under three split-bf16 terms (simclr_set_f32_matmul(*, 3)): the weight
@@ -3003,6 +3035,7 @@ int simclr_get_f32_matmul(int which) { return which == 0 ? g_f32_terms_fwd : g_f
 // Test hook: into how many parts the most recent forward / dgrad launch of this process split each left-over tile
 // (0 = the launch ran whole tiles only).  See "split tail" above.
 int simclr_conv2d_last_split_parts(void) { return g_last_split_parts; }
+int simclr_conv2d_split_tail_timeouts(unsigned* host_total) { return split_tail_timeouts(host_total); }
 // Test hook: 1 if the most recent fp32 data-gradient launch read pre-split weights (three split-bf16 terms, see presplit_weights).
 int simclr_conv2d_last_presplit(void) { return g_last_presplit; }
 

@@ -324,15 +324,17 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_wide(const ConvP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
-          __hip_atomic_store(p.part_flags + slot0 + pj - 1, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.part_flags + slot0 + pj - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         continue;
       }
       if (tid == 0) {
         for (int j = 1; j < p.rem_parts; ++j) {
           int spins = 0;
-          while (__hip_atomic_load(p.part_flags + slot0 + j - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq &&
+          while (__hip_atomic_load(p.part_flags + slot0 + j - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
                  ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(8);
+          if (spins >= (1 << 22)) atomicAdd(p.part_err, 1u);          // reported, never silent (see ConvP)
+          else __hip_atomic_store(p.part_flags + slot0 + j - 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: replay-safe
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }

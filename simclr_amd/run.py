@@ -128,6 +128,8 @@ def make_single_step(model, optimizer, strategy, all_metrics=None):
         optimizer.apply_gradients([(v.grad, v) for v in model._flat_order])                # :622
         RT.weights_version += 1
         ops.end_step()
+        if strategy is not None:
+            strategy.check_health()          # a timed-out statistics exchange of an earlier step raises here (no device sync)
 
         # ---- metrics (device scalars, no sync): tf2/run.py:587-613 -- update_pretrain_metrics_train,
         # update_finetune_metrics_train, weight_decay and total_loss = the sum of the loss terms, in two launches:

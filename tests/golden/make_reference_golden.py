@@ -28,6 +28,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)          # recipe.py (pure numpy) sits next to this script
 
 REFERENCE = os.environ.get('SIMCLR_REFERENCE', '/root/reference')
 OUT_NPZ = os.path.join(HERE, 'reference_pin.npz')
@@ -59,8 +61,11 @@ MODELS = [dict(tag='r18_cifar', depth=18, size=32, sk=0.0, batch=4, classes=10),
           # hidden layer (ft_proj_selector=1), a 64-wide projection, local BatchNorm, no linear-eval head
           dict(tag='r34_w2', depth=34, size=32, sk=0.0, batch=3, classes=5, width=2, num_proj_layers=2, ft_proj_selector=1, proj_out_dim=64),
           dict(tag='r18_localbn', depth=18, size=40, sk=0.0, batch=4, classes=6, global_bn=False, lineareval=False)]
+# well-conditioned cases (tests/golden/recipe.py: variables by NAME from a pure-numpy recipe, image-like inputs, batch 16): fp32 arithmetic
+# itself stays 5-10x inside north_star's 1e-5 / 1e-3 on them, so the device tests and bench.py gate them with FIXED tolerances
+MODELS += [dict(tag=t, sk=0.0, recipe=True, **{k: v for k, v in c.items()}) for t, c in sorted(__import__('recipe').IMG_CASES.items())]
 # the training step of tf2/run.py:557-622 (extracted from `main` by ast, see _single_step): (model tag, replicas)
-STEPS = [('r18_cifar', 1), ('r18_cifar', 2), ('r50_sk', 1)]
+STEPS = [('r18_cifar', 1), ('r18_cifar', 2), ('r50_sk', 1), ('r18_img', 1), ('r18_img', 2), ('r50_img', 1)]
 MODEL_FLAGS = dict(width='width_multiplier', num_proj_layers='num_proj_layers', ft_proj_selector='ft_proj_selector',
                    proj_out_dim='proj_out_dim', global_bn='global_bn', lineareval='lineareval_while_pretraining')
 
@@ -116,6 +121,9 @@ def _lars_inputs():
 
 
 def _model_inputs(m):
+    if m.get('recipe'):
+        import recipe
+        return recipe.structured_images(m['batch'], m['size'], 2, m['seed']), recipe.one_hot_labels(m['batch'], m['classes'], m['seed'])
     rng = _rng(70 + m['depth'] + int(m['sk'] > 0))
     images = rng.random((m['batch'], m['size'], m['size'], 6))
     labels = np.eye(m['classes'])[rng.integers(0, m['classes'], m['batch'])]
@@ -131,6 +139,11 @@ def _oracle_model(m):
     # the zero-initialised gammas (init_zero) and biases would hide wiring mistakes behind zeros: perturb every variable
     g = torch.Generator().manual_seed(12)
     init = {k: v.clone() for k, v in list(params.items()) + list(state.items())}
+    if m.get('recipe'):
+        import recipe
+        for k in params:
+            params[k] = torch.from_numpy(recipe.variable_value(k[len('model/'):], init[k].numpy(), m['perturb']))
+        return cfg, params, state, init
     for k in params:
         if k.endswith('gamma:0'):
             params[k] = params[k] + 0.5 + torch.rand(params[k].shape, generator=g, dtype=torch.float64)

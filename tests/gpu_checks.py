@@ -1599,3 +1599,197 @@ def check_gram_stats(V, H, K, N, seed=0):
         out.append(dict(name='bn_stats_mean ' + tag, err=e_mean, tol=t_mean, scale=1.0, ok=e_mean <= t_mean, nbad=0, numel=N))
         out.append(dict(name='bn_stats_var ' + tag, err=e_var, tol=1e-4, scale=1.0, ok=e_var <= 1e-4, nbad=0, numel=N))
     return out
+
+
+# ------------------------------------------------------------------ the PRODUCT against the reference-source fixtures, in one hop
+_PIN = {}
+
+
+def reference_pin():
+    """(make_reference_golden module, fixtures): tests/golden/reference_pin.npz = outputs of /root/reference/tf2/*.py themselves."""
+    if not _PIN:
+        import importlib.util
+        import os
+        here = os.path.dirname(os.path.abspath(__file__))
+        spec = importlib.util.spec_from_file_location('make_reference_golden', os.path.join(here, 'golden', 'make_reference_golden.py'))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        _PIN['m'], _PIN['ref'] = m, dict(np.load(m.OUT_NPZ))
+    return _PIN['m'], _PIN['ref']
+
+
+def pinned_product_model(mm, compute_dtype='f32', f32_matmul='exact', weight_decay=None, strategy=None, variables=None):
+    """simclr_amd.model.Model under the flags of fixture case `mm`, with the case's variables injected by NAME.
+    `variables`: name -> float64 array (default: the table make_reference_golden.py handed to the reference's own model)."""
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    m, _ = reference_pin()
+    FLAGS.reset()
+    FLAGS.update(use_blur=False, resnet_depth=mm['depth'], image_size=mm['size'], sk_ratio=mm['sk'], compute_dtype=compute_dtype,
+                 f32_matmul=f32_matmul, train_batch_size=mm['batch'],
+                 **{flag: mm[k] for k, flag in m.MODEL_FLAGS.items() if k in mm})
+    if weight_decay is not None:
+        FLAGS.update(weight_decay=weight_decay)
+    RT.reset()
+    RT.device = torch.device(DEV)
+    RT.strategy = strategy
+    model = model_lib.Model(mm['classes'])
+    with torch.no_grad():
+        model(torch.zeros(2, mm['size'], mm['size'], 6, device=DEV), training=False)      # builds the variables; nothing moves in inference mode
+    if variables is None:
+        variables = _pin_variables(mm)
+    names = sorted(v.name for v in model.variables)
+    assert names == sorted(variables), (sorted(set(names) - set(variables))[:4], sorted(set(variables) - set(names))[:4])
+    if mm.get('recipe'):
+        # the `*_img` variables are a function of (reference name, shape, the owner's initial value): derived from the PRODUCT's own freshly
+        # initialised variables they must equal the table the reference's model was given (bench.py's in-run parity block relies on it)
+        import recipe
+        for v in model.variables:
+            mine = recipe.variable_value(v.name[len('model/'):], v.value.double().cpu().numpy(), mm['perturb'])
+            assert np.array_equal(mine, np.asarray(variables[v.name])), v.name
+    for v in model.variables:
+        assert tuple(v.value.shape) == tuple(variables[v.name].shape), (v.name, v.value.shape, variables[v.name].shape)
+        v.value.copy_(torch.from_numpy(np.asarray(variables[v.name])).to(torch.float32).to(DEV))
+    RT.weights_version += 1
+    return model
+
+
+def _pin_variables(mm):
+    """name -> float64 array: the variables make_reference_golden.py injected into the reference's model for case `mm` (cached)"""
+    key = ('vars', mm['tag'])
+    if key not in _PIN:
+        m, _ = reference_pin()
+        _, params, state, _ = m._oracle_model(mm)
+        _PIN[key] = {k: v.numpy() for k, v in list(params.items()) + list(state.items())}
+    return _PIN[key]
+
+
+def _l2n(x):
+    x = np.asarray(x, dtype=np.float64)
+    return x / np.sqrt(np.maximum((x * x).sum(1, keepdims=True), 1e-12))       # tf.math.l2_normalize (tf2/objective.py:54)
+
+
+def _pin_fp32_noise(mm):
+    """What fp32 arithmetic itself does to this case: the oracle evaluated in torch-CPU float32 against the float64 fixtures
+    (normalised-embedding abs error, projection rel error, linear-eval logits rel error).  The small wiring cases (batch 3 ... 4:
+    BatchNorm over 6 ... 8 rows in the heads) sit at 5e-5 ... 1e-4 here -- their gates are calibrated by this number; the `*_img`
+    cases sit at 1e-6 ... 2e-6 and are gated by north_star's fixed 1e-5 / 1e-3."""
+    from collections import OrderedDict
+    from oracle.model_torch import Builder
+    m, ref = reference_pin()
+    if ('noise', mm['tag']) in _PIN:
+        return _PIN[('noise', mm['tag'])]
+    cfg, params, state, _ = m._oracle_model(mm)
+    images, _ = m._model_inputs(mm)
+    b = Builder(cfg, params=OrderedDict((k, v.float()) for k, v in params.items()),
+                state=OrderedDict((k, v.float()) for k, v in state.items()), dtype=torch.float32)
+    with torch.no_grad():
+        proj, sup = b.model(torch.from_numpy(images).float(), training=True)
+    t = mm['tag']
+    r = ref[t + '_proj']
+    out = dict(emb=float(np.abs(_l2n(proj.double().numpy()) - _l2n(r)).max()), proj=float(np.abs(proj.double().numpy() - r).max() / np.abs(r).max()))
+    if sup is not None:
+        out['sup'] = float(np.abs(sup.double().numpy() - ref[t + '_sup']).max() / np.abs(ref[t + '_sup']).max())
+    _PIN[('noise', mm['tag'])] = out
+    return out
+
+
+def check_reference_pin_model(tag, compute_dtype='f32', f32_matmul='exact', gate=True):
+    """simclr_amd.model.Model (train forward, BatchNorm moving statistics, inference forward, add_weight_decay) against what
+    /root/reference/tf2/model.py:228-280 ITSELF returned on the same variables and images (tests/golden/reference_pin.npz) -- the
+    product against the reference's source in ONE hop, no oracle in between.  fp32 modes: normalised embeddings <= 1e-5 abs on the
+    well-conditioned `*_img` cases (north_star); on the small wiring cases the gate is max(1e-5, 6 x the error torch-CPU fp32 shows)."""
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    m, ref = reference_pin()
+    mm = next(c for c in m.MODELS if c['tag'] == tag)
+    images, _ = m._model_inputs(mm)
+    noise = _pin_fp32_noise(mm) if gate else dict(emb=0.0, proj=0.0, sup=0.0)
+    fixed = bool(mm.get('recipe'))
+    model = pinned_product_model(mm, compute_dtype, f32_matmul)
+    x = torch.from_numpy(images).float().to(DEV)
+    mode = compute_dtype + ('' if f32_matmul == 'exact' else '/' + f32_matmul)
+    res = []
+
+    def entry(name, err, tol, **kw):
+        d = dict(name='pin_%s %s %s' % (name, tag, mode), err=float(err), tol=float(tol) if gate else float('inf'), scale=1.0,
+                 ok=bool(err <= tol) or not gate, nbad=0, numel=1)
+        d.update(kw)
+        res.append(d)
+
+    def rel(a, r):
+        return float(np.abs(np.asarray(a, dtype=np.float64) - r).max() / (np.abs(r).max() + 1e-300))
+
+    emb_tol = 1e-5 if fixed else max(1e-5, 6.0 * noise['emb'])
+    rel_tol = 5e-5 if fixed else max(5e-5, 6.0 * max(noise['proj'], noise.get('sup', 0.0)))
+    for training, sfx in ((True, ''), (False, '_eval')):
+        proj, sup = model(x, training=training)
+        torch.cuda.synchronize()
+        p = proj.double().cpu().numpy()
+        entry('embeddings_abs' + sfx, np.abs(_l2n(p) - _l2n(ref[tag + '_proj' + sfx])).max(), emb_tol, fp32_noise=noise['emb'])
+        entry('proj_rel' + sfx, rel(p, ref[tag + '_proj' + sfx]), rel_tol)
+        if ref[tag + '_sup' + sfx].size:
+            entry('sup_logits_rel' + sfx, rel(sup.dense().double().cpu().numpy(), ref[tag + '_sup' + sfx]), rel_tol)
+        else:
+            entry('no_sup_head' + sfx, 0.0 if sup is None else 1.0, 0.0)
+        if training:      # the moving averages after ONE training forward (tf2/resnet.py:62-72, batch_norm_decay 0.9), per variable, by name
+            mv = sorted((v.name, v.value.double().cpu().numpy()) for v in model.variables if 'moving_' in v.name)
+            got = np.array([[float(a.sum()), float(np.abs(a).sum())] for _, a in mv])
+            want = ref[tag + '_moving_checksum']
+            entry('moving_statistics_checksum_rel', np.abs(got - want).max() / np.abs(want).max() if got.shape == want.shape else float('inf'),
+                  2e-5 if fixed else max(2e-5, 6.0 * noise['proj']), n=len(mv))
+    FLAGS.update(weight_decay=1e-4)
+    wd = model_lib.add_weight_decay(model, adjust_per_optimizer=True)            # tf2/model.py:47-60
+    wd = float(wd.reshape(-1)[0]) if torch.is_tensor(wd) else float(wd)
+    entry('weight_decay_lars_rel', abs(wd - float(ref[tag + '_wd_lars'])) / max(abs(float(ref[tag + '_wd_lars'])), 1e-30)
+          if float(ref[tag + '_wd_lars']) != 0.0 else abs(wd), 2e-6, value=wd, ref=float(ref[tag + '_wd_lars']))
+    FLAGS.reset(); RT.reset()
+    return res
+
+
+def check_reference_pin_step(tag, compute_dtype='f32', f32_matmul='exact', gate=True):
+    """simclr_amd.run.make_single_step against the scaled loss and the seven metrics tf2/run.py:557-622 ITSELF produced (one replica;
+    the two-replica fixtures are checked in tests/test_gpu_distributed.py).  Loss terms <= 1e-3 relative (north_star); the
+    normalised embeddings the loss was computed from <= 1e-5 on the `*_img` cases."""
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    from simclr_amd.run import make_single_step
+    m, ref = reference_pin()
+    mm = next(c for c in m.MODELS if c['tag'] == tag)
+    images, labels = m._model_inputs(mm)
+    fixed = bool(mm.get('recipe'))
+    model = pinned_product_model(mm, compute_dtype, f32_matmul, weight_decay=1e-4)
+    step = make_single_step(model, model_lib.build_optimizer(0.1), None)
+    out = step(torch.from_numpy(images).float().to(DEV), {'labels': torch.from_numpy(labels).float().to(DEV)})
+    torch.cuda.synchronize()
+    mode = compute_dtype + ('' if f32_matmul == 'exact' else '/' + f32_matmul)
+    key = 'step_%s_R1' % tag
+    want = dict(zip(m.STEP_METRICS, ref[key + '_metrics']))
+    got = {k.split('/', 1)[1]: float(v.result()) for k, v in step.metrics.items()}
+    res = []
+
+    def entry(name, err, tol, **kw):
+        d = dict(name='pin_step_%s %s %s' % (name, tag, mode), err=float(err), tol=float(tol) if gate else float('inf'), scale=1.0,
+                 ok=bool(err <= tol) or not gate, nbad=0, numel=1)
+        d.update(kw)
+        res.append(d)
+    n = images.shape[0]
+    total = float(out['total_loss'].reshape(-1)[0])
+    entry('scaled_loss_rel', abs(total - float(ref[key + '_scaled_loss'][0])) / abs(float(ref[key + '_scaled_loss'][0])), 1e-3,
+          value=total, ref=float(ref[key + '_scaled_loss'][0]))
+    for k in ('contrast_loss', 'supervised_loss', 'total_loss', 'weight_decay'):
+        entry(k + '_rel', abs(got[k] - want[k]) / max(abs(want[k]), 1e-30), 1e-3 if k != 'weight_decay' else 2e-6, value=got[k], ref=want[k])
+    # argmax metrics: exact on the well-conditioned cases; on the small wiring cases one near-tie may fall the other way in fp32
+    entry('contrast_acc_abs', abs(got['contrast_acc'] - want['contrast_acc']), 1e-6 if fixed else 1.0 / n + 1e-6)
+    entry('supervised_acc_abs', abs(got['supervised_acc'] - want['supervised_acc']), 1e-6 if fixed else 0.5 / n + 1e-6)
+    entry('contrast_entropy_abs', abs(got['contrast_entropy'] - want['contrast_entropy']), 1e-3)
+    if fixed:      # the embeddings the contrastive loss was computed from = l2-normalised `proj` of the training forward
+        z = out['con_loss'].normalized.double().cpu().numpy()
+        entry('embeddings_abs', np.abs(z - _l2n(ref[tag + '_proj'])).max(), 1e-5)
+    applied = sorted(v.name[len('model/'):] for v in model._flat_order)
+    entry('applied_variable_names', 0.0 if applied == list(ref[key + '_applied_names']) else 1.0, 0.0)
+    FLAGS.reset(); RT.reset()
+    return res

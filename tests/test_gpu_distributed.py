@@ -99,6 +99,24 @@ def _worker(rank, world, port, q, backend='gloo'):
         res['bn_moving_worst_rel'] = max(
             float((v.value.double().cpu() - ns64[v.name]).abs().max()) / (float(ns64[v.name].abs().max()) + 1e-30)
             for v in model.variables if v.name in ns64)
+        # the same two replicas against the REFERENCE's own two-replica step (tf2/run.py:557-622 compiled from its source and run on two
+        # emulated replicas, tests/golden/reference_pin.npz): replica r's scaled loss = (con_r + sup_r + weight_decay) / R
+        if world == 2 and os.environ.get('SIMCLR_PEER_STATS') != '1':
+            from tests import gpu_checks as gc
+            mg, ref = gc.reference_pin()
+            pin = {}
+            for tag in ('r18_cifar', 'r18_img'):
+                mm = next(c for c in mg.MODELS if c['tag'] == tag)
+                imgs, labs = mg._model_inputs(mm)
+                per = mm['batch'] // world
+                pm = gc.pinned_product_model(mm, 'f32', 'exact', weight_decay=1e-4, strategy=strategy)
+                pstep = make_single_step(pm, model_lib.build_optimizer(0.1), strategy)
+                psl = slice(rank * per, (rank + 1) * per)
+                po = pstep(torch.from_numpy(imgs[psl]).float().cuda(), {'labels': torch.from_numpy(labs[psl]).float().cuda()})
+                torch.cuda.synchronize()
+                want = float(ref['step_%s_R2_scaled_loss' % tag][rank])
+                pin[tag] = abs(float(po['total_loss'].reshape(-1)[0]) / world - want) / abs(want)
+            res['pin_scaled_loss_rel'] = pin
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, 'ok', res))
@@ -138,21 +156,36 @@ def _run_inner(world, backend):
         # projection blocks batch (shortcut BN, bn1) forward and (tail BN, shortcut BN) backward into one exchange each
         assert m['hidden_collectives'] == 2, m
         assert m['stat_collectives'] <= 2 * 24 - 8, m
+        # replica r's scaled loss of the reference's own two-replica step (north_star: 1e-3 relative)
+        for tag, e in m.get('pin_scaled_loss_rel', {}).items():
+            assert e < 1e-3, (tag, m)
     return [m for _, _, m in sorted(res)]
 
 
+_GLOO2 = {}       # the plain two-replica run is shared by the two tests that need it (each run spawns two processes + two oracle steps)
+
+
+def _gloo2():
+    if 'res' not in _GLOO2:
+        _GLOO2['res'] = _run(2, 'gloo', env={'SIMCLR_PEER_STATS': '0'})
+    return _GLOO2['res']
+
+
 def test_two_replica_step_equals_global_batch_oracle():
-    _run(2, 'gloo')
+    res = _gloo2()
+    assert all('pin_scaled_loss_rel' in m and len(m['pin_scaled_loss_rel']) == 2 for m in res), res
 
 
-def _peer_worker(rank, world, port, q):
+def _peer_worker(rank, world, port, q, soak):
     try:
+        import time
+        import numpy as np
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         torch.cuda.set_device(0)
         dist.init_process_group('gloo', rank=rank, world_size=world)
         from simclr_amd import comm
-        ps = comm.PeerStats(None, rank, world, torch.device('cuda', 0), max_doubles=4096)
+        ps = comm.PeerStats(None, rank, world, torch.device('cuda', 0), max_doubles=4096)      # set-up includes the self-test
         g = torch.Generator().manual_seed(100 + rank)
         worst = 0.0
         for it in range(40):
@@ -168,10 +201,32 @@ def _peer_worker(rank, world, port, q):
                 ref = ref + b
             torch.cuda.synchronize()
             worst = max(worst, float((mine.cpu() - ref).abs().max()))
+        # soak: `soak` back-to-back exchanges of random sizes with NO host synchronisation in between, one rank
+        # falling behind at random (sleeps of 1 ... 50 ms and one of 1 s): payload rank r, exchange k, index i = (r + 1)(k + 1) + i / 2
+        # (exact in fp64), so every rank knows the sum in closed form; the error is accumulated on the device
+        sizes = np.random.default_rng(7).integers(1, 4097, soak)            # the same sequence on every rank
+        naps = np.random.default_rng(8 + rank)
+        tri = world * (world + 1) // 2
+        idx = torch.arange(4096, dtype=torch.float64, device='cuda') * 0.5
+        err = torch.zeros((), dtype=torch.float64, device='cuda')
+        t0 = time.time()
+        for k in range(soak):
+            n = int(sizes[k])
+            x = idx[:n] + float((rank + 1) * (k + 1))
+            ps.all_reduce_sum(x)
+            err = torch.maximum(err, (x - (world * idx[:n] + float(tri * (k + 1)))).abs().max())
+            if rank == world - 1 and (k % 499 == 17 or k == 1234):
+                torch.cuda.synchronize()
+                time.sleep(1.0 if k == 1234 else float(naps.integers(1, 51)) * 1e-3)
+            if k % 200 == 0:
+                ps.check_health()
+        ps.check_health(wait=True)
+        soak_err = float(err.item())
         missing = int(ps.status.item())
         dist.barrier()
+        ps.close()
         dist.destroy_process_group()
-        q.put((rank, 'ok', dict(worst=worst, missing=missing, exchanges=ps.exchanges)))
+        q.put((rank, 'ok', dict(worst=worst, missing=missing, exchanges=ps.exchanges, soak_err=soak_err, soak_s=time.time() - t0)))
     except Exception:  # noqa
         import traceback
         q.put((rank, 'FAIL', traceback.format_exc()))
@@ -179,26 +234,28 @@ def _peer_worker(rank, world, port, q):
 
 @pytest.mark.parametrize('world', [2, 4])
 def test_peer_mapped_stats_exchange(world):
-    """csrc/comm.hip: `world` processes on ONE GPU map each other's mailboxes through hipIpc; 40 exchanges of 1 ... 4096
-    fp64 values each must equal the rank-ordered sum bit for bit, no peer may time out."""
+    """csrc/comm.hip: `world` processes on ONE GPU map each other's mailboxes through hipIpc; 40 exchanges of 1 ... 4096 fp64 values
+    checked against the rank-ordered sum bit for bit, then a 10 000-exchange soak (random sizes, one rank delayed at random): every
+    sum exact, no peer may time out, the sticky health word stays 0."""
+    soak = 10000
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q, soak)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == 'ok' for r in res), res
     for _, _, m in res:
-        assert m['worst'] == 0.0 and m['missing'] == 0 and m['exchanges'] == 40, m
+        assert m['worst'] == 0.0 and m['soak_err'] == 0.0 and m['missing'] == 0 and m['exchanges'] == 40 + soak, m
 
 
 def test_two_replica_step_with_peer_mapped_statistics():
     """The two-replica training step with collective C on the peer-mapped exchange (SIMCLR_PEER_STATS=1): the same gates
     against the float64 oracle, every statistic all-reduce taken by the new path, and weights bit-identical to the gloo run."""
-    a = _run(2, 'gloo')
+    a = _gloo2()
     b = _run(2, 'gloo', env={'SIMCLR_PEER_STATS': '1'})
     for ma, mb in zip(a, b):
         assert ma['peer_exchanges'] == 0 and mb['peer_exchanges'] >= mb['stat_collectives'] - 2 and mb['peer_missing'] == 0, (ma, mb)
