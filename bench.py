@@ -48,9 +48,6 @@ import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
-# parity_mode vs the float64 oracle; filled in from the GPU measurement of the round (profiles/r04_notes.md)
-PARITY_NOTE_SPLIT = ('north_star met: loss 9.9e-8 rel, embeddings 1.8e-6 abs, every fp32 gate as the exact mode '
-                     '(profiles/r04_step_modes_f32_matmul.json; three terms alone miss the embedding tolerance: 1.5e-5)')
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 FLOP_PER_IMAGE = 49.15e9    # 2 views x (fwd+dgrad+wgrad), encoder + head
 # (depth, width, SK) -> FLOP per image at 224 px (SURVEY 8(d) / BASELINE.md section 3: cfg2/3, cfg4, cfg5)
@@ -58,19 +55,21 @@ FLOP_PER_IMAGE_BY_MODEL = {(50, 1, False): 49.15e9, (50, 2, True): 296.6e9, (152
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _timed_steps(fn, budget_s, max_steps):
-    fn()                                             # warm-up (allocator, MKL / oneDNN primitives)
+def _timed_steps(fn, budget_s, max_steps, warm=1, min_steps=1):
+    for _ in range(warm):                            # warm-up (allocator, MKL / oneDNN primitives)
+        fn()
     n, t0 = 0, time.time()
     while True:
         fn()
         n += 1
-        if time.time() - t0 > budget_s or n >= max_steps:
+        if n >= min_steps and (time.time() - t0 > budget_s or n >= max_steps):
             break
     return n, time.time() - t0
 
 
 def cpu_baseline():
-    """CPU oracle timings on the host cores: about 25 s in total."""
+    """CPU oracle timings on the host cores (>= 3 warm-up + >= 10 timed steps of configs[0]): about 30 s.
+    SIMCLR_CPU_THREADS overrides the thread count (the 16 below is the measured optimum on the GPU host: profiles/r05_cpu_threads.json)."""
     from collections import OrderedDict
     import numpy as np
     from oracle import lars as olars
@@ -80,22 +79,22 @@ def cpu_baseline():
     # 16 threads: on the 128-core GPU host the small CIFAR-sized convolutions run SLOWER with all cores (14.6 images/s
     # at 128 threads vs the 8-core build container's 20.4) -- thread oversubscription, not a property of the algorithm
     prev = torch.get_num_threads()
-    cores = min(16, os.cpu_count() or 1)
+    cores = min(int(os.environ.get('SIMCLR_CPU_THREADS', '16')), os.cpu_count() or 1)
     torch.set_num_threads(cores)
 
-    def model_step(depth, size, b, classes, budget, max_steps):
+    def model_step(depth, size, b, classes, budget, max_steps, warm=1, min_steps=1):
         cfg = Config(resnet_depth=depth, image_size=size, num_classes=classes)
         params, state = init_model(cfg, seed=2)
         momenta = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
         images = torch.rand(b, size, size, 6)
         labels = torch.nn.functional.one_hot(torch.randint(0, classes, (b,)), classes).float()
-        n, dt = _timed_steps(lambda: train_step(cfg, params, state, momenta, images, labels, 0.1), budget, max_steps)
+        n, dt = _timed_steps(lambda: train_step(cfg, params, state, momenta, images, labels, 0.1), budget, max_steps, warm, min_steps)
         return b * n / dt, n, dt
 
-    v1, n1, t1 = model_step(18, 32, 256, 10, 9.0, 6)            # BASELINE configs[0]
+    v1, n1, t1 = model_step(18, 32, 256, 10, 20.0, 10, warm=3, min_steps=10)     # BASELINE configs[0]: 3 warm-up + 10 timed steps
     v2, n2, t2 = model_step(50, 224, 8, 1000, 6.0, 2)           # the benchmarked architecture, small batch
-    out = dict(value=round(v1, 2), unit='images/s', cores=cores, kind='port',
-               sample='%d full train steps of BASELINE configs[0]: ResNet-18, CIFAR 32x32, batch 256, 1 replica, fp32 '
+    out = dict(value=round(v1, 2), unit='images/s', cores=cores, kind='port', steps=n1, warmup=3,
+               sample='3 warm-up + %d timed full train steps of BASELINE configs[0]: ResNet-18, CIFAR 32x32, batch 256, 1 replica, fp32 '
                       '(torch-CPU restatement of tf2/run.py:557-622; TensorFlow is not installed), %.1f s' % (n1, t1),
                resnet50_224=dict(value=round(v2, 3), unit='images/s', batch=8,
                                  sample='%d steps of the ResNet-50 1x @224 step at batch 8, %.1f s' % (n2, t2)))
@@ -202,7 +201,7 @@ def build_step(args, dtype, strategy, world, rank, dev, f32_matmul=None):
     return step_fn, data, global_batch, model
 
 
-def sample_pmc_traffic(family):
+def sample_pmc_traffic(family, extra_args=()):
     """HBM bytes per step of the dominant kernel family, measured in THIS run: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, never combined with trace domains: the rule of
     MI355X_MICROARCH.md), two steps each, parsed like tools/pmc_traffic.py (KB counters x 1024, FETCH x 2 for the 16 B/lane
@@ -224,7 +223,7 @@ def sample_pmc_traffic(family):
                 out = os.path.join(td, ctr)
                 cmd = ['rocprofv3', '--pmc', ctr, '--output-format', 'csv', '-d', out, '-o', 'p', '--', sys.executable,
                        os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no_cpu_baseline', '--no_kernel_events',
-                       '--no_f32', '--no_pmc']
+                       '--no_f32', '--no_pmc', '--no_parity'] + list(extra_args)
                 subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
                 acc = defaultdict(float)
                 files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
@@ -247,6 +246,95 @@ def sample_pmc_traffic(family):
     by = lambda ns: sum(2.0 * tot['FETCH_SIZE'].get(n, 0.0) + tot['WRITE_SIZE'].get(n, 0.0) for n in ns) / steps
     return dict(family_bytes_per_step=by(fam), kernel_dispatches_per_step=sum(calls[n] for n in fam) / steps,
                 step_total_bytes=by([n for n in names if n not in side]))
+
+
+def measured_parity(dev, modes):
+    """The `parity` object, MEASURED IN THIS RUN: one product training step (simclr_amd.run.make_single_step) per mode on the two
+    well-conditioned reference-source fixtures (tests/golden/reference_pin.npz `r18_img` / `r50_img`: /root/reference/tf2's own
+    model.py / run.py executed on oracle/tfshim.py) -- variables and images re-derived here from tests/golden/recipe.py (pure numpy,
+    by variable NAME; no oracle import), compared with the reference's contrastive loss, total loss and l2-normalised embeddings.
+    north_star: loss <= 1e-3 relative, normalised embeddings <= 1e-5 absolute."""
+    import numpy as np
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    from simclr_amd.run import make_single_step
+    gdir = os.path.join(HERE, 'tests', 'golden')
+    if gdir not in sys.path:
+        sys.path.insert(0, gdir)
+    import recipe
+    ref = np.load(os.path.join(gdir, 'reference_pin.npz'))
+    names = ['contrast_loss', 'contrast_acc', 'contrast_entropy', 'supervised_loss', 'supervised_acc', 'weight_decay', 'total_loss']
+    out = dict(measured_in_run=True, north_star=dict(loss_rel=1e-3, emb_abs=1e-5),
+               fixtures="tests/golden/reference_pin.npz: outputs of the reference's own tf2/model.py + tf2/run.py:557-622 executed on a float64 "
+                        "numpy stand-in for TensorFlow (TensorFlow's kernels themselves unpinned)", modes={})
+    for label, dtype, matmul in modes:
+        worst = dict(loss_rel=0.0, total_loss_rel=0.0, emb_abs=0.0)
+        cases = {}
+        for tag, c in sorted(recipe.IMG_CASES.items()):
+            FLAGS.reset()
+            FLAGS.update(use_blur=False, resnet_depth=c['depth'], image_size=c['size'], compute_dtype=dtype, f32_matmul=matmul,
+                         train_batch_size=c['batch'], weight_decay=1e-4)
+            RT.reset()
+            RT.device = dev
+            model = model_lib.Model(c['classes'])
+            with torch.no_grad():
+                model(torch.zeros(2, c['size'], c['size'], 6, device=dev), training=False)       # builds the variables
+            for v in model.variables:
+                val = recipe.variable_value(v.name[len('model/'):], v.value.double().cpu().numpy(), c['perturb'])
+                v.value.copy_(torch.from_numpy(val).to(torch.float32).to(dev))
+            RT.weights_version += 1
+            step = make_single_step(model, model_lib.build_optimizer(0.1), None)
+            images = torch.from_numpy(recipe.structured_images(c['batch'], c['size'], 2, c['seed'])).float().to(dev)
+            labels = torch.from_numpy(recipe.one_hot_labels(c['batch'], c['classes'], c['seed'])).float().to(dev)
+            o = step(images, {'labels': labels})
+            torch.cuda.synchronize()
+            want = dict(zip(names, ref['step_%s_R1_metrics' % tag]))
+            proj = ref[tag + '_proj']
+            zr = proj / np.sqrt(np.maximum((proj * proj).sum(1, keepdims=True), 1e-12))
+            z = o['con_loss'].normalized.double().cpu().numpy()
+            con = float(o['con_loss'].value.reshape(-1)[0])
+            tot = float(o['total_loss'].reshape(-1)[0])
+            e = dict(loss_rel=abs(con - want['contrast_loss']) / abs(want['contrast_loss']),
+                     total_loss_rel=abs(tot - want['total_loss']) / abs(want['total_loss']),
+                     emb_abs=float(np.abs(z - zr).max()))
+            cases[tag] = {k: float('%.3e' % v) for k, v in e.items()}
+            for k in worst:
+                worst[k] = max(worst[k], e[k])
+            del model, step, o
+        out['modes'][label] = dict(dtype=dtype, f32_matmul=matmul if dtype == 'f32' else None,
+                                   loss_rel=float('%.3e' % worst['loss_rel']), total_loss_rel=float('%.3e' % worst['total_loss_rel']),
+                                   emb_abs=float('%.3e' % worst['emb_abs']),
+                                   north_star_met=bool(worst['loss_rel'] <= 1e-3 and worst['total_loss_rel'] <= 1e-3 and worst['emb_abs'] <= 1e-5),
+                                   cases=cases)
+    FLAGS.reset()
+    RT.reset()
+    return out
+
+
+def ntxent_loop_us(n, dev, iters=50):
+    """The whole NT-Xent path of one step -- l2norm, forward (sweep + two finalize kernels), backward (two sweeps in one launch + combine),
+    l2norm backward: SEVEN kernels -- as `iters` back-to-back repetitions between two HIP events (launch gaps included)."""
+    from simclr_amd import ops
+    h = torch.randn(2 * n, 128, device=dev)
+    ws = None
+
+    def once():
+        nonlocal ws
+        z, inv = ops.l2norm_fwd(h)
+        out, rs, ws = ops.ntxent_fwd(z, z, 0, 0.1, ws)
+        dl, da = ops.ntxent_bwd(z, z, 0, 0.1, rs, 1.0, out, ws)
+        ops.l2norm_bwd(z, inv, dl)
+    for _ in range(5):
+        once()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        once()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
 
 
 def collective_bench(strategy, n, dev, flat_numel):
@@ -304,6 +392,7 @@ def main():
     ap.add_argument('--no_kernel_events', action='store_true', help='skip the instrumented steps (rocprof runs)')
     ap.add_argument('--no_f32', action='store_true', help='skip the fp32 parity-mode measurement')
     ap.add_argument('--no_pmc', action='store_true', help='do not sample HBM traffic (two rocprofv3 --pmc child runs of this script)')
+    ap.add_argument('--no_parity', action='store_true', help='skip the in-run parity measurement against the reference-source fixtures')
     ap.add_argument('--prof_steps', type=int, default=3)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo: the ranks talk over gloo and share cuda:0 when the box has fewer GPUs than ranks (exercises '
@@ -374,7 +463,14 @@ def main():
     coll = None
     if strategy is not None:
         coll = collective_bench(strategy, args.per_gpu_batch, dev, int(model._flat_grads.numel()))
-        coll.update(coll_counts, backend=dist.get_backend())
+        # proof that N ranks took part: an all-reduce of ones over the collective library, and the set of devices the ranks sit on
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        devs = [None] * world
+        dist.all_gather_object(devs, '%s:%d' % (socket.gethostname(), torch.cuda.current_device()))
+        coll.update(coll_counts, backend=dist.get_backend(), rccl_ranks_seen=int(ones.item()), rank_devices=devs,
+                    stat_transport='peer-mapped mailboxes (csrc/comm.hip)' if getattr(strategy, 'peer_stats', None) is not None
+                    else 'collective library', stat_transport_fallback=getattr(strategy, 'peer_stats_fallback', None))
     if rank != 0:
         return
 
@@ -436,13 +532,21 @@ def main():
             except Exception:
                 pass
         if 'ntxent_fwd' in summ and 'ntxent_bwd' in summ:
-            ms = (summ['ntxent_fwd']['ms'] + summ['ntxent_bwd']['ms']) / P
+            # every kernel of the NT-Xent path: the two library calls (3 + 2 kernels) AND the two l2norm kernels around them
+            parts = ['ntxent_fwd', 'ntxent_bwd', 'l2norm_fwd', 'l2norm_bwd']
+            ms = sum(summ[k]['ms'] for k in parts if k in summ) / P
             nfl = (summ['ntxent_fwd']['flops'] + summ['ntxent_bwd']['flops']) / P
             nby = summ['ntxent_bwd']['bytes'] / P          # fused fwd+bwd I/O: 2*(2n+2N)*D*4
-            ntx = dict(us=round(ms * 1e3, 1), alg_gbps=round(nby / (ms * 1e-3) / 1e9, 2),
-                       tflops=round(nfl / (ms * 1e-3) / 1e12, 2),
-                       frac_f32_mfma=round(nfl / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4),
-                       launches=(summ['ntxent_fwd']['launches'] + summ['ntxent_bwd']['launches']) // P,
+            loop_us = ntxent_loop_us(args.per_gpu_batch, dev) if world == 1 else None
+            t_us = loop_us if loop_us else ms * 1e3
+            ntx = dict(us=round(t_us, 1), us_events_in_step=round(ms * 1e3, 1),
+                       us_by_call={k: round(summ[k]['ms'] / P * 1e3, 1) for k in parts if k in summ},
+                       kernels=7, library_calls=sum(summ[k]['launches'] for k in parts if k in summ) // P,
+                       kernel_list='l2norm_fwd, ntxent_fwd_partial, ntxent_finalize_rows, ntxent_reduce_out, ntxent_bwd_sweeps, ntxent_combine_all, l2norm_bwd',
+                       alg_gbps=round(nby / (t_us * 1e-6) / 1e9, 2), tflops=round(nfl / (t_us * 1e-6) / 1e12, 2),
+                       frac_f32_mfma=round(nfl / (t_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS, 4),
+                       timing='`us` = 50 back-to-back repetitions of the seven kernels between two HIP events (launch gaps included); '
+                              '`us_events_in_step` = per-call HIP events inside the instrumented training steps',
                        note='bound by the fp32-input matrix pipe, not HBM (AI 384-683 FLOP/B); HBM floor 1.5 us')
 
     f32_mode = parity_mode = None
@@ -454,7 +558,7 @@ def main():
         del step_fn, data, model
         import gc
 
-        def f32_run(matmul):
+        def f32_run(matmul, profile=False):
             gc.collect()
             torch.cuda.empty_cache()
             s32, d32, _, m32 = build_step(args, 'f32', None, 1, 0, dev, f32_matmul=matmul)
@@ -471,17 +575,95 @@ def main():
             out = dict(value=round(global_batch * k32 / e32, 2), unit='images/s', ms_per_step=round(e32 / k32 * 1e3, 2),
                        steps=k32, warmup=w32, dtype='f32', f32_matmul=matmul,
                        bn_statistics='pivoted' if _o.bn_pivot_enabled(torch.float32) else 'raw moments')
+            if profile and not args.no_kernel_events and args.prof_steps > 0:
+                out.update(split_mode_roofline(s32, d32, _o, matmul))
             del s32, d32, m32
             gc.collect()
             torch.cuda.empty_cache()
             return out
+
+        def split_mode_roofline(s32, d32, _o, matmul):
+            """roofline of the fp32-storage / split-bf16 mode: per-launch HIP events of `prof_steps` instrumented steps.  Bytes: SURVEY
+            8(d)'s minimum at 4 B / element.  Matrix work: every fp32 product runs as `terms` bf16 MFMAs (6 forward, 3 backward), so
+            the MFMA roof of a family is 2.5 PFLOP/s / terms; the binding roof of the family is whichever limit costs more time."""
+            terms = dict(zip(('fwd', 'bwd'), _o.F32_MATMUL_TERMS[matmul]))
+            prof32 = _o.KernelProfiler()
+            _o.PROFILER = prof32
+            for _ in range(args.prof_steps):
+                f, l = next(d32); s32(f, l)
+            torch.cuda.synchronize()
+            _o.PROFILER = None
+            sm = prof32.summary()
+            P = args.prof_steps
+            fam_terms = {'conv_igemm_fwd': terms['fwd'] or 16, 'conv_igemm_dgrad': terms['bwd'] or 16, 'conv_wgrad': terms['bwd'] or 16}
+            fams = {}
+            for k, t in fam_terms.items():
+                if k not in sm or sm[k]['ms'] <= 0:
+                    continue
+                d = sm[k]
+                sec = d['ms'] * 1e-3
+                t_mfma = d['flops'] * t / (PEAK_BF16_TFLOPS * 1e12)          # seconds at the dense bf16 MFMA peak
+                t_hbm = d['bytes'] / (PEAK_HBM_GBPS * 1e9)                   # seconds at the HBM peak
+                fams[k] = dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3), bf16_terms=t,
+                               bound='mfma' if t_mfma >= t_hbm else 'hbm', frac=round(max(t_mfma, t_hbm) / sec, 4),
+                               mfma_frac=round(t_mfma / sec, 4), hbm_frac=round(t_hbm / sec, 4),
+                               fp32_product_tflops=round(d['flops'] / sec / 1e12, 2), bf16_mfma_tflops=round(d['flops'] * t / sec / 1e12, 2),
+                               alg_gbps=round(d['bytes'] / sec / 1e9, 1), algorithmic_bytes_per_launch=round(d['bytes'] / max(d['launches'], 1)))
+            # dominant family by time: the forward and data-gradient launches are ONE kernel template (conv_igemm_persistent)
+            ig = [k for k in ('conv_igemm_fwd', 'conv_igemm_dgrad') if k in fams]
+            ig_ms = sum(sm[k]['ms'] for k in ig)
+            wg_ms = sm['conv_wgrad']['ms'] if 'conv_wgrad' in fams else -1.0
+            members = ig if ig_ms >= wg_ms else ['conv_wgrad']
+            name = 'conv_igemm' if ig_ms >= wg_ms else 'conv_wgrad'
+            sec = sum(sm[k]['ms'] for k in members) * 1e-3
+            fl = sum(sm[k]['flops'] for k in members)
+            by = sum(sm[k]['bytes'] for k in members)
+            nl = sum(sm[k]['launches'] for k in members)
+            t_mfma = sum(sm[k]['flops'] * fam_terms[k] for k in members) / (PEAK_BF16_TFLOPS * 1e12)
+            t_hbm = by / (PEAK_HBM_GBPS * 1e9)
+            hbm = t_hbm > t_mfma
+            r = dict(bound='hbm' if hbm else 'mfma', kernel=name,
+                     achieved=round(by / sec / 1e9, 1) if hbm else round(t_mfma * PEAK_BF16_TFLOPS / sec, 2),
+                     peak=PEAK_HBM_GBPS if hbm else PEAK_BF16_TFLOPS, unit='GB/s' if hbm else 'TFLOP/s (bf16 MFMA work: fp32 products x terms)',
+                     frac=round(max(t_mfma, t_hbm) / sec, 4), mfma_frac=round(t_mfma / sec, 4), hbm_frac=round(t_hbm / sec, 4),
+                     traffic=None, traffic_measured_in_run=False,
+                     bytes_rule='SURVEY 8(d) minimum at 4 B / element: (input + output + weights) per launch, each read / written once',
+                     algorithmic_bytes_per_launch=round(by / max(nl, 1)), flops_per_launch_avg=fl / max(nl, 1),
+                     fp32_product_tflops=round(fl / sec / 1e12, 2), avg_launch_us=round(sec * 1e6 / max(nl, 1), 2),
+                     launches_per_step=nl // P, ms_per_step=round(sec * 1e3 / P, 3),
+                     measured_over='%d instrumented steps after the timed region of this mode' % P)
+            if default_cfg and not args.no_pmc:
+                sampled = sample_pmc_traffic(name, extra_args=('--dtype', 'f32', '--f32_matmul', matmul))
+                if sampled:
+                    per_launch = sampled['family_bytes_per_step'] / max(r['launches_per_step'], 1)
+                    r.update(traffic=round(per_launch), traffic_measured_in_run=True,
+                             traffic_source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this script in this mode (separate passes, FETCH x2)',
+                             traffic_kernel_dispatches_per_step=sampled['kernel_dispatches_per_step'],
+                             traffic_over_algorithmic=round(per_launch / r['algorithmic_bytes_per_launch'], 3),
+                             step_total_traffic_gb=round(sampled['step_total_bytes'] / 1e9, 2))
+            other = {k: dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3)) for k, d in sm.items() if k not in fams}
+            return dict(roofline=r, families=fams, other_kernels=other)
         f32_mode = f32_run('exact')
         f32_mode['step_mfma_frac'] = round(f32_mode['value'] * flop_img / (PEAK_F32_TFLOPS * 1e12), 4) if flop_img else None
-        parity_mode = f32_run('bf16x6_3')
+        parity_mode = f32_run('bf16x6_3', profile=True)
         # bf16 MFMA work of the split step: 6 terms on the forward third of the FLOPs, 3 on the two backward thirds
         parity_mode['step_bf16_mfma_frac'] = round(parity_mode['value'] * flop_img * 4.0 / (PEAK_BF16_TFLOPS * 1e12), 4) if flop_img else None
         from simclr_amd import ops as _ops
         _ops.set_f32_matmul('exact')
+
+    parity = None
+    if world == 1 and not args.no_parity:
+        try:
+            del step_fn, data, model
+        except NameError:
+            pass
+        modes = [('bf16 (value)', 'bf16', 'exact')] if args.dtype == 'bf16' else [(args.f32_matmul, 'f32', args.f32_matmul)]
+        if args.dtype == 'bf16' and not args.no_f32:
+            modes += [('f32_mode', 'f32', 'exact'), ('parity_mode', 'f32', 'bf16x6_3')]
+        try:
+            parity = measured_parity(dev, modes)
+        except Exception as e:      # a failed side measurement must be visible in the line, not kill it
+            parity = dict(measured_in_run=False, error=repr(e))
 
     augment = None
     if world == 1:
@@ -534,10 +716,8 @@ def main():
         'kernels': kernels,
         'f32_mode': f32_mode,
         'parity_mode': parity_mode,
-        # what each mode measures against the float64 oracle on a ResNet-50 / 224 px / batch-32 step (tests/gpu_checks.py
-        # check_train_step_fixed): north_star asks loss 1e-3 relative, normalised embeddings 1e-5
-        'parity': {'oracle': "pinned to the reference's source executed on a numpy stand-in for TensorFlow (tests/golden/reference_pin.npz); TensorFlow's kernels unpinned",
-                   'f32_mode': 'north_star met', 'parity_mode': PARITY_NOTE_SPLIT, 'bf16 (value)': 'loss 5e-4 / embeddings 1.1e-2: speed mode'},
+        # measured in this run: every mode's training step against the reference-source fixtures (measured_parity above)
+        'parity': parity,
         'allgather': coll,
         'augment': augment,
         'train_metrics': {k: round(v, 5) for k, v in metrics.items()},

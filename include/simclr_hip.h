@@ -76,7 +76,10 @@ int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long
  * resnet.py:196-208, model.py:148-153): number of bf16 terms per fp32 product, for the forward GEMM and for the two backward
  * GEMMs (dgrad, wgrad).  0 (default) = exact fp32 MFMA; 3 = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi (~2^-17 per product);
  * 6 = every term of weight >= 2^-18 of a three-way split (fp32 level).  Storage, accumulation, statistics and every
- * elementwise kernel stay fp32; bf16 launches are unaffected.  Process-wide, not stream-ordered: set it between steps.
+ * elementwise kernel stay fp32; bf16 launches are unaffected.  Process-wide, not stream-ordered: set it between steps
+ * (the one piece of process-global state in this ABI: two streams of one process cannot run different settings at once).
+ * The setting is a LOWER bound on accuracy: the non-persistent fallback kernel (debug switch SIMCLR_NO_PERSISTENT, or more than
+ * 64 N-tiles) always runs the exact fp32 MFMA whatever is selected here.
  * simclr_get_f32_matmul(0 | 1) returns the forward | backward setting. */
 int simclr_set_f32_matmul(int fwd_terms, int bwd_terms);
 int simclr_get_f32_matmul(int which);

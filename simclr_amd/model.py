@@ -267,7 +267,7 @@ class Model(Layer):
                              f'(got input shape {tuple(inputs.shape)})')
         if FLAGS.train_mode == 'finetune':
             raise NotImplementedError('train_mode=finetune is outside the pretraining hot path')
-        ops.set_f32_matmul(FLAGS.f32_matmul)      # evaluation passes do not go through ops.begin_step
+        ops.select_f32_matmul()      # evaluation passes do not go through ops.begin_step
         if FLAGS.use_blur and training and FLAGS.train_mode == 'pretrain':
             # batch_random_blur on the device (tf2/model.py:255-258), fused over the k views
             inputs = data_util.batch_random_blur_tensor(inputs, FLAGS.image_size, FLAGS.image_size)

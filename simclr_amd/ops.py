@@ -77,13 +77,14 @@ def l2norm_fwd(x):
     rows, D = x.shape
     z = torch.empty_like(x)
     inv = torch.empty(rows, device=x.device, dtype=torch.float32)
-    lib().l2norm_fwd(_p(x), _p(z), _p(inv), rows, D, _s())
+    _launch('l2norm_fwd', 3.0 * rows * D, 8.0 * rows * D, lambda: lib().l2norm_fwd(_p(x), _p(z), _p(inv), rows, D, _s()))
     return z, inv
 
 
 def l2norm_bwd(z, inv, dz):
     dx = torch.empty_like(z)
-    lib().l2norm_bwd(_p(z), _p(inv), _p(dz), _p(dx), z.shape[0], z.shape[1], _s())
+    _launch('l2norm_bwd', 5.0 * z.numel(), 12.0 * z.numel(),
+            lambda: lib().l2norm_bwd(_p(z), _p(inv), _p(dz), _p(dx), z.shape[0], z.shape[1], _s()))
     return dx
 
 
@@ -448,11 +449,28 @@ def set_f32_matmul(mode):
         L.set_f32_matmul(fwd, bwd)
 
 
+def select_f32_matmul():
+    """Apply FLAGS.f32_matmul -- for compute_dtype='f32' ONLY: with a bf16 encoder and head_dtype='f32' the fp32
+    projection / linear-eval heads exist to keep the loss gradient exact, so they always run the exact fp32-input MFMA."""
+    from .flags import FLAGS
+    set_f32_matmul(getattr(FLAGS, 'f32_matmul', 'exact') if getattr(FLAGS, 'compute_dtype', 'f32') == 'f32' else 'exact')
+
+
 def begin_step(device):
     """Zero the statistics arena and select the fp32 matrix arithmetic; call once at the start of every training step."""
-    from .flags import FLAGS
-    set_f32_matmul(getattr(FLAGS, 'f32_matmul', 'exact'))
+    select_f32_matmul()
     _ARENA.begin_step(device)
+
+
+def check_split_tail_health():
+    """Raise if a workgroup sharing a left-over tile of the persistent convolution grid ever timed out waiting for a partner
+    (simclr_conv2d_split_tail_timeouts: sticky device counters; synchronous -- call where the host synchronises anyway)."""
+    n = ctypes.c_uint(0)
+    lib().conv2d_split_tail_timeouts(ctypes.byref(n))
+    if n.value:
+        raise RuntimeError('%d split-tail partner(s) of the persistent convolution grid timed out: results of those tiles are wrong '
+                           '(SIMCLR_IGEMM_SPLIT=0 disables the split tail)' % n.value)
+    return 0
 
 
 def end_step():

@@ -362,6 +362,7 @@ def main(argv):
         step += 1
         if step % log_every == 0:
             torch.cuda.synchronize()
+            ops.check_split_tail_health()        # a split-tail partner that never arrived is an error, not a silent wrong tile
             dt = time.time() - t0
             t0 = time.time()
             if rank0:

@@ -291,6 +291,43 @@ def test_conv_split_tail_paths(V, H, Cin, Cout, k, s, bn_case, dtype, tile):
         os.environ.pop('SIMCLR_IGEMM_SPLIT', None)
         os.environ.pop('SIMCLR_IGEMM_WIDE', None)
     _assert(res)
+    torch.cuda.synchronize()
+    assert ops.check_split_tail_health() == 0          # no partner ever timed out (sticky device counter)
+
+
+def test_conv_split_tail_replays_in_a_hipgraph():
+    """the split tail carries no host-side sequence number any more (the consumer resets each flag inside the launch), so a
+    launch captured into a hipGraph must replay correctly: two replays on fresh inputs are bit-identical to the eager launches."""
+    from simclr_amd import ops
+    from simclr_amd._lib import lib
+    os.environ['SIMCLR_IGEMM_SPLIT'] = '1'
+    os.environ['SIMCLR_IGEMM_WIDE'] = '0'
+    try:
+        V, H, Cin, Cout = 24, 56, 1024, 128
+        xs = [torch.randn(V, H, H, Cin, device='cuda').to(BF) for _ in range(3)]
+        w_t = ops.prep_weights(torch.randn(1, 1, Cin, Cout, device='cuda') * 0.05, 0, BF)
+        eager = [ops.conv2d_fwd(x, w_t, 1, 1, 1, 0, H, H).clone() for x in xs]
+        assert lib().conv2d_last_split_parts() >= 2
+        side = torch.cuda.Stream()
+        x_static = xs[0].clone()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # the library's split scratch is per stream: create it before the capture
+            ops.conv2d_fwd(x_static, w_t, 1, 1, 1, 0, H, H)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            y_static = ops.conv2d_fwd(x_static, w_t, 1, 1, 1, 0, H, H)
+            parts = lib().conv2d_last_split_parts()
+        assert parts >= 2, 'the captured launch did not take the split tail'
+        for i in (1, 2, 0, 1):
+            x_static.copy_(xs[i])
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y_static, eager[i]), i
+        assert ops.check_split_tail_health() == 0
+    finally:
+        os.environ.pop('SIMCLR_IGEMM_SPLIT', None)
+        os.environ.pop('SIMCLR_IGEMM_WIDE', None)
 
 
 # BASELINE cfg2 (ResNet-50 1x, 224 px) layer classes at the row counts the benchmark runs: every persistent
