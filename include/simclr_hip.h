@@ -97,6 +97,12 @@ int simclr_conv2d_last_split_parts(void);
  * *host_total: 0 on a healthy device.  The flags are reset by the consumer inside the launch and carry no host-side sequence
  * number, so a launch captured into a hipGraph replays correctly (the scratch must exist before the capture starts). */
 int simclr_conv2d_split_tail_timeouts(unsigned* host_total);
+/* Which kernel instantiation the most recent forward / dgrad launch of this process selected: the template-argument list as
+ * spelled at the launch site plus element size, GEMM role, grid, block, LDS bytes, tile counts and split-tail parts.  With the
+ * environment variable SIMCLR_DRY_RUN=1 the convolution entry points take every launch decision and record it here WITHOUT
+ * touching the device (pointers are not dereferenced, nothing is allocated or launched): tools/instantiation_table.py dumps the
+ * (layer class -> instantiation) table of the benchmark models on a machine without a GPU. */
+const char* simclr_conv2d_last_instantiation(void);
 /* Three-term data gradient of the SIMCLR_DT_F32 launches (simclr_set_f32_matmul(*, 3)): the weight operand is rewritten once per
  * launch into (hi, lo) bf16 planes in a library-owned per-stream buffer (the second exception to "never allocates": the
  * largest weight matrix, >= 16 MB, hipMalloc'ed on first use), so the k-loop does no splitting work for it; bitwise the

@@ -28,6 +28,7 @@ void simclr_set_error(const char* fmt, ...);
 
 #define SIMCLR_CHECK_LAUNCH()                                        \
   do {                                                               \
+    { const char* d__ = getenv("SIMCLR_DRY_RUN"); if (d__ && d__[0] == '1') break; }  /* decisions only: no device (conv.hip) */ \
     hipError_t e__ = hipGetLastError();                              \
     if (e__ != hipSuccess) {                                         \
       simclr_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, \

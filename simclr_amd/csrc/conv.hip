@@ -2552,8 +2552,27 @@ __global__ void unpack_stem_dw(const float* __restrict__ src, float* __restrict_
 // fp32 matrix arithmetic of the forward and of the two backward GEMMs (process-wide, simclr_set_f32_matmul)
 static int g_f32_terms_fwd = 0, g_f32_terms_bwd = 0;
 
+// ---- which instantiation ran: ONE place that records every forward / dgrad launch decision ----------
+// SIMCLR_LAUNCH replaces hipLaunchKernelGGL inside launch_igemm_one: it writes the kernel's template-argument list (as spelled
+// at the launch site, with the element size and the GEMM role appended) plus grid / block / LDS into g_last_inst and launches --
+// unless SIMCLR_DRY_RUN=1, in which case NOTHING touches the device: tools/instantiation_table.py walks the layer classes of
+// the benchmark models on a machine without a GPU, dumps (layer class -> instantiation) to profiles/, and a CPU test asserts
+// that the table has not changed behind anybody's back.  simclr_conv2d_last_instantiation() returns the record.
+static char g_last_inst[512] = "";
+static bool dry_run() { const char* e = getenv("SIMCLR_DRY_RUN"); return e && e[0] == '1'; }
+template <typename T, int MODE> static void record_inst(const char* kern, unsigned grid, unsigned block, size_t lds, const ConvP& p) {
+  snprintf(g_last_inst, sizeof(g_last_inst), "%s elt=%d role=%s grid=%u block=%u lds=%zu m_tiles=%d n_tiles=%d tail_parts=%d", kern,
+           (int)sizeof(T), MODE == MODE_FWD ? "fwd" : "dgrad", grid, block, lds, p.m_tiles, p.n_tiles, p.rem_parts);
+}
+#define SIMCLR_LAUNCH(kern, grid, block, lds, stream, ...)                                   \
+  do {                                                                                       \
+    record_inst<T, MODE>(#kern, (grid).x, (block).x, (size_t)(lds), p);                      \
+    if (!dry_run()) hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);         \
+  } while (0)
+
 static const void* zero_page() {
   static void* zp = nullptr;
+  if (dry_run()) return (const void*)&g_last_inst;          // never dereferenced: nothing is launched in a dry run
   if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess) zp = nullptr;
   return zp;
 }
@@ -2675,6 +2694,10 @@ static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size
   // partial exchange would cost more than the idle round), or so many rounds that one more is noise
   if (R == 0 || full == 0 || P < 2 || full > 24) return true;
   const size_t slots = (size_t)R * p.n_tiles * (P - 1);
+  if (dry_run()) {                                  // decision only: nothing is allocated, nothing will be launched
+    p.rem_full = full; p.rem_tiles = R; p.rem_parts = P; g_last_split_parts = P;
+    return true;
+  }
   SplitScratch* sc = nullptr;
   for (int i = 0; i < g_split_scratch_n; ++i)
     if (g_split_scratch[i].stream == stream) sc = &g_split_scratch[i];
@@ -2747,6 +2770,7 @@ static int g_last_presplit = 0;          // simclr_conv2d_last_presplit (tests):
 static const void* presplit_weights(const void* w, long long rows, int K, hipStream_t stream) {
   const char* e = getenv("SIMCLR_F32_PRESPLIT");
   if ((e && atoi(e) == 0) || K % 32 != 0 || rows <= 0) return nullptr;
+  if (dry_run()) return w;                           // decision only
   PresplitScratch* sc = nullptr;
   for (int i = 0; i < g_presplit_n; ++i)
     if (g_presplit[i].stream == stream) sc = &g_presplit[i];
@@ -2821,8 +2845,8 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         const bool flatw = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.cs == 1 && p.IH == p.OH && p.IW == p.OW;
 #define LWD(STv, BEv)                                                                                                          \
         do {                                                                                                                   \
-          if (flatw) hipLaunchKernelGGL((conv_igemm_wide<MODE, STv, BEv, true>), dim3(pgw), dim3(512), ldsw, stream, p);       \
-          else hipLaunchKernelGGL((conv_igemm_wide<MODE, STv, BEv, false>), dim3(pgw), dim3(512), ldsw, stream, p);            \
+          if (flatw) SIMCLR_LAUNCH((conv_igemm_wide<MODE, STv, BEv, true>), dim3(pgw), dim3(512), ldsw, stream, p);       \
+          else SIMCLR_LAUNCH((conv_igemm_wide<MODE, STv, BEv, false>), dim3(pgw), dim3(512), ldsw, stream, p);            \
         } while (0)
         if (p.bn_mode) LWD(true, true);
         else if (st) LWD(true, false);
@@ -2841,8 +2865,8 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         if (p.fapply) { p.rem_parts = 0; g_last_split_parts = 0; }
 #define L2(STv, BEv, EXv, FAv)                                                                                                \
         do {                                                                                                                   \
-          if (p.rem_parts >= 2) { if constexpr (!(FAv)) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv, 0, true>), dim3(pg2), dim3(512), lds2, stream, p); } \
-          else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv>), dim3(pg2), dim3(512), lds2, stream, p); \
+          if (p.rem_parts >= 2) { if constexpr (!(FAv)) SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv, 0, true>), dim3(pg2), dim3(512), lds2, stream, p); } \
+          else SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE, 256, 256, 8, 2, STv, BEv, EXv, false, FAv>), dim3(pg2), dim3(512), lds2, stream, p); \
         } while (0)
         if (p.fapply) { if constexpr (MODE == MODE_FWD) L2(false, false, false, true); }
         else if (p.x2 && p.bn_mode) L2(true, true, true, false);
@@ -2885,18 +2909,18 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       const char* e = getenv("SIMCLR_BNEPI_SPECIAL");
       if (e && atoi(e) == 0) eps = 0;
     }
-#define LPE(BNv, EXv, EPSv) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, true, true, EXv, false, false, 0, false, false, 0, EPSv>), dim3(pg), dim3(256), plds, stream, p)
+#define LPE(BNv, EXv, EPSv) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, true, true, EXv, false, false, 0, false, false, 0, EPSv>), dim3(pg), dim3(256), plds, stream, p)
 #define LPX(BNv, STv, BEv, EXv)                                                                                              \
     do {                                                                                                                     \
       if constexpr (sizeof(T) == 4) {                                                                                        \
-        if (psb) { if constexpr (MODE == MODE_DGRAD) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3, false, true>), dim3(pg), dim3(256), plds, stream, p); } \
-        else if (p.split == 3) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3>), dim3(pg), dim3(256), plds, stream, p); \
-        else if (p.split == 6) hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 6>), dim3(pg), dim3(256), plds, stream, p); \
-        else hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
+        if (psb) { if constexpr (MODE == MODE_DGRAD) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3, false, true>), dim3(pg), dim3(256), plds, stream, p); } \
+        else if (p.split == 3) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3>), dim3(pg), dim3(256), plds, stream, p); \
+        else if (p.split == 6) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 6>), dim3(pg), dim3(256), plds, stream, p); \
+        else SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
       } else if ((BNv) == 128 && p.rem_parts >= 2) {                                                                         \
-        hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, STv, BEv, EXv, false, false, 0, true>), dim3(pg), dim3(256), plds, stream, p); \
+        SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, 128, 4, 2, STv, BEv, EXv, false, false, 0, true>), dim3(pg), dim3(256), plds, stream, p); \
       } else {                                                                                                               \
-        hipLaunchKernelGGL((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
+        SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
       }                                                                                                                      \
     } while (0)
 #define LP(BNv, STv, BEv) LPX(BNv, STv, BEv, false)
@@ -2908,9 +2932,9 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       { const char* e = getenv("SIMCLR_FAPPLY_SPECIAL"); if (e && atoi(e) == 0) fas = 0; }
 #define LF(BNv)                                                                                                                \
       do {                                                                                                                     \
-        if (fas == 1) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 0, false, false, 1>), dim3(pg), dim3(256), plds, stream, p); \
-        else if (fas == 2) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 0, false, false, 2>), dim3(pg), dim3(256), plds, stream, p); \
-        else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p); \
+        if (fas == 1) SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 0, false, false, 1>), dim3(pg), dim3(256), plds, stream, p); \
+        else if (fas == 2) SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 0, false, false, 2>), dim3(pg), dim3(256), plds, stream, p); \
+        else SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p); \
       } while (0)
       if (BN == 64) LF(64); else LF(128);
 #undef LF
@@ -2924,12 +2948,12 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       const size_t wlds = (size_t)p.win_bytes + 2 * BN * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long) + 128;
 #define LW(BNv, STv, BEv)                                                                                                     \
       do {                                                                                                                     \
-        if ((BNv) == 128 && p.rem_parts >= 2) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, STv, BEv, false, true, false, 0, true>), dim3(pg), dim3(256), wlds, stream, p); \
-        else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, BNv, 4, 2, STv, BEv, false, true>), dim3(pg), dim3(256), wlds, stream, p); \
+        if ((BNv) == 128 && p.rem_parts >= 2) SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, STv, BEv, false, true, false, 0, true>), dim3(pg), dim3(256), wlds, stream, p); \
+        else SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE, 128, BNv, 4, 2, STv, BEv, false, true>), dim3(pg), dim3(256), wlds, stream, p); \
       } while (0)
       if (p.bn_mode && eps == 1 && p.rem_parts < 2) {
-        if (BN == 64) hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, 64, 4, 2, true, true, false, true, false, 0, false, false, 0, 1>), dim3(pg), dim3(256), wlds, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, true, true, false, true, false, 0, false, false, 0, 1>), dim3(pg), dim3(256), wlds, stream, p);
+        if (BN == 64) SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE, 128, 64, 4, 2, true, true, false, true, false, 0, false, false, 0, 1>), dim3(pg), dim3(256), wlds, stream, p);
+        else SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, true, true, false, true, false, 0, false, false, 0, 1>), dim3(pg), dim3(256), wlds, stream, p);
       }
       else if (p.bn_mode) { if (BN == 64) LW(64, true, true); else LW(128, true, true); }
       else if (BN == 64) { if (st) LW(64, true, false); else LW(64, false, false); }
@@ -2960,8 +2984,8 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   }
 #define L(BNv, STv)                                                                                    \
   do {                                                                                                 \
-    if (no_glds) hipLaunchKernelGGL((conv_igemm<T, MODE, BNv, STv, false>), dim3(grid), dim3(256), lds, stream, p); \
-    else hipLaunchKernelGGL((conv_igemm<T, MODE, BNv, STv, true>), dim3(grid), dim3(256), lds, stream, p);          \
+    if (no_glds) SIMCLR_LAUNCH((conv_igemm<T, MODE, BNv, STv, false>), dim3(grid), dim3(256), lds, stream, p); \
+    else SIMCLR_LAUNCH((conv_igemm<T, MODE, BNv, STv, true>), dim3(grid), dim3(256), lds, stream, p);          \
   } while (0)
   if (BN == 64) { if (st) L(64, true); else L(64, false); }
   else { if (st) L(128, true); else L(128, false); }
@@ -3035,6 +3059,7 @@ int simclr_get_f32_matmul(int which) { return which == 0 ? g_f32_terms_fwd : g_f
 // Test hook: into how many parts the most recent forward / dgrad launch of this process split each left-over tile
 // (0 = the launch ran whole tiles only).  See "split tail" above.
 int simclr_conv2d_last_split_parts(void) { return g_last_split_parts; }
+const char* simclr_conv2d_last_instantiation(void) { return g_last_inst; }
 int simclr_conv2d_split_tail_timeouts(unsigned* host_total) { return split_tail_timeouts(host_total); }
 // Test hook: 1 if the most recent fp32 data-gradient launch read pre-split weights (three split-bf16 terms, see presplit_weights).
 int simclr_conv2d_last_presplit(void) { return g_last_presplit; }
@@ -3105,10 +3130,11 @@ int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* st
   // the persistent fp32 kernel is the one that knows about the pivot (launch_igemm_one: n_tiles <= 64, no A/B switches)
   const bool persistent = Cout <= 64 * 64 && !getenv("SIMCLR_NO_GLDS") && !getenv("SIMCLR_NO_PERSISTENT");
   if (persistent) {
-    hipLaunchKernelGGL(conv_pivot_row, dim3(ceil_div(Cout, 4)), dim3(256), 0, stream, (const float*)x, (const float*)w_t, pivot,
-                       IH, IW, Cin, Cin, OH, OW, Cout, KH, KW, stride, pad);
+    if (!dry_run())
+      hipLaunchKernelGGL(conv_pivot_row, dim3(ceil_div(Cout, 4)), dim3(256), 0, stream, (const float*)x, (const float*)w_t, pivot,
+                         IH, IW, Cin, Cin, OH, OW, Cout, KH, KW, stride, pad);
     p.pivot = pivot;
-  } else {
+  } else if (!dry_run()) {
     if (hipMemsetAsync(pivot, 0, (size_t)Cout * sizeof(float), stream) != hipSuccess) { simclr_set_error("conv2d_fwd_pivoted: memset failed"); return 2; }
   }
   launch_igemm<float, MODE_FWD>(p, stream);

@@ -158,3 +158,20 @@ def test_class_id_cache_follows_the_label_tensor():
     lab[0] = torch.tensor([1.0, 0.0, 0.0])                     # in-place change bumps the version -> recomputed
     assert _class_ids(lab).tolist() == [0, 0, 1]
     assert _class_ids(torch.tensor([1, 2])).tolist() == [1, 2]
+
+
+def test_instantiation_table_matches_the_committed_one():
+    """which kernel instantiation every (ResNet-50 layer class, launch kind, storage mode) selects is ONE table,
+    produced without a GPU (SIMCLR_DRY_RUN=1: launch_igemm_one takes its decisions and records them instead of launching) and
+    committed under profiles/ -- a change of a selection rule shows up here as a diff of that file."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # a subprocess: the library caches a few environment switches at first use
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'instantiation_table.py')], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if not k.startswith('SIMCLR_')})
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = open(os.path.join(root, 'profiles', 'r05_instantiations.txt')).read()
+    assert r.stdout == want, 'the (layer class -> instantiation) table changed: regenerate profiles/r05_instantiations.txt with tools/instantiation_table.py and review the diff'
+    rows = [l for l in want.splitlines() if l and not l.startswith('#')]
+    assert len(rows) > 200 and any('conv_igemm_wide' in l for l in rows) and any('elt=4' in l and ', 6>' in l for l in rows)
