@@ -48,24 +48,27 @@ def _worker(rank, world, port, q, backend='gloo'):
         g = torch.Generator().manual_seed(5)
         images = torch.rand(world * b, image_size, image_size, 6, generator=g)          # global batch
         labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (world * b,), generator=g), num_classes).float()
-        FLAGS.reset()
-        FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='f32', use_blur=False,
-                     weight_decay=wd, train_batch_size=world * b)
-        RT.reset()
-        RT.device = torch.device('cuda', devno)
-        strategy = comm.Strategy()
-        RT.strategy = strategy
-        model = model_lib.Model(num_classes)
-        with torch.no_grad():
-            model(torch.zeros(2, image_size, image_size, 6, device='cuda'), training=False)
-        allv = dict(params); allv.update(state)
-        for v in model.variables:
-            v.value.copy_(allv[v.name].cuda())
-        RT.weights_version += 1
-        opt = model_lib.build_optimizer(lr)
-        step = make_single_step(model, opt, strategy)
-        sl = slice(rank * b, (rank + 1) * b)
-        out = step(images[sl].cuda(), {'labels': labels[sl].cuda()})
+        def run_step():
+            FLAGS.reset()
+            FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='f32', use_blur=False,
+                         weight_decay=wd, train_batch_size=world * b)
+            RT.reset()
+            RT.device = torch.device('cuda', devno)
+            strategy = comm.Strategy()
+            RT.strategy = strategy
+            model = model_lib.Model(num_classes)
+            with torch.no_grad():
+                model(torch.zeros(2, image_size, image_size, 6, device='cuda'), training=False)
+            allv = dict(params); allv.update(state)
+            for v in model.variables:
+                v.value.copy_(allv[v.name].cuda())
+            RT.weights_version += 1
+            opt = model_lib.build_optimizer(lr)
+            step = make_single_step(model, opt, strategy)
+            sl = slice(rank * b, (rank + 1) * b)
+            out = step(images[sl].cuda(), {'labels': labels[sl].cuda()})
+            return strategy, model, out
+        strategy, model, out = run_step()
         torch.cuda.synchronize()
         # oracle: ONE replica on the global batch, float64
         p64 = OrderedDict((k, v.double()) for k, v in params.items())
@@ -117,6 +120,23 @@ def _worker(rank, world, port, q, backend='gloo'):
                 want = float(ref['step_%s_R2_scaled_loss' % tag][rank])
                 pin[tag] = abs(float(po['total_loss'].reshape(-1)[0]) / world - want) / abs(want)
             res['pin_scaled_loss_rel'] = pin
+        if os.environ.get('SIMCLR_TEST_ALSO_PEER') == '1':
+            # the same step once more with collective C on the peer-mapped exchange (csrc/comm.hip), in the same processes (one spawn +
+            # one oracle step instead of two of each): counters and the bit-level fingerprint of the updated weights
+            os.environ['SIMCLR_PEER_STATS'] = '1'
+            try:
+                st2, model2, _ = run_step()
+                torch.cuda.synchronize()
+                st2.check_health(wait=True)
+                by2 = {v.name: v for v in model2._flat_order}
+                res['peer'] = dict(stat_collectives=st2.stat_collectives,
+                                   peer_exchanges=st2.peer_stats.exchanges if st2.peer_stats is not None else 0,
+                                   peer_missing=int(st2.peer_stats.status.item()) if st2.peer_stats is not None else -1,
+                                   fallback=st2.peer_stats_fallback,
+                                   checksum=[float(sum(float(by2[k].value.double().sum()) for k in np64)),
+                                             float(max(float(by2[k].value.double().abs().max()) for k in np64))])
+            finally:
+                os.environ['SIMCLR_PEER_STATS'] = '0'
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, 'ok', res))
@@ -167,7 +187,7 @@ _GLOO2 = {}       # the plain two-replica run is shared by the two tests that ne
 
 def _gloo2():
     if 'res' not in _GLOO2:
-        _GLOO2['res'] = _run(2, 'gloo', env={'SIMCLR_PEER_STATS': '0'})
+        _GLOO2['res'] = _run(2, 'gloo', env={'SIMCLR_PEER_STATS': '0', 'SIMCLR_TEST_ALSO_PEER': '1'})
     return _GLOO2['res']
 
 
@@ -253,13 +273,14 @@ def test_peer_mapped_stats_exchange(world):
 
 
 def test_two_replica_step_with_peer_mapped_statistics():
-    """The two-replica training step with collective C on the peer-mapped exchange (SIMCLR_PEER_STATS=1): the same gates
-    against the float64 oracle, every statistic all-reduce taken by the new path, and weights bit-identical to the gloo run."""
-    a = _gloo2()
-    b = _run(2, 'gloo', env={'SIMCLR_PEER_STATS': '1'})
-    for ma, mb in zip(a, b):
-        assert ma['peer_exchanges'] == 0 and mb['peer_exchanges'] >= mb['stat_collectives'] - 2 and mb['peer_missing'] == 0, (ma, mb)
-        assert ma['checksum'] == mb['checksum'], (ma['checksum'], mb['checksum'])
+    """The two-replica training step with collective C on the peer-mapped exchange (SIMCLR_PEER_STATS=1): every statistic all-reduce
+    taken by the new path, no peer ever missing, and the updated weights bit-identical to the gloo run (both runs happen in the worker
+    processes of test_two_replica_step_equals_global_batch_oracle: one spawn, one oracle step)."""
+    for m in _gloo2():
+        p = m['peer']
+        assert p['fallback'] is None, p
+        assert m['peer_exchanges'] == 0 and p['peer_exchanges'] >= p['stat_collectives'] - 2 and p['peer_missing'] == 0, (m, p)
+        assert m['checksum'] == p['checksum'], (m['checksum'], p['checksum'])
 
 
 def test_two_replica_step_over_rccl():

@@ -52,7 +52,10 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--what', default='conv,bn,ntxent,lars')
     ap.add_argument('--out', default='gpurun_out/microbench.json')
+    ap.add_argument('--f32_matmul', default='exact', help="--dtype f32: matrix arithmetic (ops.set_f32_matmul), e.g. bf16x6_3 = the parity mode")
     args = ap.parse_args()
+    if args.dtype != 'bf16':
+        ops.set_f32_matmul(args.f32_matmul)
     dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     dev = 'cuda'
     V = args.views

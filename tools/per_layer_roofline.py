@@ -14,6 +14,13 @@ V = 1024
 
 
 def main():
+    # optional: --elt 4 --terms 6,3,3 = fp32 storage with split-bf16 arithmetic (the parity mode): bytes at 4 B / element and the
+    # MFMA bound per pass at 2.5 PFLOP/s / terms (forward, dgrad, wgrad)
+    elt, terms = 2.0, (1, 1, 1)
+    if '--elt' in sys.argv:
+        elt = float(sys.argv[sys.argv.index('--elt') + 1])
+    if '--terms' in sys.argv:
+        terms = tuple(int(t) for t in sys.argv[sys.argv.index('--terms') + 1].split(','))
     rows = json.load(open(sys.argv[1]))
     print('| layer (x count) | GFLOP | alg. MB (fwd) | bound us (MFMA / HBM@8 / HBM@6.29) | fwd us (frac) | dgrad us (frac) | wgrad us (frac) |')
     print('|---|---|---|---|---|---|---|')
@@ -25,13 +32,14 @@ def main():
         H, ci, co, k, s, cnt = map(int, m.groups())
         OH = H // s
         in_px = H * H if (k == 3 or s == 1) else OH * OH          # a strided 1x1 touches every s-th pixel only
-        by = 2.0 * V * (in_px * ci + OH * OH * co) + 2.0 * k * k * ci * co
+        by = elt * V * (in_px * ci + OH * OH * co) + elt * k * k * ci * co
         fl = r['flops']
-        t_m, t_h, t_h2 = fl / MFMA * 1e6, by / HBM * 1e6, by / 6.29e12 * 1e6
+        t_m, t_h, t_h2 = fl * terms[0] / MFMA * 1e6, by / HBM * 1e6, by / 6.29e12 * 1e6
         b, b2 = max(t_m, t_h), max(t_m, t_h2)
+        bd, bw = max(fl * terms[1] / MFMA * 1e6, t_h), max(fl * terms[2] / MFMA * 1e6, t_h)      # = b when terms are (1, 1, 1)
         print('| %s | %.0f | %.0f | %.0f (%.0f / %.0f / %.0f) | %.0f (%.2f) | %.0f (%.2f) | %.0f (%.2f) |' % (
-            r['layer'], fl / 1e9, by / 1e6, b, t_m, t_h, t_h2, r['fwd_us'], b / r['fwd_us'], r['dgrad_us'], b / r['dgrad_us'],
-            r['wgrad_us'], b / r['wgrad_us']))
+            r['layer'], fl / 1e9, by / 1e6, b, t_m, t_h, t_h2, r['fwd_us'], b / r['fwd_us'], r['dgrad_us'], bd / r['dgrad_us'],
+            r['wgrad_us'], bw / r['wgrad_us']))
         tot['bound'] += cnt * b; tot['bound629'] += cnt * b2
         for key in ('fwd', 'dgrad', 'wgrad'):
             tot[key] += cnt * r[key + '_us']
