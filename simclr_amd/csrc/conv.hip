@@ -2287,8 +2287,12 @@ struct StemP {
 // KS > 0 (the 7x7 stem in bf16: 7 k-steps, one padded kernel row of 8 taps x 4 channels each): the k-loop is unrolled and
 // all 14 activation fragments of a tile are requested before the first MFMA -- one L1/L2 round trip per tile instead of
 // one per kernel row (the runtime loop exposed the load latency seven times per tile).
-template <typename T, bool STATS, int KS = 0>
+// SPL (fp32 storage, simclr_set_f32_matmul): 3 / 6 split-bf16 terms per product instead of the exact fp32 MFMA -- two
+// consecutive 16-element k-steps of a lane become the eight reduction elements of one v_mfma_f32_16x16x32_bf16 (the same pairing
+// for the activation and the weight operand, so every product is formed exactly once; an odd trailing k-step is paired with zeros).
+template <typename T, bool STATS, int KS = 0, int SPL = 0>
 __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
+  static_assert(SPL == 0 || (sizeof(T) == 4 && KS == 0), "split-bf16 terms: fp32 storage, runtime k-loop");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int KSTEP = 4 * EPC;     // elements per MFMA k-step
   constexpr int BN = 64;
@@ -2354,6 +2358,20 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = MMA<T>::run(bf, afk[ks][mi], acc[ni][mi]);
         }
+    } else if constexpr (SPL > 0) {
+      for (int kp = 0; kp < ksteps; kp += 2) {
+        mma_f32_chunks<4, 2, false, SPL>(&acc[0][0],
+            [&](int ni, int h) {
+              const int ks = kp + h;
+              return ks < ksteps ? *(const u32x4*)(smem + (ni * 16 + fl) * pitch + (ks * 4 + g) * 16) : zero16();
+            },
+            [&](int mi, int h) {
+              const int ks = kp + h;
+              const int e = ks * KSTEP + g * EPC;
+              const int kh = e / row_elems, within = e - kh * row_elems;
+              return (ok[mi] && ks < ksteps) ? ld16(X + base[mi] + (long long)kh * p.WP * 4 + within) : zero16();
+            });
+      }
     } else
     for (int ks = 0; ks < ksteps; ++ks) {
       const int e = ks * KSTEP + g * EPC;          // element offset along padded K
@@ -3454,8 +3472,21 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   static const bool stem_dma_on = !getenv("SIMCLR_STEM_WGRAD_DMA") || atoi(getenv("SIMCLR_STEM_WGRAD_DMA")) != 0;
   const bool stem_dma = stem_mt && stem_dma_on && dtype == SIMCLR_DT_BF16 && KW == 1 && pad == 0 && stride % 2 == 0 && IW % 2 == 0 &&
                         pixpitch == 4 && Cin == 32;
+  // fp32 stem under split-bf16 terms: a packed pixel is 4 floats = 16 bytes, so every source of the multi-tap k-tile is 16-byte
+  // aligned at ANY stride / width; 32-pixel chunks x 2 stages.  The exact fp32 arithmetic keeps the register-staged kernel.
+  static const bool stem_split_on = !getenv("SIMCLR_STEM_SPLIT") || atoi(getenv("SIMCLR_STEM_SPLIT")) != 0;
+  const bool stem_dma_f32 = stem_mt && stem_dma_on && stem_split_on && dtype == SIMCLR_DT_F32 && p.split != 0 && KW == 1 && pad == 0 &&
+                            pixpitch == 4 && Cin == 32;
   if (big256) {
     hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 256, 1, 4, 2, 4>), dim3(grid), dim3(512), lds, stream, p);
+  } else if (stem_dma_f32) {
+    const size_t lds_s = (size_t)2 * 32 * (256 + 64) * 4;      // 2 stages x 32 pixels x (256 + 64) fp32
+    p.xcd_map = 1;
+    const int grid_s = p.k_tiles * p.n_tiles * ceil_div(p.splits, 8) * 8;
+    // 8 waves (4 along the 256 k-rows x 2 along n): 4 k-fragments and 4 LDS-DMA source states per wave -- the 4-wave shape keeps 8 + 8
+    // of them next to the split fragments and spills ~100 registers
+    if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, 256, 64, 2, 2, 4, 2, false, true, 3>), dim3(grid_s), dim3(512), lds_s, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_dma<float, 256, 64, 2, 2, 4, 2, false, true, 6>), dim3(grid_s), dim3(512), lds_s, stream, p);
   } else if (stem_dma) {
     const size_t lds_s = (size_t)2 * 64 * (256 + 64) * 2;      // 2 stages x 64 pixels x (256 + 64) bf16
     p.xcd_map = 1;
@@ -3599,8 +3630,17 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
     } else if (stats) hipLaunchKernelGGL((stem_conv_fwd<uint16_t, true>), grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((stem_conv_fwd<uint16_t, false>), grid, dim3(256), lds, stream, p);
   } else {
-    if (stats) hipLaunchKernelGGL((stem_conv_fwd<float, true>), grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((stem_conv_fwd<float, false>), grid, dim3(256), lds, stream, p);
+    // fp32 storage: the forward terms of simclr_set_f32_matmul (0 = exact fp32 MFMA; SIMCLR_STEM_SPLIT=0 keeps the exact kernel)
+    static const bool stem_split_on = !getenv("SIMCLR_STEM_SPLIT") || atoi(getenv("SIMCLR_STEM_SPLIT")) != 0;
+    const int spl = stem_split_on ? g_f32_terms_fwd : 0;
+#define LSF(STv)                                                                                              \
+    do {                                                                                                       \
+      if (spl == 3) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 3>), grid, dim3(256), lds, stream, p);    \
+      else if (spl == 6) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 6>), grid, dim3(256), lds, stream, p); \
+      else hipLaunchKernelGGL((stem_conv_fwd<float, STv>), grid, dim3(256), lds, stream, p);                   \
+    } while (0)
+    if (stats) LSF(true); else LSF(false);
+#undef LSF
   }
   SIMCLR_CHECK_LAUNCH();
   return 0;

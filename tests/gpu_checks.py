@@ -315,7 +315,17 @@ def check_dgrad_bn(V, H, Cin, Cout, k, dtype, mask_mode, accumulate, seed=0):
     return res
 
 
-def check_stem(V, H, k, stride, Cout, dtype, seed=0):
+def check_stem(V, H, k, stride, Cout, dtype, seed=0, matmul='exact'):
+    """matmul (fp32 only): simclr_set_f32_matmul mode -- the split-bf16 stem forward (stem_conv_fwd<float, ., 0, 3 | 6>) and the LDS-DMA
+    stem weight gradient (conv_wgrad_dma<float, 256, 64, ..., MT, 3 | 6>) against the same float64 reference."""
+    ops.set_f32_matmul(matmul if dtype == torch.float32 else 'exact')
+    try:
+        return _check_stem(V, H, k, stride, Cout, dtype, seed, matmul)
+    finally:
+        ops.set_f32_matmul('exact')
+
+
+def _check_stem(V, H, k, stride, Cout, dtype, seed, matmul):
     g = torch.Generator().manual_seed(seed)
     img = torch.rand(V // 2, H, H, 6, generator=g)
     w = _rand((k, k, 3, Cout), dtype, g, (k * k * 3) ** -0.5)
@@ -335,12 +345,14 @@ def check_stem(V, H, k, stride, Cout, dtype, seed=0):
     sums = ops.bn_reduce_slots(stats)
     dw = ops.stem_conv_wgrad(xp, dy.to(DEV), geo, k, k, stride)
     torch.cuda.synchronize()
-    tag = 'V%d %d k%d s%d ->%d %s' % (V, H, k, stride, Cout, str(dtype).split('.')[-1])
+    tag = 'V%d %d k%d s%d ->%d %s%s' % (V, H, k, stride, Cout, str(dtype).split('.')[-1], '' if matmul == 'exact' else '/' + matmul)
     t = _tol(dtype)
     y_ref = yr.detach().permute(0, 2, 3, 1)
-    return [_res('stem_fwd ' + tag, y, y_ref, t),
+    bwd_scale = 2.0 if matmul in ('bf16x3', 'bf16x6_3') else 1.0          # three-term backward arithmetic: ~2^-17 per product
+    fwd_scale = 4.0 if matmul == 'bf16x3' else 1.0
+    return [_res('stem_fwd ' + tag, y, y_ref, t * fwd_scale),
             _res('stem_stats_sq ' + tag, sums[1], (y_ref ** 2).sum((0, 1, 2)), 1e-4),
-            _res('stem_wgrad ' + tag, dw, wr.grad, 2e-5 if dtype == torch.float32 else 1e-4)]
+            _res('stem_wgrad ' + tag, dw, wr.grad, (2e-5 if dtype == torch.float32 else 1e-4) * bwd_scale)]
 
 
 # ------------------------------------------------------------------ BN

@@ -495,6 +495,17 @@ def test_stem_conv(V, H, k, s, dtype):
     _assert(gc.check_stem(V, H, k, s, 64, dtype))
 
 
+@pytest.mark.parametrize('matmul', ['bf16x6_3', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('V,H,k,s', [(4, 32, 7, 2), (4, 16, 3, 1), (2, 224, 7, 2), (2, 33, 7, 2), (6, 48, 3, 2)])
+def test_stem_conv_f32_split_bf16_matmul(V, H, k, s, matmul):
+    """The stem in the fast parity mode (round 5: 3.9 + 5.1 ms of the 190 ms fp32-storage step ran on the exact fp32 MFMA): split-bf16 forward
+    (two 16-element k-steps per bf16 MFMA; the CIFAR stem's odd third k-step paired with zeros) and the LDS-DMA multi-tap weight gradient,
+    every stride / width (a packed fp32 pixel is 16 bytes: always aligned) -- same float64 bar as the exact kernels."""
+    from simclr_amd._lib import lib
+    from tests import gpu_checks as gc
+    _assert(gc.check_stem(V, H, k, s, 64, F32, matmul=matmul))
+
+
 @pytest.mark.parametrize('dtype', [F32, BF])
 @pytest.mark.parametrize('shape,C,relu,resid', [((6, 7, 5), 64, True, None), ((6, 7, 5), 64, False, None),
                                                 ((6, 7, 5), 64, True, 'identity'), ((6, 7, 5), 64, True, 'bn'),
