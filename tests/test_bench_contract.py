@@ -60,3 +60,45 @@ def test_flop_table_and_backend_flag():
     src = inspect.getsource(b.main)
     for needle in ("'--backend'", 'SIMCLR_DIST_BACKEND', 'SIMCLR_SHARE_GPU', 'peak_hbm_gb', 'stat_collectives_per_step'):
         assert needle in src, needle
+
+
+def test_parity_block_is_measured_not_claimed():
+    """VERDICT r04 / ADVICE r04: the line's `parity` object is computed in the run from the reference-source fixtures -- no hard-coded
+    claim survives in bench.py, the inputs come from tests/golden/recipe.py (pure numpy, no oracle import outside cpu_baseline)."""
+    import inspect
+    import re
+    b = _bench()
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'north_star met' not in src and 'PARITY_NOTE' not in src
+    msrc = inspect.getsource(b.measured_parity)
+    for needle in ('measured_in_run', 'reference_pin.npz', 'recipe.variable_value', 'make_single_step', 'north_star_met'):
+        assert needle in msrc, needle
+    assert 'oracle' not in re.sub(r'""".*?"""', '', msrc, flags=re.S).replace("oracle/tfshim.py", '')      # the docstring may name it
+    # only the cpu_baseline leg imports the oracle
+    body = src.replace(inspect.getsource(b.cpu_baseline), '')
+    assert 'from oracle' not in body and 'import oracle' not in body
+    # the recipe really is oracle-free and deterministic by NAME
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location('recipe', os.path.join(ROOT, 'tests', 'golden', 'recipe.py'))
+    r = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(r)
+    rsrc = open(os.path.join(ROOT, 'tests', 'golden', 'recipe.py')).read()
+    assert 'import torch' not in rsrc and 'from oracle' not in rsrc
+    a = r.variable_value('resnet/conv2d_fixed_padding/conv2d/kernel:0', np.zeros((3, 3, 3, 8)), True)
+    assert np.array_equal(a, r.variable_value('resnet/conv2d_fixed_padding/conv2d/kernel:0', np.ones((3, 3, 3, 8)), False))
+    assert np.abs(a).max() <= 2 * (1 / 27) ** 0.5 / .87962566103423978 + 1e-12
+    g = r.variable_value('x/gamma:0', np.ones(4), True)
+    assert np.all((g >= 1.5) & (g < 2.5)) and np.array_equal(r.variable_value('x/gamma:0', np.ones(4), False), np.ones(4))
+    assert set(r.IMG_CASES) == {'r18_img', 'r50_img'}
+
+
+def test_parity_mode_and_ntxent_accounting_fields():
+    import inspect
+    b = _bench()
+    src = inspect.getsource(b.main)
+    for needle in ('split_mode_roofline', "'families'", 'bf16_terms', 'traffic_measured_in_run', "kernels=7", 'us_events_in_step',
+                   'rccl_ranks_seen', 'rank_devices', 'stat_transport'):
+        assert needle in src.replace('families=fams', "'families'"), needle
+    csrc = inspect.getsource(b.cpu_baseline)
+    assert 'warm=3' in csrc and 'min_steps=10' in csrc

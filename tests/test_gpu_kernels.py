@@ -878,7 +878,7 @@ def test_train_step_resnet152_sk_f32_and_the_3x_architecture():
     for k in enc:       # every encoder dimension other than the 3 image channels and the kernel size scales with the width
         a, b = shapes1[k], shapes3[k]
         assert len(a) == len(b), (k, a, b)
-        if '/sk__conv2d/' in k:      # the squeeze width of SK_Conv2D is max(int(f * sk_ratio), 32) (tf2/resnet.py:242): not linear in the width
+        if 'sk__conv2d' in k:        # the squeeze width of SK_Conv2D is max(int(f * sk_ratio), 32) (tf2/resnet.py:242): not linear in the width
             assert all(x <= y <= 3 * x for x, y in zip(a, b)), (k, a, b)
         else:
             assert all(y in (x, 3 * x) for x, y in zip(a, b)), (k, a, b)
