@@ -66,9 +66,9 @@ MODELS = [dict(tag='r18_cifar', depth=18, size=32, sk=0.0, batch=4, classes=10),
 MODELS += [dict(tag=t, sk=0.0, recipe=True, **{k: v for k, v in c.items()}) for t, c in sorted(__import__('recipe').IMG_CASES.items())]
 # the training step of tf2/run.py:557-622 (extracted from `main` by ast, see _single_step): (model tag, replicas)
 STEPS = [('r18_cifar', 1), ('r18_cifar', 2), ('r50_sk', 1), ('r18_img', 1), ('r18_img', 2), ('r50_img', 1)]
-# d loss / d variable of the reference's training step by CENTRAL DIFFERENCES of the reference's own single_step (tf2/run.py:557-622 on
+# DIRECTIONAL derivatives <d loss / d variable, direction> of the reference's training step by CENTRAL DIFFERENCES of the reference's own single_step (tf2/run.py:557-622 on
 # oracle/tfshim.py) -- the stand-in GradientTape cannot differentiate, so this is what pins the BACKWARD values (the oracle's torch
-# autograd and the product's hand-written backward are both tested against it).  (variable of `r18_img`, coordinates per variable);
+# autograd and the product's hand-written backward are both tested against it).  (variable of `r18_img`, directions per variable);
 # the differentiated loss follows the reference's gradient flow: the linear-eval head sits behind tf.stop_gradient (tf2/model.py:276-277),
 # so encoder / projection-head variables see the contrastive loss only and the head's own variables the supervised loss + weight decay
 GRAD_FD_TAG = 'r18_img'
@@ -85,14 +85,16 @@ GRAD_FD_VARS = [('resnet/conv2d_fixed_padding/conv2d/kernel:0', 2),
 GRAD_FD_STEP = 1e-7
 
 
-def grad_fd_coordinates(shapes):
-    """[(variable name, flat index)]: deterministic by name (crc32), `shapes`: name -> shape"""
+def grad_fd_directions(shapes):
+    """[(variable name, unit-norm direction of that variable's shape)]: deterministic by name (crc32-seeded normal draws).  DIRECTIONAL
+    derivatives, not single coordinates: an fp32 forward flips a handful of ReLU signs that float64 does not, and one flip is a visible
+    fraction of ONE weight coordinate's gradient (percent level) while <gradient, direction> over a whole tensor averages them out."""
     import zlib
     out = []
     for name, k in GRAD_FD_VARS:
-        size = int(np.prod(shapes[name]))
         for j in range(k):
-            out.append((name, zlib.crc32(('%s#%d' % (name, j)).encode()) % size))
+            d = np.random.default_rng([zlib.crc32(('%s#%d' % (name, j)).encode()), 5]).standard_normal(tuple(shapes[name]))
+            out.append((name, d / np.sqrt((d * d).sum())))
     return out
 
 
@@ -430,14 +432,12 @@ def reference_cases(ref_dir=REFERENCE):
                     strategy.run(step, shards)
                     return {k: float(fresh[k].result()) for k in STEP_METRICS}
                 g = []
-                for name, idx in grad_fd_coordinates({n: v.value.shape for n, v in byname.items()}):
+                for name, d in grad_fd_directions({n: v.value.shape for n, v in byname.items()}):
                     v = byname[name]
                     base = v.numpy().copy()
                     vals = []
                     for sgn in (+1.0, -1.0):
-                        w = base.copy()
-                        w.reshape(-1)[idx] += sgn * GRAD_FD_STEP
-                        v.assign(w)
+                        v.assign(base + sgn * GRAD_FD_STEP * d)
                         m_ = losses()
                         # the loss this variable's gradient flows from (stop_gradient in front of the linear-eval head, model.py:276-277)
                         vals.append(m_['supervised_loss'] + m_['weight_decay'] if 'head_supervised' in name else m_['contrast_loss'])
@@ -606,8 +606,8 @@ def oracle_cases():
             from oracle.model_torch import train_step
             mom = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
             _, _, _, t = train_step(cfg, params, state, mom, torch.from_numpy(images), torch.from_numpy(labels), 0.1)
-            coords = grad_fd_coordinates({n[len('model/'):]: tuple(v.shape) for n, v in params.items()})
-            out[key + '_grad_fd'] = np.array([float(t['grads']['model/' + n].reshape(-1)[i]) for n, i in coords])
+            dirs = grad_fd_directions({n[len('model/'):]: tuple(v.shape) for n, v in params.items()})
+            out[key + '_grad_fd'] = np.array([float((t['grads']['model/' + n].double().numpy() * d).sum()) for n, d in dirs])
     return out
 
 

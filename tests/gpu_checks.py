@@ -1823,16 +1823,20 @@ def check_reference_pin_step(tag, compute_dtype='f32', f32_matmul='exact', gate=
     applied = sorted(v.name[len('model/'):] for v in model._flat_order)
     entry('applied_variable_names', 0.0 if applied == list(ref[key + '_applied_names']) else 1.0, 0.0)
     if key + '_grad_fd' in ref:
-        # BACKWARD values against the reference: d loss / d variable at a few coordinates by central differences of the reference's own
+        # BACKWARD values against the reference: <d loss / d variable, direction> for unit directions over whole tensors, by central differences of the reference's own
         # single_step (make_reference_golden.py GRAD_FD_VARS; the oracle's autograd agrees with them to 3e-6) vs the product's hand-written
         # backward (the gradients the step handed to LARS)
         byname = {v.name: v for v in model._flat_order}
-        coords = m.grad_fd_coordinates({n[len('model/'):]: tuple(v.value.shape) for n, v in byname.items()})
+        dirs = m.grad_fd_directions({n[len('model/'):]: tuple(v.value.shape) for n, v in byname.items()})
         want_g = ref[key + '_grad_fd']
-        got_g = np.array([float(byname['model/' + n].grad.reshape(-1)[i]) for n, i in coords])
+        got_g = np.array([float((byname['model/' + n].grad.double().cpu().numpy() * d).sum()) for n, d in dirs])
+        gnorm = np.array([float(byname['model/' + n].grad.double().norm()) for n, _ in dirs])
+        # <g, d> for a unit direction: the error is measured against the gradient tensor's own norm (a direction nearly orthogonal to
+        # the gradient says nothing relative to its own small value)
         rtol = 2e-3 if f32_matmul == 'exact' else 5e-3          # three-term backward arithmetic: ~2^-17 per product
-        worst = float(np.max(np.abs(got_g - want_g) / (rtol * np.abs(want_g) + 2e-5)))
-        entry('backward_vs_reference_central_differences', worst, 1.0 if compute_dtype == 'f32' else float('inf'), n=len(coords),
+        worst = float(np.max(np.abs(got_g - want_g) / (rtol * gnorm + 1e-9)))
+        entry('backward_vs_reference_central_differences', worst, 1.0 if compute_dtype == 'f32' else float('inf'), n=len(dirs),
+              got=[float('%.6g' % x) for x in got_g], want=[float('%.6g' % x) for x in want_g], gnorm=[float('%.4g' % x) for x in gnorm],
               worst_rel=float(np.max(np.abs(got_g - want_g) / np.abs(want_g))))
     FLAGS.reset(); RT.reset()
     return res
