@@ -65,14 +65,14 @@ MODELS = [dict(tag='r18_cifar', depth=18, size=32, sk=0.0, batch=4, classes=10),
 # itself stays 5-10x inside north_star's 1e-5 / 1e-3 on them, so the device tests and bench.py gate them with FIXED tolerances
 MODELS += [dict(tag=t, sk=0.0, recipe=True, **{k: v for k, v in c.items()}) for t, c in sorted(__import__('recipe').IMG_CASES.items())]
 # the training step of tf2/run.py:557-622 (extracted from `main` by ast, see _single_step): (model tag, replicas)
-STEPS = [('r18_cifar', 1), ('r18_cifar', 2), ('r50_sk', 1), ('r18_img', 1), ('r18_img', 2), ('r50_img', 1)]
+STEPS = [('r18_cifar', 1), ('r18_cifar', 2), ('r50_sk', 1), ('r18_img', 1), ('r18_img', 2), ('r50_img', 1), ('r50', 1)]
 # DIRECTIONAL derivatives <d loss / d variable, direction> of the reference's training step by CENTRAL DIFFERENCES of the reference's own single_step (tf2/run.py:557-622 on
 # oracle/tfshim.py) -- the stand-in GradientTape cannot differentiate, so this is what pins the BACKWARD values (the oracle's torch
-# autograd and the product's hand-written backward are both tested against it).  (variable of `r18_img`, directions per variable);
+# autograd and the product's hand-written backward are both tested against it).  (model tag -> [(variable, directions)]);
 # the differentiated loss follows the reference's gradient flow: the linear-eval head sits behind tf.stop_gradient (tf2/model.py:276-277),
 # so encoder / projection-head variables see the contrastive loss only and the head's own variables the supervised loss + weight decay
-GRAD_FD_TAG = 'r18_img'
-GRAD_FD_VARS = [('resnet/conv2d_fixed_padding/conv2d/kernel:0', 2),
+GRAD_FD_VARS = {
+    'r18_img': [('resnet/conv2d_fixed_padding/conv2d/kernel:0', 2),
                 ('resnet/block_group3/residual_block_4/conv2d_fixed_padding_11/conv2d_11/kernel:0', 1),
                 ('resnet/block_group3/residual_block_4/conv2d_fixed_padding_12/conv2d_12/kernel:0', 1),
                 ('resnet/block_group3/residual_block_4/conv2d_fixed_padding_13/conv2d_13/kernel:0', 1),
@@ -81,17 +81,29 @@ GRAD_FD_VARS = [('resnet/conv2d_fixed_padding/conv2d/kernel:0', 2),
                 ('projection_head/nl_0/dense/kernel:0', 1),
                 ('projection_head/nl_2/batch_norm_relu_23/sync_batch_normalization_23/gamma:0', 1),
                 ('head_supervised/linear_layer/dense_3/kernel:0', 1),
-                ('head_supervised/linear_layer/dense_3/bias:0', 1)]
+                ('head_supervised/linear_layer/dense_3/bias:0', 1)],
+    # ResNet-50 (the small wiring case, every gamma / beta perturbed): the 7 x 7 stem, a strided projection shortcut and a strided 3 x 3 of
+    # the first block of group 2, and all of an identity bottleneck block -- the block whose tail BatchNorm backward the product FOLDS into
+    # its last convolution (DESIGN.md section 3.1)
+    'r50': [('resnet/conv2d_fixed_padding/conv2d/kernel:0', 1),
+            ('resnet/block_group2/bottleneck_block_3/conv2d_fixed_padding_11/conv2d_11/kernel:0', 1),
+            ('resnet/block_group2/bottleneck_block_3/conv2d_fixed_padding_13/conv2d_13/kernel:0', 1),
+            ('resnet/block_group2/bottleneck_block_4/conv2d_fixed_padding_15/conv2d_15/kernel:0', 1),
+            ('resnet/block_group2/bottleneck_block_4/conv2d_fixed_padding_16/conv2d_16/kernel:0', 1),
+            ('resnet/block_group2/bottleneck_block_4/conv2d_fixed_padding_17/conv2d_17/kernel:0', 1),
+            ('resnet/block_group2/bottleneck_block_4/batch_norm_relu_17/sync_batch_normalization_17/gamma:0', 1),
+            ('resnet/block_group2/bottleneck_block_4/batch_norm_relu_17/sync_batch_normalization_17/beta:0', 1)],
+}
 GRAD_FD_STEP = 1e-7
 
 
-def grad_fd_directions(shapes):
+def grad_fd_directions(tag, shapes):
     """[(variable name, unit-norm direction of that variable's shape)]: deterministic by name (crc32-seeded normal draws).  DIRECTIONAL
     derivatives, not single coordinates: an fp32 forward flips a handful of ReLU signs that float64 does not, and one flip is a visible
     fraction of ONE weight coordinate's gradient (percent level) while <gradient, direction> over a whole tensor averages them out."""
     import zlib
     out = []
-    for name, k in GRAD_FD_VARS:
+    for name, k in GRAD_FD_VARS[tag]:
         for j in range(k):
             d = np.random.default_rng([zlib.crc32(('%s#%d' % (name, j)).encode()), 5]).standard_normal(tuple(shapes[name]))
             out.append((name, d / np.sqrt((d * d).sum())))
@@ -422,7 +434,7 @@ def reference_cases(ref_dir=REFERENCE):
             out[key + '_applied_names'] = np.array(sorted(opt.applied[0]))
             assert all(a == opt.applied[0] for a in opt.applied) and len(opt.applied) == R
             assert tfshim.GradientTape.recorded[0][1] == opt.applied[0]
-            if tag == GRAD_FD_TAG and R == 1:
+            if tag in GRAD_FD_VARS and R == 1:
                 byname = {v.name: v for v in tfshim.CREATED_VARIABLES}
 
                 def losses():
@@ -432,7 +444,7 @@ def reference_cases(ref_dir=REFERENCE):
                     strategy.run(step, shards)
                     return {k: float(fresh[k].result()) for k in STEP_METRICS}
                 g = []
-                for name, d in grad_fd_directions({n: v.value.shape for n, v in byname.items()}):
+                for name, d in grad_fd_directions(tag, {n: v.value.shape for n, v in byname.items()}):
                     v = byname[name]
                     base = v.numpy().copy()
                     vals = []
@@ -600,13 +612,13 @@ def oracle_cases():
         out[key + '_metrics'] = np.array([float(o['con_loss']), acc, ent, float(o['sup_loss']), sup_acc, float(o['weight_decay']),
                                           float(o['total_loss'])])
         out[key + '_applied_names'] = np.array(sorted(n[len('model/'):] for n in params))
-        if tag == GRAD_FD_TAG and R == 1:
-            # the same coordinates from torch autograd of the oracle's step (train_step = what tape.gradient would return)
+        if tag in GRAD_FD_VARS and R == 1:
+            # the same directions from torch autograd of the oracle's step (train_step = what tape.gradient would return)
             from collections import OrderedDict
             from oracle.model_torch import train_step
             mom = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
             _, _, _, t = train_step(cfg, params, state, mom, torch.from_numpy(images), torch.from_numpy(labels), 0.1)
-            dirs = grad_fd_directions({n[len('model/'):]: tuple(v.shape) for n, v in params.items()})
+            dirs = grad_fd_directions(tag, {n[len('model/'):]: tuple(v.shape) for n, v in params.items()})
             out[key + '_grad_fd'] = np.array([float((t['grads']['model/' + n].double().numpy() * d).sum()) for n, d in dirs])
     return out
 

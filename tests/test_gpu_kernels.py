@@ -173,7 +173,7 @@ def test_lars_kernels_match_the_reference_source_fixtures():
 
 
 PIN_MODEL_TAGS = ['r18_cifar', 'r50', 'r50_sk', 'r34_w2', 'r18_localbn', 'r18_img', 'r50_img']
-PIN_STEP_TAGS = ['r18_cifar', 'r50_sk', 'r18_img', 'r50_img']
+PIN_STEP_TAGS = ['r18_cifar', 'r50_sk', 'r18_img', 'r50_img', 'r50']
 
 
 @pytest.mark.parametrize('matmul', ['exact', 'bf16x6_3'])

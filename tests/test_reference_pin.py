@@ -28,7 +28,7 @@ def test_oracle_reproduces_the_reference_source_fixtures():
     ref = dict(np.load(m.OUT_NPZ))
     orc = m.oracle_cases()
     assert set(ref) == set(orc), (sorted(set(ref) - set(orc))[:5], sorted(set(orc) - set(ref))[:5])
-    assert len(ref) >= 303 and 'step_r18_img_R1_grad_fd' in ref
+    assert len(ref) >= 307 and 'step_r18_img_R1_grad_fd' in ref and 'step_r50_R1_grad_fd' in ref
     bad = [(k, m.compare(ref[k], orc[k], k)) for k in sorted(ref) if m.compare(ref[k], orc[k], k) > m.tolerance(k)]
     assert not bad, bad[:10]
     # what the table covers (a fixture file that silently lost a family would pass the loop above)
