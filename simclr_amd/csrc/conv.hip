@@ -3449,8 +3449,13 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   const int brm = ((cfg >= 2 && big) || big256) ? 1 : 2;
   const int stages = big256 ? 4 : (cfg <= 1 ? 2 : (big ? (cfg == 2 ? 3 : 4) : 3));
   const int br = (dtype == SIMCLR_DT_BF16 ? 32 : 16) * brm;
+  // workgroup target of the bf16 launches: 1024 (round 5 sweep, interleaved pairs on one box, ms per step at 768 / 1024 / 1536 / 2048 /
+  // 3072: 64.1 / 63.7 / 63.9 / 64.6 / 65.1 -- fewer, longer pixel ranges write fewer fp32 slabs); the fp32 launches keep the 1536 of
+  // SIMCLR_WGRAD_BLOCKS' default (parity mode 190.5 / 187.4 / 187.2 at 1024 / 1536 / 2048).  The workspace is sized for 1536.
+  static const bool blocks_env = getenv("SIMCLR_WGRAD_BLOCKS") != nullptr;
+  const int want_wg = (dtype == SIMCLR_DT_BF16 && !blocks_env && bkw != 256) ? 1024 : 0;
   p.splits = stem_mt ? wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split, 1024, 1024)
-                     : wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split);
+                     : wgrad_splits(p.M, p.K, p.N, bkw, bnw, br, &p.chunks_per_split, 256, want_wg);
   p.k_tiles = ceil_div(p.K, bkw);
   p.n_tiles = ceil_div(p.N, bnw);
   // XCD-aware mapping: with the LDS-DMA kernel a win (or neutral) on every ResNet-50 layer; the register-staged
