@@ -546,7 +546,10 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_apply: C=%d must be a multiple of %d", C, epc);
   SIMCLR_CHECK_ARG(!rscale || res, "bn_apply: rscale needs res");
-  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 0;   // bit0: non-temporal policy
+  // bit0: non-temporal loads / stores.  Default ON since round 5: interleaved three-fold A/B on one box (profiles/r05_notes.md section 8),
+  // ms per training step: ResNet-50 63.19 -> 62.63, fp32 parity mode 186.5 -> 184.3 -- the streamed tensors are far larger than L2 / MALL
+  // and are next read by a different kernel, so keeping them out of the caches leaves those to the convolutions' re-reads.
+  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 1;   // bit0: non-temporal policy
   const bool nt = (cfg & 1) != 0;
   const int cpr = C / epc;
   const long long nchunks = rows * cpr;
@@ -612,7 +615,7 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
                         int dtype, hipStream_t stream) {
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, epc);
-  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 0;
+  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 1;      // see simclr_bn_apply
   const bool nt = (cfg & 1) != 0;
   const int cpr = C / epc;
   const long long nchunks = rows * cpr;

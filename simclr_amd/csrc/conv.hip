@@ -2649,7 +2649,7 @@ static bool igemm_use_wide(const ConvP& p, bool fwd) {
   if (p.bn_mode && p.bn_mode != 4 && !p.bn_x) return false;
   // 32-bit byte offsets into the operands, below the out-of-range marker of the kernel (0xF0000000)
   if ((long long)p.V * p.IH * p.IW * p.pixpitch * 2 >= 0xE0000000ll || (long long)p.N * p.K * 2 >= 0xE0000000ll) return false;
-  if (mode >= 2) return true;
+  if (mode == 2) return true;
   // Rule from the per-layer A/B at 1024 views (tools/microbench.py --what wide, profiles/r04_notes.md; us, 128-wide -> wide):
   //   forward (statistics, plain or statistics-only): wins wherever it applies -- 56^2 64->256 544 -> 443, 14^2 1024->512
   //   254 -> 223, 14^2 1024->2048 s2 288 -> 239, 7^2 2048->512 132 -> 113 -- except the 3x3 stride-1 layers, where the
@@ -2659,8 +2659,14 @@ static bool igemm_use_wide(const ConvP& p, bool fwd) {
   //   dgrad + BatchNorm-backward reduce: loses everywhere but at 7^2 (+4 ... +29 %: one workgroup per CU cannot hide the
   //   row pass's operand loads) -> stays on conv_igemm_persistent.
   if (p.M < 32768) return false;
-  if (fwd) return !(p.KH == 3 && p.KW == 3 && p.stride == 1);
-  return !p.bn_mode && !p.accumulate && p.KH == 1 && p.KW == 1 && p.IC >= 512;
+  // modes 3 / 4 (A/B runs): the rule for the forward launches only / for the data-gradient launches only.
+  // Forward, round 5: only launches of >= 300 GFLOP.  Stand-alone the wide tile wins on every layer it applies to, but a 150 KB workgroup
+  // needs a whole CU's LDS -- it cannot start until the previous kernel has drained from that CU and nothing starts beside it -- and
+  // INSIDE the training step that fixed cost outweighs the gain on ResNet-50 1x (105 ... 237 GFLOP per launch: 63.19 -> 62.65 ms per
+  // step with the forward rule off, three interleaved runs) while ResNet-50 2x + SK (420 ... 950 GFLOP per launch) loses 2.4 ms of 286
+  // without it (profiles/r05_notes.md section 8).
+  if (fwd) return mode != 4 && !(p.KH == 3 && p.KW == 3 && p.stride == 1) && (mode == 3 || 2.0 * (double)p.M * p.K * p.N >= 3.0e11);
+  return mode != 3 && !p.bn_mode && !p.accumulate && p.KH == 1 && p.KW == 1 && p.IC >= 512;
 }
 
 // Short-K layers (1x1 convolutions from <= SIMCLR_IGEMM_BN64_K channels, default 128: one or two k-tiles per output tile)
@@ -2669,7 +2675,9 @@ static bool igemm_use_wide(const ConvP& p, bool fwd) {
 // workgroups instead of N/128 -- irrelevant for an HBM-bound layer).  Measured in the step: 66.49 / 66.33 vs 66.72 / 66.66 ms
 // (-0.3 ms, two interleaved pairs, profiles/r03_notes.md); K <= 64 alone and K <= 256 give 66.60 / 66.50.
 static bool igemm_narrow(const ConvP& p, size_t esz) {
-  static const int kmax = getenv("SIMCLR_IGEMM_BN64_K") ? atoi(getenv("SIMCLR_IGEMM_BN64_K")) : 128;
+  // Round 5 (three interleaved runs each on one box, profiles/r05_notes.md section 8): K <= 64 only -- 63.19 -> 62.56 ms per step; the K = 128
+  // layers (28^2 128 -> 512) are better off on the 128-wide tile now that its epilogues carry their options as compile-time constants.
+  static const int kmax = getenv("SIMCLR_IGEMM_BN64_K") ? atoi(getenv("SIMCLR_IGEMM_BN64_K")) : 64;
   return esz == 2 && p.N > 64 && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.x2 && p.K <= kmax && p.N / 64 <= 64;
 }
 
