@@ -2665,7 +2665,8 @@ static bool igemm_use_wide(const ConvP& p, bool fwd) {
   // INSIDE the training step that fixed cost outweighs the gain on ResNet-50 1x (105 ... 237 GFLOP per launch: 63.19 -> 62.65 ms per
   // step with the forward rule off, three interleaved runs) while ResNet-50 2x + SK (420 ... 950 GFLOP per launch) loses 2.4 ms of 286
   // without it (profiles/r05_notes.md section 8).
-  if (fwd) return mode != 4 && !(p.KH == 3 && p.KW == 3 && p.stride == 1) && (mode == 3 || 2.0 * (double)p.M * p.K * p.N >= 3.0e11);
+  // mode 5: the rule of round 4 (no work threshold on the forward launches), kept for A/B runs against the current default
+  if (fwd) return mode != 4 && !(p.KH == 3 && p.KW == 3 && p.stride == 1) && (mode == 3 || mode == 5 || 2.0 * (double)p.M * p.K * p.N >= 3.0e11);
   return mode != 3 && !p.bn_mode && !p.accumulate && p.KH == 1 && p.KW == 1 && p.IC >= 512;
 }
 
