@@ -50,6 +50,8 @@ class PeerStats:
         handle = (ctypes.c_ubyte * 64)()
         err = None
         try:
+            if os.environ.get('SIMCLR_PEER_TEST_FAIL') == str(rank):      # test hook: this rank "cannot export its mailbox"
+                raise RuntimeError('simulated comm_create failure (SIMCLR_PEER_TEST_FAIL)')
             L.comm_create(world, max_doubles, ctypes.byref(mailbox), handle)
             self._mailbox = mailbox.value
         except Exception as e:      # noqa: BLE001 -- any local failure must reach the collective decision below

@@ -524,3 +524,43 @@ def test_two_replicas_without_global_bn_fused_tail_matches_unfused():
     for _, _, m in res:
         assert m['stat_collectives'] == 0, m           # no statistic exchange without global BatchNorm
         assert m['loss_rel'] < 2e-3 and m['grad_one_minus_cos'] < 5e-3, m
+
+
+def _peer_fallback_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          SIMCLR_PEER_STATS='1', SIMCLR_PEER_TEST_FAIL='1')
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from simclr_amd import comm
+        st = comm.Strategy()                      # rank 1 fails to create its mailbox: EVERY rank must fall back, nobody may hang
+        x = torch.full((2, 64), float(rank + 1), dtype=torch.float64, device='cuda')
+        st.all_reduce_sum(x)                      # collective C over the collective library
+        torch.cuda.synchronize()
+        st.check_health(wait=True)
+        ok = bool((x == float(world * (world + 1) // 2)).all())
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok', dict(peer=st.peer_stats is None, why=st.peer_stats_fallback, sum_ok=ok)))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, 'FAIL', traceback.format_exc()))
+
+
+def test_peer_mapped_exchange_falls_back_collectively():
+    """a rank that cannot set up the peer-mapped exchange must not leave the others waiting -- the set-up result is agreed
+    collectively and ALL ranks keep the collective library for the SyncBatchNormalization statistics."""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in res), res
+    for _, _, m in res:
+        assert m['peer'] and m['sum_ok'] and 'create failed on rank 1' in m['why'], m
