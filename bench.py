@@ -381,7 +381,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--per_gpu_batch', type=int, default=512)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--f32_matmul', default='exact', choices=['exact', 'bf16x3', 'bf16x6', 'bf16x6_3'],
+    ap.add_argument('--f32_matmul', default='exact', choices=['exact', 'bf16x3', 'bf16x6', 'bf16x6_3', 'f16x3_3'],
                     help='--dtype f32 only: matrix arithmetic of the fp32 step (FLAGS.f32_matmul)')
     ap.add_argument('--resnet_depth', type=int, default=50)
     ap.add_argument('--image_size', type=int, default=224)

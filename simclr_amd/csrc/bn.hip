@@ -326,7 +326,9 @@ __global__ __launch_bounds__(kSlotThreads) void bn_bwd_finalize(const double* __
 }
 
 // dx = scale*(dy_m - c1 - x^*c2)   [dmasked = dy_m]; same block-contiguous streaming shape as bn_apply
-template <typename T, int U, bool NT>
+// PSO (fp32 only): dx is written in the pre-split block format (common.h), bf16 pieces -- its consumers are the data-gradient and
+// weight-gradient GEMMs of the convolution in front of this BatchNorm, which then split nothing in their k-loops.
+template <typename T, int U, bool NT, bool PSO = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                              const T* __restrict__ mask_src, const float* __restrict__ scale,
                              const float* __restrict__ shift, const float* __restrict__ mean,
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, co
         const float xh = (xf[e] - mu[e]) * rs[e];
         o[e] = sc[e] * (d[e] - k1[e] - xh * k2[e]);
       }
-      stg16<NT>(dx + i * EPC, f32_to_chunk<T>(o));
+      if constexpr (PSO) ps_store_quad<false, NT>(dx, i, o);
+      else stg16<NT>(dx + i * EPC, f32_to_chunk<T>(o));
       if (dmasked) stg16<NT>(dmasked + i * EPC, f32_to_chunk<T>(d));
     }
   }
@@ -613,8 +616,12 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
                         const float* shift, const float* mean, const float* rstd, const float* c1,
                         const float* c2, long long rows, int C, int mask_mode, void* dx, void* dmasked,
                         int dtype, hipStream_t stream) {
+  // dtype | SIMCLR_FMT_PS_OUT (fp32 only, C a multiple of 32): dx in the pre-split block format, bf16 pieces (common.h)
+  const bool ps_out = (dtype & SIMCLR_FMT_PS_OUT) != 0;
+  dtype &= 0xff;
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, epc);
+  SIMCLR_CHECK_ARG(!ps_out || (dtype == SIMCLR_DT_F32 && C % 32 == 0), "bn_bwd_apply: pre-split output needs fp32 storage and C %% 32 == 0 (C=%d)", C);
   static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 1;      // see simclr_bn_apply
   const bool nt = (cfg & 1) != 0;
   const int cpr = C / epc;
@@ -628,9 +635,14 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
                        rstd, c1, c2, nchunks, C, mask_mode, (TT*)dx, (TT*)dmasked)
 #define LBX(TT) do { if (two) { if (nt) LBW(TT, 2, true); else LBW(TT, 2, false); } \
                      else { if (nt) LBW(TT, 1, true); else LBW(TT, 1, false); } } while (0)
+#define LBP(UU, NN) hipLaunchKernelGGL((bn_bwd_apply<float, UU, NN, true>), dim3(grid), dim3(256), 0, stream, \
+                       (const float*)dy, (const float*)x, (const float*)mask_src, scale, shift, mean, \
+                       rstd, c1, c2, nchunks, C, mask_mode, (float*)dx, (float*)dmasked)
   if (grid > 0) {
-    if (dtype == SIMCLR_DT_BF16) LBX(uint16_t); else LBX(float);
+    if (ps_out) { if (two) { if (nt) LBP(2, true); else LBP(2, false); } else { if (nt) LBP(1, true); else LBP(1, false); } }
+    else if (dtype == SIMCLR_DT_BF16) LBX(uint16_t); else LBX(float);
   }
+#undef LBP
 #undef LBX
 #undef LBW
   SIMCLR_CHECK_LAUNCH();

@@ -54,6 +54,62 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2_t));
 }
 
+// ---- pre-split block format ("PS") of an fp32 tensor [rows][C], C a multiple of 32 -----------------------------------
+// The fast parity mode multiplies fp32 operands as three 16-bit-piece MFMA terms (csrc/conv.hip mma_f32_chunks): x = hi + lo,
+// hi = rn16(x), lo = rn16(x - hi), pieces bf16 (8-bit, fp32's range: gradients) or fp16 (11-bit, |x| < 65504: forward operands).
+// A tensor whose only heavy consumers are those GEMMs is kept PRE-SPLIT by its (elementwise) producer: same 4 bytes per
+// element, same addresses per 128-byte block of 32 channels, but the block holds eight 16-byte chunks of pieces instead of
+// eight chunks of floats -- chunk g (g < 4) = the hi pieces of channels {4g..4g+3, 16+4g..16+4g+3} (what lane group g of a
+// k-step reads from the fp32 block: chunks g and 4 + g), chunk 4 + g = their lo pieces.  The GEMM's LDS-DMA stream, swizzle
+// and fragment reads do not change; its k-loop loses the splitting work (2.5 - 3 VALU instructions per element).
+// Elementwise view: the 16-byte fp32 chunk i of the logical tensor (4 consecutive channels) lives as one 8-byte hi quad at
+// byte ps_quad_offset(i) and one 8-byte lo quad 64 bytes further.
+#define SIMCLR_FMT_PS_IN 0x100    // dtype flag of an entry point: the (first) tensor operand is pre-split
+#define SIMCLR_FMT_PS_OUT 0x200   // dtype flag: the output tensor is written pre-split
+#define SIMCLR_FMT_PS_F16 0x400   // the pieces are fp16 (default: bf16)
+#define SIMCLR_FMT_PS_IN2 0x800   // the second tensor operand (wgrad: x; bn_apply: res) is pre-split
+typedef _Float16 hw_f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  const hw_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_f16x2_t));      // v_cvt_pk_f16_f32 (round to nearest even)
+}
+template <bool F16> __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& l) {
+  if constexpr (F16) {
+    h = pack_f16x2(x0, x1);
+    const hw_f16x2_t hv = __builtin_bit_cast(hw_f16x2_t, h);
+    l = pack_f16x2(x0 - (float)hv[0], x1 - (float)hv[1]);
+  } else {
+    h = pack_bf16x2(x0, x1);
+    l = pack_bf16x2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
+  }
+}
+__device__ __forceinline__ long long ps_quad_offset(long long i) { return (i >> 3) * 128 + (i & 3) * 16 + ((i >> 2) & 1) * 8; }
+template <bool F16, bool NT = false> __device__ __forceinline__ void ps_store_quad(void* base, long long i, const float* v) {
+  u32x2 h, l;
+  uint32_t a, b;
+  split_pair<F16>(v[0], v[1], a, b); h[0] = a; l[0] = b;
+  split_pair<F16>(v[2], v[3], a, b); h[1] = a; l[1] = b;
+  unsigned char* p = (unsigned char*)base + ps_quad_offset(i);
+  if (NT) { __builtin_nontemporal_store(h, (u32x2*)p); __builtin_nontemporal_store(l, (u32x2*)(p + 64)); }
+  else { *(u32x2*)p = h; *(u32x2*)(p + 64) = l; }
+}
+template <bool F16, bool NT = false> __device__ __forceinline__ void ps_load_quad(const void* base, long long i, float* v) {
+  const unsigned char* p = (const unsigned char*)base + ps_quad_offset(i);
+  const u32x2 h = NT ? __builtin_nontemporal_load((const u32x2*)p) : *(const u32x2*)p;
+  const u32x2 l = NT ? __builtin_nontemporal_load((const u32x2*)(p + 64)) : *(const u32x2*)(p + 64);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if constexpr (F16) {
+      const hw_f16x2_t hv = __builtin_bit_cast(hw_f16x2_t, h[j]), lv = __builtin_bit_cast(hw_f16x2_t, l[j]);
+      v[2 * j] = (float)hv[0] + (float)lv[0];
+      v[2 * j + 1] = (float)hv[1] + (float)lv[1];
+    } else {
+      v[2 * j] = __uint_as_float(h[j] << 16) + __uint_as_float(l[j] << 16);
+      v[2 * j + 1] = __uint_as_float(h[j] & 0xffff0000u) + __uint_as_float(l[j] & 0xffff0000u);
+    }
+  }
+}
+
 // Element traits: storage type T is float or uint16_t (bf16 bits).
 template <typename T> struct Elem;
 template <> struct Elem<float> {

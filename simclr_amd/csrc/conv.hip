@@ -87,6 +87,8 @@ struct ConvP {
   float* part_ws;
   unsigned* part_flags;
   unsigned* part_err;
+  int x_ps;          // fp32 dgrad, three bf16 terms: the gathered tensor p.x (the upstream gradient) is in the pre-split block format
+                     // (common.h; written by simclr_bn_bwd_apply with SIMCLR_FMT_PS_OUT) -> PSX instantiation, no splitting in the k-loop
   unsigned x_bytes;  // conv_igemm_wide: size of the gathered tensor in bytes (range check of its buffer descriptor)
   // conv_igemm_wide: (images, class rows, class columns) that 8, 128 and 136 consecutive GEMM rows advance an output pixel
   int rs_dq[3], rs_drow[3], rs_dcol[3];
@@ -148,19 +150,44 @@ __device__ __forceinline__ void split_terms3(const u32x4& c0, const u32x4& c1, u
 __device__ __forceinline__ f32x4 mma_bf16(const u32x4& a, const u32x4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// ---- split-fp16 arithmetic (terms == 13: "three fp16 terms") ----------------------------------------------------------
+// An fp16 piece carries 11 significand bits against bf16's 8: x = hi + lo with hi = fp16(x), lo = fp16(x - hi) represents x to
+// ~2^-22 (two bf16 pieces: 2^-16), so the THREE products hi*hi + hi*lo + lo*hi (dropped: lo*lo ~ 2^-22) are as accurate as the
+// six bf16 terms at half the MFMA work -- v_mfma_f32_16x16x32_f16 runs at the bf16 rate, fp16 products are exact in fp32.
+// The price is fp16's range (|x| < 65504, pieces below 2^-14 are subnormal: absolute resolution 2^-25): fine for what the
+// FORWARD multiplies -- BatchNorm outputs, pooled features, images (O(1)) and weights, which are pre-split with a power-of-two
+// scale (F16_WSCALE_LOG2, undone on the accumulators: exact) so that their lo pieces stay normal.  Gradients span too many
+// binades for fp16 without per-tensor scaling: the backward keeps the bf16 terms.  An operand beyond the fp16 range turns into
+// inf / NaN in the output (loud), never into a silently wrong number.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+#define F16_WSCALE_LOG2 8
+// (pack_f16x2 / split_pair<F16>: common.h)
+__device__ __forceinline__ void split_terms2_f16(const u32x4& c0, const u32x4& c1, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = __uint_as_float(j < 2 ? c0[2 * j] : c1[2 * j - 4]), x1 = __uint_as_float(j < 2 ? c0[2 * j + 1] : c1[2 * j - 3]);
+    uint32_t h, l;
+    split_pair<true>(x0, x1, h, l);
+    hi[j] = h; lo[j] = l;
+  }
+}
+__device__ __forceinline__ f32x4 mma_f16(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 // acc(i, j) += A_i . B_j over the 32 reduction elements of one k-step; lda(i, h) / ldb(j, h) return 16-byte chunk h (0 | 1) of
 // fragment row i / j (fp32: 4 values; the two chunks of a row are this lane's 8 reduction elements).
 // terms (compile time: the six-term path needs ~60 more registers): 0 = exact fp32 MFMA (8 x v_mfma_f32_16x16x4_f32 per pair), 3 / 6 = split bf16 (small terms accumulated first,
-// term-major so that consecutive MFMAs write different accumulators).  The B operand is split once, the A operand one
+// term-major so that consecutive MFMAs write different accumulators), 13 = three split-fp16 terms.  The B operand is split once, the A operand one
 // fragment at a time (register pressure: NB x 12 + 12 split registers instead of (NA + NB) x 12).
 // TR: the accumulator array is indexed [j][i] (acc[NB][NA]) instead of [i][j].
-// PSA (terms == 3 only): the A operand arrives PRE-SPLIT (presplit_rows below): chunk 0 of a fragment row is this lane's
+// PSA (terms == 3 | 13): the A operand arrives PRE-SPLIT (presplit_rows below): chunk 0 of a fragment row is this lane's
 // eight hi values, chunk 1 its eight lo values -- the same two 16-byte reads, no VALU work for that operand.  Bitwise the
-// same products as the in-register split (same rounding instruction, same MFMA order).
-template <int NA, int NB, bool TR, int terms, bool PSA = false, typename LA, typename LB>
+// same products as the in-register split (same rounding instruction, same MFMA order).  PSB2: the same for the B operand
+// (an activation / gradient tensor kept in the pre-split block format by its producer).
+template <int NA, int NB, bool TR, int terms, bool PSA = false, bool PSB2 = false, typename LA, typename LB>
 __device__ __forceinline__ void mma_f32_chunks(f32x4* __restrict__ accp, LA lda, LB ldb) {
-  static_assert(terms == 0 || terms == 3 || terms == 6, "0 = exact fp32, 3 / 6 = split-bf16 terms");
-  static_assert(!PSA || terms == 3, "pre-split operand: two planes (hi, lo) = the three-term product only");
+  static_assert(terms == 0 || terms == 3 || terms == 6 || terms == 13, "0 = exact fp32, 3 / 6 = split-bf16 terms, 13 = three split-fp16 terms");
+  static_assert(!(PSA || PSB2) || terms == 3 || terms == 13, "pre-split operand: two planes (hi, lo) = the three-term products only");
 #define acc_(i, j) accp[TR ? (j) * NA + (i) : (i) * NB + (j)]
   if constexpr (terms == 0) {
 #pragma unroll
@@ -178,21 +205,28 @@ __device__ __forceinline__ void mma_f32_chunks(f32x4* __restrict__ accp, LA lda,
           for (int e = 0; e < 4; ++e)
             acc_(i, j) = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), __uint_as_float(b[j][e]), acc_(i, j), 0, 0, 0);
     }
-  } else if constexpr (terms == 3) {
+  } else if constexpr (terms == 3 || terms == 13) {
+    constexpr bool F16 = terms == 13;
+    auto mm = [](const u32x4& a, const u32x4& b, f32x4 c) __attribute__((always_inline)) { return F16 ? mma_f16(a, b, c) : mma_bf16(a, b, c); };
     u32x4 bh[NB], bl[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) split_terms2(ldb(j, 0), ldb(j, 1), bh[j], bl[j]);
+    for (int j = 0; j < NB; ++j) {
+      if constexpr (PSB2) { bh[j] = ldb(j, 0); bl[j] = ldb(j, 1); }
+      else if constexpr (F16) split_terms2_f16(ldb(j, 0), ldb(j, 1), bh[j], bl[j]);
+      else split_terms2(ldb(j, 0), ldb(j, 1), bh[j], bl[j]);
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       u32x4 ah, al;
       if constexpr (PSA) { ah = lda(i, 0); al = lda(i, 1); }
+      else if constexpr (F16) split_terms2_f16(lda(i, 0), lda(i, 1), ah, al);
       else split_terms2(lda(i, 0), lda(i, 1), ah, al);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(al, bh[j], acc_(i, j));
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mm(al, bh[j], acc_(i, j));
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(ah, bl[j], acc_(i, j));
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mm(ah, bl[j], acc_(i, j));
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc_(i, j) = mma_bf16(ah, bh[j], acc_(i, j));
+      for (int j = 0; j < NB; ++j) acc_(i, j) = mm(ah, bh[j], acc_(i, j));
     }
   } else {
     u32x4 bh[NB], bl[NB], bm[NB];     // h = hi, l = lo, m = lo2
@@ -545,7 +579,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
-          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false, int FAS = 0, int EPS = 0>
+          bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false, int FAS = 0, int EPS = 0, bool PSX = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
   // EPS (bf16 BNEPI only): the mask mode and the accumulate flag of the fused BatchNorm-backward-reduce epilogue as compile-time
   // constants -- EPS - 1 = 2 * (mode == 4) + accumulate for the modes a ResNet step uses (2: mask recomputed from the BatchNorm
@@ -564,7 +598,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   const bool fa_n32 = FAS ? true : (p.N & 31) == 0;
   // PSB (fp32 storage, three split-bf16 terms): the weight matrix p.w was rewritten by presplit_rows into (hi, lo) bf16
   // planes per 128-byte k-block -- same bytes, same LDS-DMA stream, no splitting work for that operand in the k-loop
-  static_assert(!PSB || (SPL == 3 && sizeof(T) == 4), "pre-split weights: fp32 storage, three terms");
+  // (SPL == 13, the forward: fp16 planes of the weights times 2^F16_WSCALE_LOG2 -- undone on the accumulators after the k-loop.)
+  // PSX: the GATHERED operand p.x is kept in the same pre-split block format by its producer (an elementwise kernel): with PSB
+  // and PSX the k-loop is LDS reads + MFMAs only.
+  static_assert(!PSB || ((SPL == 3 || SPL == 13) && sizeof(T) == 4), "pre-split weights: fp32 storage, three terms");
+  static_assert(!PSX || ((SPL == 3 || SPL == 13) && sizeof(T) == 4), "pre-split gathered operand: fp32 storage, three terms");
+  static_assert(SPL != 13 || PSB, "split-fp16 terms need the pre-split (scaled) weight planes");
   static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
   // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
   // before it is stored -- y = act(bf16(conv) * scale + shift + res) with exactly the arithmetic of bn_apply (csrc/bn.hip),
@@ -922,7 +961,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       if (issued < total) issue_next();
       if constexpr (sizeof(T) == 4) {
         if (!DIAG(1))
-          mma_f32_chunks<NI, MI, false, SPL, PSB>(&acc[0][0],
+          mma_f32_chunks<NI, MI, false, SPL, PSB, PSX>(&acc[0][0],
               [&](int i, int ks) { const int r = wn * 64 + i * 16 + fl; return Bs[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))]; },
               [&](int i, int ks) { const int r = wm * (MI * 16) + i * 16 + fl; return As[buf * STG + r * 8 + ((ks * 4 + g) ^ (r & 7))]; });
       } else
@@ -956,6 +995,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     if (DIAG(4)) {
       if (acc[0][0][0] == 12345.678f) Y[0] = (T)0;     // keeps the accumulators live
       continue;
+    }
+    if constexpr (SPL == 13) {                          // the fp16 weight planes carry 2^F16_WSCALE_LOG2 (exact to undo)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] *= (1.0f / (float)(1 << F16_WSCALE_LOG2));
     }
     if (part) {
       // split tail: fp32 accumulators travel lane-linear ([fragment][thread] float4: fully coalesced both ways).
@@ -2257,14 +2302,22 @@ __global__ __launch_bounds__(256) void conv_pivot_row(const float* __restrict__ 
 // chunk g (g < 4) = hi of the eight values lane group g reads in a k-step (c_g, then c_{4+g}); chunk 4 + g = their lo
 // = bf16(x - hi).  Same bytes, same addresses per block, so the LDS-DMA stream and the swizzle of the consumer do not change;
 // its two fragment reads (chunks g and 4 + g) return the operands split_terms2 would have produced -- bit for bit.
-__global__ __launch_bounds__(256) void presplit_rows(const float* __restrict__ src, uint32_t* __restrict__ dst, long long nblocks) {
+// F16: fp16 planes of scale * x (scale a power of two: the split-fp16 forward's weights, F16_WSCALE_LOG2).
+template <bool F16>
+__global__ __launch_bounds__(256) void presplit_rows(const float* __restrict__ src, uint32_t* __restrict__ dst, long long nblocks, float scale) {
   const long long i = blockIdx.x * 256ll + threadIdx.x;       // one output chunk per thread
   if (i >= nblocks * 8) return;
   const long long blk = i >> 3;
   const int c = (int)(i & 7), gq = c & 3;
-  const u32x4 c0 = *(const u32x4*)(src + blk * 32 + gq * 4), c1 = *(const u32x4*)(src + blk * 32 + 16 + gq * 4);
+  u32x4 c0 = *(const u32x4*)(src + blk * 32 + gq * 4), c1 = *(const u32x4*)(src + blk * 32 + 16 + gq * 4);
   u32x4 hi, lo;
-  split_terms2(c0, c1, hi, lo);
+  if constexpr (F16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c0[e] = __float_as_uint(__uint_as_float(c0[e]) * scale); c1[e] = __float_as_uint(__uint_as_float(c1[e]) * scale); }
+    split_terms2_f16(c0, c1, hi, lo);
+  } else {
+    split_terms2(c0, c1, hi, lo);
+  }
   *(u32x4*)(dst + i * 4) = (c < 4) ? hi : lo;
 }
 
@@ -2794,7 +2847,8 @@ struct PresplitScratch { hipStream_t stream; void* buf; size_t bytes; };
 static PresplitScratch g_presplit[8];
 static int g_presplit_n = 0;
 static int g_last_presplit = 0;          // simclr_conv2d_last_presplit (tests): 1 if the most recent dgrad launch ran PSB
-static const void* presplit_weights(const void* w, long long rows, int K, hipStream_t stream) {
+static int g_igemm_fail = 0;             // set by launch_igemm_one when a launch cannot honour its operand format (pre-split input without PSB)
+static const void* presplit_weights(const void* w, long long rows, int K, hipStream_t stream, bool f16 = false) {
   const char* e = getenv("SIMCLR_F32_PRESPLIT");
   if ((e && atoi(e) == 0) || K % 32 != 0 || rows <= 0) return nullptr;
   if (dry_run()) return w;                           // decision only
@@ -2815,8 +2869,10 @@ static const void* presplit_weights(const void* w, long long rows, int K, hipStr
     sc->bytes = want;
   }
   const long long nblocks = rows * (K / 32);
-  hipLaunchKernelGGL(presplit_rows, dim3((unsigned)ceil_div(nblocks * 8, 256)), dim3(256), 0, stream,
-                     (const float*)w, (uint32_t*)sc->buf, nblocks);
+  if (f16) hipLaunchKernelGGL(presplit_rows<true>, dim3((unsigned)ceil_div(nblocks * 8, 256)), dim3(256), 0, stream,
+                              (const float*)w, (uint32_t*)sc->buf, nblocks, (float)(1 << F16_WSCALE_LOG2));
+  else hipLaunchKernelGGL(presplit_rows<false>, dim3((unsigned)ceil_div(nblocks * 8, 256)), dim3(256), 0, stream,
+                          (const float*)w, (uint32_t*)sc->buf, nblocks, 1.0f);
   return sc->buf;
 }
 
@@ -2927,6 +2983,14 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
         if (ws) { p.w = ws; psb = true; g_last_presplit = 1; }
       }
     }
+    if (p.x_ps && !psb) { g_igemm_fail = 1; return; }      // a pre-split operand cannot be read as floats: refuse (the entry point reports it)
+    // split-fp16 forward (13): fp16 weight planes times 2^F16_WSCALE_LOG2, once per launch; no scratch -> six bf16 terms
+    if constexpr (sizeof(T) == 4 && MODE == MODE_FWD) {
+      if (p.split == 13) {
+        const void* ws = presplit_weights(p.w, p.N, p.K, stream, true);
+        if (ws) { p.w = ws; psb = true; } else p.split = 6;
+      }
+    }
     // fused BatchNorm-backward-reduce epilogue with its mask mode / accumulate flag compiled in (EPS instantiations, bf16):
     // 1 = (mode 2, store), 3 = (mode 4, store), 4 = (mode 4, accumulate); SIMCLR_BNEPI_SPECIAL=0 (read per launch) = generic
     int eps = 0;
@@ -2940,7 +3004,10 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
 #define LPX(BNv, STv, BEv, EXv)                                                                                              \
     do {                                                                                                                     \
       if constexpr (sizeof(T) == 4) {                                                                                        \
-        if (psb) { if constexpr (MODE == MODE_DGRAD) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3, false, true>), dim3(pg), dim3(256), plds, stream, p); } \
+        if (psb && p.x_ps) { if constexpr (MODE == MODE_DGRAD && !(EXv)) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, false, false, false, 3, false, true, 0, 0, true>), dim3(pg), dim3(256), plds, stream, p); \
+                             else g_igemm_fail = 1; } \
+        else if (psb) { if constexpr (MODE == MODE_DGRAD) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3, false, true>), dim3(pg), dim3(256), plds, stream, p); \
+                   else if constexpr (!(BEv) && !(EXv)) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, false, false, false, false, 13, false, true>), dim3(pg), dim3(256), plds, stream, p); } \
         else if (p.split == 3) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 3>), dim3(pg), dim3(256), plds, stream, p); \
         else if (p.split == 6) SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv, false, false, 6>), dim3(pg), dim3(256), plds, stream, p); \
         else SIMCLR_LAUNCH((conv_igemm_persistent<T, MODE, 128, BNv, 4, 2, STv, BEv, EXv>), dim3(pg), dim3(256), plds, stream, p); \
@@ -3009,6 +3076,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
 #undef LPE
     return;
   }
+  if (p.x_ps) { g_igemm_fail = 1; return; }
 #define L(BNv, STv)                                                                                    \
   do {                                                                                                 \
     if (no_glds) SIMCLR_LAUNCH((conv_igemm<T, MODE, BNv, STv, false>), dim3(grid), dim3(256), lds, stream, p); \
@@ -3076,8 +3144,8 @@ extern "C" {
 // default), 3 = hi*hi + hi*lo + lo*hi (~2^-17 relative per product), 6 = all terms of weight >= 2^-18 (fp32 level).
 // Storage stays fp32; bf16 launches are unaffected.  Process-wide; returns 1 on a bad argument.
 int simclr_set_f32_matmul(int fwd_terms, int bwd_terms) {
-  SIMCLR_CHECK_ARG((fwd_terms == 0 || fwd_terms == 3 || fwd_terms == 6) && (bwd_terms == 0 || bwd_terms == 3 || bwd_terms == 6),
-                   "set_f32_matmul: terms must be 0, 3 or 6 (got %d, %d)", fwd_terms, bwd_terms);
+  SIMCLR_CHECK_ARG((fwd_terms == 0 || fwd_terms == 3 || fwd_terms == 6 || fwd_terms == 13) && (bwd_terms == 0 || bwd_terms == 3 || bwd_terms == 6),
+                   "set_f32_matmul: terms must be 0, 3 or 6 (forward also 13 = three split-fp16 terms) (got %d, %d)", fwd_terms, bwd_terms);
   g_f32_terms_fwd = fwd_terms;
   g_f32_terms_bwd = bwd_terms;
   return 0;
@@ -3208,6 +3276,11 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
 int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulate, int V, int IH,
                         int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
                         int dtype, hipStream_t stream) {
+  // dtype | SIMCLR_FMT_PS_IN (fp32, three bf16 backward terms, Cout a multiple of 32): dy is in the pre-split block format (common.h)
+  const bool dy_ps = (dtype & SIMCLR_FMT_PS_IN) != 0;
+  dtype &= 0xff;
+  SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && g_f32_terms_bwd == 3 && Cout % 32 == 0),
+                   "conv2d_dgrad: a pre-split dy needs fp32 storage, three backward terms (simclr_set_f32_matmul) and Cout %% 32 == 0");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0, "conv2d_dgrad: Cout=%d must be a multiple of %d", Cout, 8 * epc);
@@ -3221,8 +3294,11 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
   p.V = V; p.IH = OH; p.IW = OW; p.IC = Cout; p.OH = IH; p.OW = IW; p.N = Cin;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cout;
   p.M = V * IH * IW; p.K = KH * KW * Cout;
+  p.x_ps = dy_ps ? 1 : 0;
+  g_igemm_fail = 0;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
   else launch_igemm<float, MODE_DGRAD>(p, stream);
+  SIMCLR_CHECK_ARG(!g_igemm_fail, "conv2d_dgrad: no kernel for a pre-split dy on this launch path (pre-split weights unavailable?)");
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -3237,6 +3313,10 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
                            const float* bn_mean, const float* bn_rstd, int mask_mode, float* stats, int nslot,
                            int V, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
                            int stride, int pad, int dtype, hipStream_t stream) {
+  const bool dy_ps = (dtype & SIMCLR_FMT_PS_IN) != 0;          // see simclr_conv2d_dgrad
+  dtype &= 0xff;
+  SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && g_f32_terms_bwd == 3 && Cout % 32 == 0),
+                   "conv2d_dgrad_bn: a pre-split dy needs fp32 storage, three backward terms (simclr_set_f32_matmul) and Cout %% 32 == 0");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_bn: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0, "conv2d_dgrad_bn: Cout=%d must be a multiple of %d", Cout, 8 * epc);
@@ -3256,8 +3336,11 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   p.M = V * IH * IW; p.K = KH * KW * Cout;
   p.bn_x = bn_x; p.bn_mask = bn_mask; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
   p.bn_mean = bn_mean; p.bn_rstd = bn_rstd; p.bn_mode = mask_mode;
+  p.x_ps = dy_ps ? 1 : 0;
+  g_igemm_fail = 0;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_DGRAD>(p, stream);
   else launch_igemm<float, MODE_DGRAD>(p, stream);
+  SIMCLR_CHECK_ARG(!g_igemm_fail, "conv2d_dgrad_bn: no kernel for a pre-split dy on this launch path (pre-split weights unavailable?)");
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -3646,7 +3729,7 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
   } else {
     // fp32 storage: the forward terms of simclr_set_f32_matmul (0 = exact fp32 MFMA; SIMCLR_STEM_SPLIT=0 keeps the exact kernel)
     static const bool stem_split_on = !getenv("SIMCLR_STEM_SPLIT") || atoi(getenv("SIMCLR_STEM_SPLIT")) != 0;
-    const int spl = stem_split_on ? g_f32_terms_fwd : 0;
+    const int spl = stem_split_on ? (g_f32_terms_fwd == 13 ? 6 : g_f32_terms_fwd) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
 #define LSF(STv)                                                                                              \
     do {                                                                                                       \
       if (spl == 3) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 3>), grid, dim3(256), lds, stream, p);    \

@@ -62,7 +62,8 @@ _DEFS = [
     ('f32_matmul', 'exact', str, "MI355X build, compute_dtype='f32' only: matrix arithmetic of the fp32 convolutions / dense layers. "
                                   "'exact' = fp32-input MFMA (1/16 of the bf16 rate); 'bf16x3' / 'bf16x6' = every fp32 product as 3 / 6 "
                                   "bf16 MFMA terms with fp32 accumulation (fp32 storage everywhere); 'bf16x6_3' = 6 terms forward, 3 "
-                                  "backward (the fast parity mode: forward at fp32 level, gradients at ~2^-17).  Ignored (exact) when "
+                                  "backward (forward at fp32 level, gradients at ~2^-17); 'f16x3_3' = 3 split-FP16 terms forward (11-bit pieces: ~2^-22 per "
+                                  "product at half the MFMA work of six bf16 terms), 3 bf16 terms backward -- the fast parity mode.  Ignored (exact) when "
                                   "compute_dtype='bf16': fp32 heads on a bf16 encoder always run the exact fp32-input MFMA."),
     ('head_dtype', 'same', str, "MI355X build: dtype of the projection / supervised heads: 'same' (= compute_dtype) or 'f32' "
                                 "(the heads are 0.2 % of the FLOPs; fp32 there keeps the loss gradient exact)."),

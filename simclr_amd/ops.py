@@ -436,7 +436,9 @@ class _StatsArena:
 _ARENA = _StatsArena()
 
 
-F32_MATMUL_TERMS = {'exact': (0, 0), 'bf16x3': (3, 3), 'bf16x6': (6, 6), 'bf16x6_3': (6, 3)}
+# (forward terms, backward terms) of simclr_set_f32_matmul; 13 = three split-FP16 terms (11-bit pieces: the accuracy of six bf16
+# terms at half the MFMA work; forward only -- gradients span too many binades for fp16 pieces)
+F32_MATMUL_TERMS = {'exact': (0, 0), 'bf16x3': (3, 3), 'bf16x6': (6, 6), 'bf16x6_3': (6, 3), 'f16x3_3': (13, 3)}
 
 
 def set_f32_matmul(mode):

@@ -65,6 +65,21 @@ def check_probes():
         for r in range(4):
             got[(l >> 4) * 4 + r, l & 15] = d[l, r]
     out.append(_res('probe_mfma_f32_16x16x4_layout', got, a.double() @ b.double(), 1e-6))
+    # v_mfma_f32_16x16x32_f16: the bf16 layout, and SUBNORMAL fp16 inputs must take part in the products (the lo pieces of the
+    # split-fp16 forward, csrc/conv.hip split_pair<true>, fall below 2^-14 for |x| < 2^-3)
+    for tag, sa in (('normal', 1.0), ('subnormal_a', 2.0 ** -18)):
+        a = (torch.randn(16, 32, generator=g) * sa).half()
+        b = torch.randn(32, 16, generator=g).half()
+        o = torch.zeros(64 * 4, device=DEV)
+        ad, bd = a.to(DEV).view(torch.int16), b.to(DEV).view(torch.int16)
+        lib().probe(3, ops._p(ad), ops._p(bd), ops._p(o), ops._s())
+        d = o.cpu().view(64, 4)
+        ref = a.double() @ b.double()
+        got = torch.zeros(16, 16, dtype=torch.float64)
+        for l in range(64):
+            for r in range(4):
+                got[(l >> 4) * 4 + r, l & 15] = d[l, r]
+        out.append(_res('probe_mfma_f16_16x16x32_%s' % tag, got, ref, 1e-5))
     return out
 
 
@@ -232,9 +247,11 @@ def _check_conv(V, H, W, Cin, Cout, k, stride, dtype, seed, matmul):
     dw = ops.conv2d_wgrad(xd, dyd, k, k, stride, pad)
     torch.cuda.synchronize()
     tag = 'V%d %dx%d %d->%d k%d s%d %s%s' % (V, H, W, Cin, Cout, k, stride, str(dtype).split('.')[-1], '' if matmul == 'exact' else ' ' + matmul)
-    t = _tol(dtype) * (2 if matmul == 'bf16x3' else 1)
-    tw = (2e-5 if dtype == torch.float32 else 1e-4) * (2 if matmul == 'bf16x3' else 1)
-    res = [_res('conv_fwd ' + tag, y, y_ref, t),
+    b3 = matmul in ('bf16x3', 'bf16x6_3', 'f16x3_3')       # three bf16 terms in the backward GEMMs
+    tf = _tol(dtype) * (2 if matmul == 'bf16x3' else 1)   # forward: 'f16x3_3' (three split-fp16 terms) is held to the exact mode's gate
+    t = _tol(dtype) * (2 if b3 else 1)
+    tw = (2e-5 if dtype == torch.float32 else 1e-4) * (2 if b3 else 1)
+    res = [_res('conv_fwd ' + tag, y, y_ref, tf),
            _res('conv_stats_sum ' + tag, sums[0], y_ref.sum((0, 1, 2)), 1e-4, 1e-3 * float(y_ref.abs().sum((0, 1, 2)).max())),
            _res('conv_stats_sq ' + tag, sums[1], (y_ref ** 2).sum((0, 1, 2)), 1e-4),
            _res('conv_dgrad ' + tag, dx, dx_ref, t),
@@ -348,7 +365,7 @@ def _check_stem(V, H, k, stride, Cout, dtype, seed, matmul):
     tag = 'V%d %d k%d s%d ->%d %s%s' % (V, H, k, stride, Cout, str(dtype).split('.')[-1], '' if matmul == 'exact' else '/' + matmul)
     t = _tol(dtype)
     y_ref = yr.detach().permute(0, 2, 3, 1)
-    bwd_scale = 2.0 if matmul in ('bf16x3', 'bf16x6_3') else 1.0          # three-term backward arithmetic: ~2^-17 per product
+    bwd_scale = 2.0 if matmul in ('bf16x3', 'bf16x6_3', 'f16x3_3') else 1.0          # three-term backward arithmetic: ~2^-17 per product
     fwd_scale = 4.0 if matmul == 'bf16x3' else 1.0
     return [_res('stem_fwd ' + tag, y, y_ref, t * fwd_scale),
             _res('stem_stats_sq ' + tag, sums[1], (y_ref ** 2).sum((0, 1, 2)), 1e-4),

@@ -100,21 +100,23 @@ def test_conv_fwd_dgrad_wgrad(V, H, Cin, Cout, k, s, dtype):
     _assert(gc.check_conv(V, H, H, Cin, Cout, k, s, dtype))
 
 
-@pytest.mark.parametrize('matmul', ['bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('matmul', ['bf16x3', 'bf16x6', 'f16x3_3'])
 @pytest.mark.parametrize('V,H,Cin,Cout,k,s', [CONV_CASES[i] for i in (0, 1, 2, 3, 4, 5, 8, 10)])
 def test_conv_f32_split_bf16_matmul(V, H, Cin, Cout, k, s, matmul):
-    """The fast parity mode (simclr_set_f32_matmul): fp32 storage, every product as 3 / 6 bf16 MFMA terms, against float64."""
+    """The fast parity modes (simclr_set_f32_matmul): fp32 storage, every product as 3 / 6 bf16 MFMA terms -- or, forward only, 3 split-fp16
+    terms ('f16x3_3': held to the exact mode's forward gate) -- against float64."""
     from tests import gpu_checks as gc
     _assert(gc.check_conv(V, H, H, Cin, Cout, k, s, F32, matmul=matmul))
 
 
 @pytest.mark.parametrize('V,H,Cin,Cout,k,s,bn_case', [(1024, 14, 256, 256, 3, 1, (2, 0)), (256, 56, 256, 64, 1, 1, (3, 1)),
                                                        (256, 56, 128, 128, 3, 2, None), (256, 28, 128, 512, 1, 1, (1, 0))])
-def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case):
-    """Split-bf16 arithmetic on the persistent / XCD-mapped code paths the benchmark runs (full-tensor float64 reference)."""
+@pytest.mark.parametrize('matmul', ['bf16x6_3', 'f16x3_3'])
+def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case, matmul):
+    """Split-bf16 / split-fp16 arithmetic on the persistent / XCD-mapped code paths the benchmark runs (full-tensor float64 reference)."""
     from simclr_amd import ops
     from tests import gpu_checks as gc
-    ops.set_f32_matmul('bf16x6_3')
+    ops.set_f32_matmul(matmul)
     _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, F32, bn_case=bn_case, bwd_tol_scale=2.0))
 
 
@@ -176,7 +178,7 @@ PIN_MODEL_TAGS = ['r18_cifar', 'r50', 'r50_sk', 'r34_w2', 'r18_localbn', 'r18_im
 PIN_STEP_TAGS = ['r18_cifar', 'r50_sk', 'r18_img', 'r50_img', 'r50']
 
 
-@pytest.mark.parametrize('matmul', ['exact', 'bf16x6_3'])
+@pytest.mark.parametrize('matmul', ['exact', 'bf16x6_3', 'f16x3_3'])
 @pytest.mark.parametrize('tag', PIN_MODEL_TAGS)
 def test_product_model_matches_the_reference_source_fixtures(tag, matmul):
     """simclr_amd.model.Model itself (train + inference forward, moving statistics, add_weight_decay; variables
@@ -189,7 +191,7 @@ def test_product_model_matches_the_reference_source_fixtures(tag, matmul):
     _assert(res)
 
 
-@pytest.mark.parametrize('matmul', ['exact', 'bf16x6_3'])
+@pytest.mark.parametrize('matmul', ['exact', 'bf16x6_3', 'f16x3_3'])
 @pytest.mark.parametrize('tag', PIN_STEP_TAGS)
 def test_product_single_step_matches_the_reference_source_fixtures(tag, matmul):
     """simclr_amd.run.make_single_step against tf2/run.py:557-622 compiled from its own source: scaled loss and all seven metrics
@@ -441,11 +443,12 @@ def test_train_step_resnet50_224_batch32_fixed_thresholds(compute_dtype):
     torch.cuda.empty_cache()
 
 
-def test_train_step_resnet50_224_batch32_fast_parity_mode():
-    """the same step with fp32 storage and split-bf16 matrix arithmetic (six terms forward, three
-    backward) must pass the FP32 gates -- north_star's 1e-3 loss / 1e-5 embeddings included."""
+@pytest.mark.parametrize('matmul', ['bf16x6_3', 'f16x3_3'])
+def test_train_step_resnet50_224_batch32_fast_parity_mode(matmul):
+    """the same step with fp32 storage and split matrix arithmetic (six bf16 terms forward -- or three fp16
+    terms, round 6 -- and three bf16 terms backward) must pass the FP32 gates -- north_star's 1e-3 loss / 1e-5 embeddings included."""
     from tests import gpu_checks as gc
-    res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f32', f32_matmul='bf16x6_3')
+    res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f32', f32_matmul=matmul)
     for r in res:
         print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
     _assert(res)
@@ -495,7 +498,7 @@ def test_stem_conv(V, H, k, s, dtype):
     _assert(gc.check_stem(V, H, k, s, 64, dtype))
 
 
-@pytest.mark.parametrize('matmul', ['bf16x6_3', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('matmul', ['bf16x6_3', 'bf16x3', 'bf16x6', 'f16x3_3'])
 @pytest.mark.parametrize('V,H,k,s', [(4, 32, 7, 2), (4, 16, 3, 1), (2, 224, 7, 2), (2, 33, 7, 2), (6, 48, 3, 2)])
 def test_stem_conv_f32_split_bf16_matmul(V, H, k, s, matmul):
     """The stem in the fast parity mode (round 5: 3.9 + 5.1 ms of the 190 ms fp32-storage step ran on the exact fp32 MFMA): split-bf16 forward
