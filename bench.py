@@ -12,23 +12,29 @@ is resident in HBM before the timed region.  One "image" = one dataset image = t
 (BASELINE.md).  Per-GPU batch is fixed at 512 images (BASELINE.json configs[1] at N=1,
 configs[2] = global 4096 at N=8) => weak scaling; `value` = global_batch * K / max-over-ranks time.
 
+WHICH MODE IS THE HEADLINE (round 6): the top-level value / dtype / roofline belong to the fastest mode whose outputs meet north_star's
+tolerances (loss 1e-3 relative, normalised embeddings 1e-5 absolute against the reference-source fixtures, measured in this run:
+`north_star_met`, `parity`): fp32 storage and accumulation, every product as three 16-bit-piece MFMA terms (fp16 pieces forward, bf16
+pieces backward) -- `--dtype f32 --f32_matmul f16x3_3`, the defaults.  The bf16-storage speed mode (narrower than the reference's fp32;
+misses the tolerances) is measured beside it as `speed_mode`, the exact fp32-input MFMA as `f32_mode`, round 5's six-bf16-term forward
+as `parity_mode_bf16x6`; `--dtype bf16` makes the speed mode the headline of a run.
+
 Timing protocol: W un-timed warm-up steps, then EXACTLY K steps between barrier +
 device-synchronize pairs (wall clock, max over ranks -> `value`).  Inside the timed loop only ONE HIP
 event per step boundary is recorded (on the launch stream) -> `step_ms` p10 / median / p90.  The
 per-launch HIP-event profiler (2 events per kernel launch) runs in SEPARATE instrumented steps right
-after the timed region, same process, same data -> `roofline`, `kernels`, `ntxent`.
+after the timed region, same process, same data -> `roofline`, `families`, `kernels`, `ntxent`.
 
 JSON line extras:
-  roofline      -- dominant kernel family (most GPU time): algorithmic FLOPs (2*M*N*K per launch) and
-                   SURVEY 8(d)'s MINIMUM bytes ((H^2*Cin + Ho^2*Cout + k^2*Cin*Cout) * elt per conv pass) over
-                   the summed launch time.  `frac` is quoted against the roof that binds at that arithmetic
-                   intensity (HBM 8 TB/s below the ridge, dense bf16 MFMA 2.5 PFLOP/s above); the
-                   as-implemented byte count (fused BN-epilogue operands included) is under `impl_*` keys and the
-                   PMC traffic per launch (profiles/, separate rocprofv3 --pmc passes) under `traffic` when its
-                   launch count matches this run's.
+  roofline      -- dominant kernel family (most GPU time).  Split modes: SURVEY 8(d)'s MINIMUM bytes at 4 B / element against 8 TB/s and
+                   the 16-bit MFMA work (fp32 products x terms) against 2.5 PFLOP/s, whichever costs more time is the binding roof
+                   (`families` gives forward / data gradient / weight gradient separately).  bf16 / exact fp32: algorithmic FLOPs
+                   (2*M*N*K per launch) and minimum bytes over the summed launch time, roof chosen by the arithmetic intensity; the
+                   as-implemented byte count is under `impl_*`.  `traffic` = PMC bytes per launch, sampled by two rocprofv3 --pmc child
+                   runs of this script in the same mode.
   ntxent        -- the fused NT-Xent forward+backward kernels (north_star's named kernel): us, algorithmic
                    GB/s, TFLOP/s and fraction of the fp32-input MFMA peak.
-  f32_mode      -- the same step in the fp32 parity mode (the mode that meets north_star's tolerances).
+  speed_mode / f32_mode / parity_mode_bf16x6 -- the same step in the other modes (N = 1), same K / W.
   allgather     -- N>1: bandwidth of collective A (all-gather of the hidden block) and of the gradient all-reduce.
   cpu_baseline  -- the CPU oracle (torch-CPU restatement of the TF2 reference; TensorFlow is not installed)
                    timed on this box's host cores (rank 0, N=1 only) on BASELINE configs[0] (ResNet-18,
@@ -380,8 +386,10 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--per_gpu_batch', type=int, default=512)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--f32_matmul', default='exact', choices=['exact', 'bf16x3', 'bf16x6', 'bf16x6_3', 'f16x3_3'],
+    ap.add_argument('--dtype', default='f32', choices=['bf16', 'f32'],
+                    help="storage type of the headline step; default f32 with --f32_matmul f16x3_3 = the fastest mode that meets north_star's "
+                         "tolerances (the bf16 speed mode is measured beside it as `speed_mode`)")
+    ap.add_argument('--f32_matmul', default='f16x3_3', choices=['exact', 'bf16x3', 'bf16x6', 'bf16x6_3', 'f16x3_3'],
                     help='--dtype f32 only: matrix arithmetic of the fp32 step (FLAGS.f32_matmul)')
     ap.add_argument('--resnet_depth', type=int, default=50)
     ap.add_argument('--image_size', type=int, default=224)
@@ -390,7 +398,7 @@ def main():
     ap.add_argument('--use_blur', action='store_true', help='include the on-device batch_random_blur (reference default)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_kernel_events', action='store_true', help='skip the instrumented steps (rocprof runs)')
-    ap.add_argument('--no_f32', action='store_true', help='skip the fp32 parity-mode measurement')
+    ap.add_argument('--no_f32', '--no_side', dest='no_f32', action='store_true', help='skip the side measurements of the other modes (bf16 speed mode, exact fp32, bf16x6_3)')
     ap.add_argument('--no_pmc', action='store_true', help='do not sample HBM traffic (two rocprofv3 --pmc child runs of this script)')
     ap.add_argument('--no_parity', action='store_true', help='skip the in-run parity measurement against the reference-source fixtures')
     ap.add_argument('--prof_steps', type=int, default=3)
@@ -474,19 +482,38 @@ def main():
     if rank != 0:
         return
 
-    peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
     default_cfg = (args.resnet_depth == 50 and args.image_size == 224 and args.width_multiplier == 1 and
                    args.sk_ratio == 0 and args.per_gpu_batch == 512)
     flop_img = FLOP_PER_IMAGE_BY_MODEL.get((args.resnet_depth, args.width_multiplier, args.sk_ratio > 0)) if args.image_size == 224 else None
-    roofline, kernels, ntx = None, {}, None
-    if prof is not None:
-        summ = prof.summary()
-        P = args.prof_steps
-        for fam, d in summ.items():
-            kernels[fam] = dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3),
-                                tflops=round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2) if d['ms'] > 0 else None,
-                                alg_gbps=round(d['bytes'] / (d['ms'] * 1e-3) / 1e9, 1) if d['ms'] > 0 else None)
-        # dominant family = most GPU time; the fwd and dgrad launches are the same kernel template
+    from simclr_amd import ops as _o
+
+    def mode_label(dtype, matmul):
+        return 'bf16' if dtype == 'bf16' else 'f32/' + matmul
+
+    def mfma_terms(t):
+        """16-bit-piece MFMA products per fp32 product: 3 / 6 bf16 terms, 13 = three fp16 terms, 0 = the exact fp32-input MFMA (1/16 rate)."""
+        return 3 if t == 13 else (t or 16)
+
+    def step_mfma_frac(v, dtype, matmul):
+        """whole-step matrix work of the mode against its MFMA peak: bf16 = FLOPs / 2.5 PF; split modes = 16-bit MFMA work (forward third x
+        forward terms + two backward thirds x backward terms) / 2.5 PF; exact fp32 = FLOPs / the fp32-input MFMA peak."""
+        if not flop_img:
+            return None
+        if dtype == 'bf16':
+            return round(v * flop_img / (world * PEAK_BF16_TFLOPS * 1e12), 4)
+        tf, tb = _o.F32_MATMUL_TERMS[matmul]
+        if tf == 0 and tb == 0:
+            return round(v * flop_img / (world * PEAK_F32_TFLOPS * 1e12), 4)
+        return round(v * flop_img * (mfma_terms(tf) + 2.0 * mfma_terms(tb)) / 3.0 / (world * PEAK_BF16_TFLOPS * 1e12), 4)
+
+    def kernel_table(summ, P):
+        return {fam: dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3),
+                          tflops=round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2) if d['ms'] > 0 else None,
+                          alg_gbps=round(d['bytes'] / (d['ms'] * 1e-3) / 1e9, 1) if d['ms'] > 0 else None) for fam, d in summ.items()}
+
+    def plain_roofline(summ, P, dtype, pmc_args=None):
+        """bf16 storage / exact fp32: dominant family = most GPU time (the fwd and dgrad launches are the same kernel template), algorithmic
+        FLOPs and SURVEY 8(d) minimum bytes over the summed launch time, PMC traffic of the family sampled by two child runs."""
         fams = {'conv_igemm': [k for k in summ if k.startswith('conv_igemm')], 'conv_wgrad': ['conv_wgrad']}
         best, best_ms = None, -1.0
         for name, members in fams.items():
@@ -498,39 +525,85 @@ def main():
         nl = sum(summ[m]['launches'] for m in members)
         by = sum(summ[m]['bytes'] for m in members)
         impl = sum(summ[m]['impl_bytes'] for m in members)
-        roofline = make_roofline(best, fl, by, impl, best_ms, nl, P, peak)
-        # HBM traffic per launch of the same kernel family: from the committed rocprofv3 --pmc passes (FETCH_SIZE /
-        # WRITE_SIZE collected separately, FETCH x2 for wide loads); PMC counters cannot be sampled from inside this
-        # process, so this stays null unless the committed file describes this family, configuration and launch count
-        import glob
-        cands = sorted(glob.glob(os.path.join(HERE, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))
-        tpath = cands[-1] if cands else ''
-        sampled = None
-        if default_cfg and args.dtype == 'bf16' and world == 1 and not args.no_pmc:
-            sampled = sample_pmc_traffic(best)
+        r = make_roofline(best, fl, by, impl, best_ms, nl, P, PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS)
+        sampled = sample_pmc_traffic(best, extra_args=pmc_args) if pmc_args is not None else None
         if sampled:
-            per_launch = sampled['family_bytes_per_step'] / max(roofline['launches_per_step'], 1)
-            roofline['traffic'] = round(per_launch)
-            roofline['traffic_measured_in_run'] = True
-            roofline['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this script on this box '
-                                          '(separate passes, FETCH x2 for 16 B/lane loads, MI355X_MICROARCH.md)')
-            roofline['traffic_kernel_dispatches_per_step'] = sampled['kernel_dispatches_per_step']
-            roofline['traffic_over_algorithmic'] = round(per_launch / roofline['algorithmic_bytes_per_launch'], 3)
-            roofline['step_total_traffic_gb'] = round(sampled['step_total_bytes'] / 1e9, 2)
-        elif default_cfg and args.dtype == 'bf16' and tpath:
-            try:
-                tj = json.load(open(tpath))
-                # PMC bytes of the family per STEP (committed rocprofv3 passes of this same command) divided by THIS
-                # run's launches per step, so `traffic` and `achieved` use one definition of a launch (= one library
-                # call; a strided dgrad call dispatches one kernel per output-parity class, hence more dispatches)
-                if tj.get('kernel') == best and tj.get('family_bytes_per_step'):
-                    per_launch = tj['family_bytes_per_step'] / max(roofline['launches_per_step'], 1)
-                    roofline['traffic'] = round(per_launch)
-                    roofline['traffic_source'] = 'profiles/' + os.path.basename(tpath) + ' (committed rocprofv3 --pmc passes of this command; not sampled in this run)'
-                    roofline['traffic_kernel_dispatches_per_step'] = tj.get('kernel_dispatches_per_step')
-                    roofline['traffic_over_algorithmic'] = round(per_launch / roofline['algorithmic_bytes_per_launch'], 3)
-            except Exception:
-                pass
+            per_launch = sampled['family_bytes_per_step'] / max(r['launches_per_step'], 1)
+            r.update(traffic=round(per_launch), traffic_measured_in_run=True,
+                     traffic_source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this script in this mode on this box '
+                                    '(separate passes, FETCH x2 for 16 B/lane loads, MI355X_MICROARCH.md)',
+                     traffic_kernel_dispatches_per_step=sampled['kernel_dispatches_per_step'],
+                     traffic_over_algorithmic=round(per_launch / r['algorithmic_bytes_per_launch'], 3),
+                     step_total_traffic_gb=round(sampled['step_total_bytes'] / 1e9, 2))
+        return r
+
+    def split_roofline(sm, P, matmul, pmc_args=None):
+        """fp32 storage / split 16-bit-piece matrix arithmetic.  Bytes: SURVEY 8(d)'s minimum at 4 B / element.  Matrix work: every fp32
+        product runs as `terms` 16-bit MFMAs (forward: 3 fp16 or 6 bf16; backward: 3 bf16), so the MFMA roof of a family is 2.5 PFLOP/s /
+        terms; the binding roof of a family is whichever limit costs more time."""
+        tf, tb = _o.F32_MATMUL_TERMS[matmul]
+        fam_terms = {'conv_igemm_fwd': mfma_terms(tf), 'conv_igemm_dgrad': mfma_terms(tb), 'conv_wgrad': mfma_terms(tb)}
+        fams = {}
+        for k, t in fam_terms.items():
+            if k not in sm or sm[k]['ms'] <= 0:
+                continue
+            d = sm[k]
+            sec = d['ms'] * 1e-3
+            t_mfma = d['flops'] * t / (PEAK_BF16_TFLOPS * 1e12)          # seconds at the dense 16-bit MFMA peak
+            t_hbm = d['bytes'] / (PEAK_HBM_GBPS * 1e9)                   # seconds at the HBM peak
+            fams[k] = dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3), mfma_terms=t,
+                           bound='mfma' if t_mfma >= t_hbm else 'hbm', frac=round(max(t_mfma, t_hbm) / sec, 4),
+                           mfma_frac=round(t_mfma / sec, 4), hbm_frac=round(t_hbm / sec, 4),
+                           fp32_product_tflops=round(d['flops'] / sec / 1e12, 2), mfma_work_tflops=round(d['flops'] * t / sec / 1e12, 2),
+                           alg_gbps=round(d['bytes'] / sec / 1e9, 1), algorithmic_bytes_per_launch=round(d['bytes'] / max(d['launches'], 1)))
+        # dominant family by time: the forward and data-gradient launches are ONE kernel template (conv_igemm_persistent)
+        ig = [k for k in ('conv_igemm_fwd', 'conv_igemm_dgrad') if k in fams]
+        ig_ms = sum(sm[k]['ms'] for k in ig)
+        wg_ms = sm['conv_wgrad']['ms'] if 'conv_wgrad' in fams else -1.0
+        members = ig if ig_ms >= wg_ms else ['conv_wgrad']
+        name = 'conv_igemm' if ig_ms >= wg_ms else 'conv_wgrad'
+        sec = sum(sm[k]['ms'] for k in members) * 1e-3
+        fl = sum(sm[k]['flops'] for k in members)
+        by = sum(sm[k]['bytes'] for k in members)
+        nl = sum(sm[k]['launches'] for k in members)
+        t_mfma = sum(sm[k]['flops'] * fam_terms[k] for k in members) / (PEAK_BF16_TFLOPS * 1e12)
+        t_hbm = by / (PEAK_HBM_GBPS * 1e9)
+        hbm = t_hbm > t_mfma
+        r = dict(bound='hbm' if hbm else 'mfma', kernel=name,
+                 achieved=round(by / sec / 1e9, 1) if hbm else round(t_mfma * PEAK_BF16_TFLOPS / sec, 2),
+                 peak=PEAK_HBM_GBPS if hbm else PEAK_BF16_TFLOPS, unit='GB/s' if hbm else 'TFLOP/s',
+                 unit_note=None if hbm else '16-bit MFMA work: fp32 products x terms (fp16 / bf16 pieces, dense peak 2.5 PFLOP/s either way)',
+                 frac=round(max(t_mfma, t_hbm) / sec, 4), mfma_frac=round(t_mfma / sec, 4), hbm_frac=round(t_hbm / sec, 4),
+                 traffic=None, traffic_measured_in_run=False,
+                 bytes_rule='SURVEY 8(d) minimum at 4 B / element: (input + output + weights) per launch, each read / written once',
+                 algorithmic_bytes_per_launch=round(by / max(nl, 1)), flops_per_launch_avg=fl / max(nl, 1),
+                 fp32_product_tflops=round(fl / sec / 1e12, 2), avg_launch_us=round(sec * 1e6 / max(nl, 1), 2),
+                 launches_per_step=nl // P, ms_per_step=round(sec * 1e3 / P, 3),
+                 measured_over='%d instrumented steps after the timed region of this mode' % P)
+        if pmc_args is not None:
+            sampled = sample_pmc_traffic(name, extra_args=pmc_args)
+            if sampled:
+                per_launch = sampled['family_bytes_per_step'] / max(r['launches_per_step'], 1)
+                r.update(traffic=round(per_launch), traffic_measured_in_run=True,
+                         traffic_source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this script in this mode (separate passes, FETCH x2)',
+                         traffic_kernel_dispatches_per_step=sampled['kernel_dispatches_per_step'],
+                         traffic_over_algorithmic=round(per_launch / r['algorithmic_bytes_per_launch'], 3),
+                         step_total_traffic_gb=round(sampled['step_total_bytes'] / 1e9, 2))
+        other = {k: dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3)) for k, d in sm.items() if k not in fams}
+        return r, fams, other
+
+    def mode_roofline(summ, P, dtype, matmul):
+        pmc_args = ('--dtype', dtype, '--f32_matmul', matmul) if (default_cfg and world == 1 and not args.no_pmc) else None
+        if dtype == 'f32' and matmul != 'exact':
+            return split_roofline(summ, P, matmul, pmc_args)
+        return plain_roofline(summ, P, dtype, pmc_args), None, None
+
+    roofline, families, other_kernels, kernels, ntx = None, None, None, {}, None
+    if prof is not None:
+        summ = prof.summary()
+        P = args.prof_steps
+        kernels = kernel_table(summ, P)
+        roofline, families, other_kernels = mode_roofline(summ, P, args.dtype, args.f32_matmul)
         if 'ntxent_fwd' in summ and 'ntxent_bwd' in summ:
             # every kernel of the NT-Xent path: the two library calls (3 + 2 kernels) AND the two l2norm kernels around them
             parts = ['ntxent_fwd', 'ntxent_bwd', 'l2norm_fwd', 'l2norm_bwd']
@@ -549,107 +622,55 @@ def main():
                               '`us_events_in_step` = per-call HIP events inside the instrumented training steps',
                        note='bound by the fp32-input matrix pipe, not HBM (AI 384-683 FLOP/B); HBM floor 1.5 us')
 
-    f32_mode = parity_mode = None
-    if world == 1 and args.dtype == 'bf16' and not args.no_f32:
-        # the same step with fp32 storage, same K / W as the headline: (i) f32_mode = exact fp32-input MFMA (1/16 of the
-        # bf16 rate); (ii) parity_mode = the FAST mode that meets north_star's 1e-3 loss / 1e-5 embedding tolerances --
-        # fp32 storage, every product as bf16 MFMA terms with fp32 accumulation (6 terms forward, 3 backward;
-        # tests/test_gpu_kernels.py::test_train_step_resnet50_224_batch32_fast_parity_mode)
+    # ---- the OTHER modes of the same step, same K / W, one GPU: `speed_mode` = bf16 storage (narrower than the reference's fp32: misses
+    # north_star's tolerances, reported not credited), `f32_mode` = exact fp32-input MFMA (1/16 of the 16-bit rate), `parity_mode_bf16x6` =
+    # round 5's tolerance-meeting mode (six bf16 terms forward).  The headline (top-level value) is whatever --dtype / --f32_matmul say:
+    # by default the FASTEST mode that meets the tolerances (fp32 storage, three fp16 terms forward, three bf16 terms backward).
+    side = {}
+    headline = (args.dtype, args.f32_matmul if args.dtype == 'f32' else 'exact')
+    if world == 1 and not args.no_f32:
         del step_fn, data, model
         import gc
 
-        def f32_run(matmul, profile=False):
+        def side_run(dtype, matmul, profile):
             gc.collect()
             torch.cuda.empty_cache()
-            s32, d32, _, m32 = build_step(args, 'f32', None, 1, 0, dev, f32_matmul=matmul)
-            w32, k32 = args.warmup, args.steps
-            for _ in range(w32):
-                f, l = next(d32); s32(f, l)
+            s2, d2, _, m2 = build_step(args, dtype, None, 1, 0, dev, f32_matmul=matmul)
+            w2, k2 = args.warmup, args.steps
+            for _ in range(w2):
+                f, l = next(d2); s2(f, l)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(k32):
-                f, l = next(d32); s32(f, l)
+            for _ in range(k2):
+                f, l = next(d2); s2(f, l)
             torch.cuda.synchronize()
-            e32 = time.perf_counter() - t1
-            from simclr_amd import ops as _o
-            out = dict(value=round(global_batch * k32 / e32, 2), unit='images/s', ms_per_step=round(e32 / k32 * 1e3, 2),
-                       steps=k32, warmup=w32, dtype='f32', f32_matmul=matmul,
-                       bn_statistics='pivoted' if _o.bn_pivot_enabled(torch.float32) else 'raw moments')
+            e2 = time.perf_counter() - t1
+            v = global_batch * k2 / e2
+            out = dict(value=round(v, 2), unit='images/s', ms_per_step=round(e2 / k2 * 1e3, 2), steps=k2, warmup=w2, dtype=dtype,
+                       f32_matmul=matmul if dtype == 'f32' else None, step_mfma_frac=step_mfma_frac(v, dtype, matmul),
+                       bn_statistics=('pivoted' if _o.bn_pivot_enabled(torch.float32) else 'raw moments') if dtype == 'f32' else 'raw moments')
             if profile and not args.no_kernel_events and args.prof_steps > 0:
-                out.update(split_mode_roofline(s32, d32, _o, matmul))
-            del s32, d32, m32
+                pr = _o.KernelProfiler()
+                _o.PROFILER = pr
+                for _ in range(args.prof_steps):
+                    f, l = next(d2); s2(f, l)
+                torch.cuda.synchronize()
+                _o.PROFILER = None
+                sm = pr.summary()
+                r, fams, other = mode_roofline(sm, args.prof_steps, dtype, matmul)
+                out.update(roofline=r, kernels=kernel_table(sm, args.prof_steps))
+                if fams is not None:
+                    out.update(families=fams)
+            del s2, d2, m2
             gc.collect()
             torch.cuda.empty_cache()
             return out
 
-        def split_mode_roofline(s32, d32, _o, matmul):
-            """roofline of the fp32-storage / split-bf16 mode: per-launch HIP events of `prof_steps` instrumented steps.  Bytes: SURVEY
-            8(d)'s minimum at 4 B / element.  Matrix work: every fp32 product runs as `terms` bf16 MFMAs (6 forward, 3 backward), so
-            the MFMA roof of a family is 2.5 PFLOP/s / terms; the binding roof of the family is whichever limit costs more time."""
-            terms = dict(zip(('fwd', 'bwd'), _o.F32_MATMUL_TERMS[matmul]))
-            prof32 = _o.KernelProfiler()
-            _o.PROFILER = prof32
-            for _ in range(args.prof_steps):
-                f, l = next(d32); s32(f, l)
-            torch.cuda.synchronize()
-            _o.PROFILER = None
-            sm = prof32.summary()
-            P = args.prof_steps
-            fam_terms = {'conv_igemm_fwd': terms['fwd'] or 16, 'conv_igemm_dgrad': terms['bwd'] or 16, 'conv_wgrad': terms['bwd'] or 16}
-            fams = {}
-            for k, t in fam_terms.items():
-                if k not in sm or sm[k]['ms'] <= 0:
-                    continue
-                d = sm[k]
-                sec = d['ms'] * 1e-3
-                t_mfma = d['flops'] * t / (PEAK_BF16_TFLOPS * 1e12)          # seconds at the dense bf16 MFMA peak
-                t_hbm = d['bytes'] / (PEAK_HBM_GBPS * 1e9)                   # seconds at the HBM peak
-                fams[k] = dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3), bf16_terms=t,
-                               bound='mfma' if t_mfma >= t_hbm else 'hbm', frac=round(max(t_mfma, t_hbm) / sec, 4),
-                               mfma_frac=round(t_mfma / sec, 4), hbm_frac=round(t_hbm / sec, 4),
-                               fp32_product_tflops=round(d['flops'] / sec / 1e12, 2), bf16_mfma_tflops=round(d['flops'] * t / sec / 1e12, 2),
-                               alg_gbps=round(d['bytes'] / sec / 1e9, 1), algorithmic_bytes_per_launch=round(d['bytes'] / max(d['launches'], 1)))
-            # dominant family by time: the forward and data-gradient launches are ONE kernel template (conv_igemm_persistent)
-            ig = [k for k in ('conv_igemm_fwd', 'conv_igemm_dgrad') if k in fams]
-            ig_ms = sum(sm[k]['ms'] for k in ig)
-            wg_ms = sm['conv_wgrad']['ms'] if 'conv_wgrad' in fams else -1.0
-            members = ig if ig_ms >= wg_ms else ['conv_wgrad']
-            name = 'conv_igemm' if ig_ms >= wg_ms else 'conv_wgrad'
-            sec = sum(sm[k]['ms'] for k in members) * 1e-3
-            fl = sum(sm[k]['flops'] for k in members)
-            by = sum(sm[k]['bytes'] for k in members)
-            nl = sum(sm[k]['launches'] for k in members)
-            t_mfma = sum(sm[k]['flops'] * fam_terms[k] for k in members) / (PEAK_BF16_TFLOPS * 1e12)
-            t_hbm = by / (PEAK_HBM_GBPS * 1e9)
-            hbm = t_hbm > t_mfma
-            r = dict(bound='hbm' if hbm else 'mfma', kernel=name,
-                     achieved=round(by / sec / 1e9, 1) if hbm else round(t_mfma * PEAK_BF16_TFLOPS / sec, 2),
-                     peak=PEAK_HBM_GBPS if hbm else PEAK_BF16_TFLOPS, unit='GB/s' if hbm else 'TFLOP/s (bf16 MFMA work: fp32 products x terms)',
-                     frac=round(max(t_mfma, t_hbm) / sec, 4), mfma_frac=round(t_mfma / sec, 4), hbm_frac=round(t_hbm / sec, 4),
-                     traffic=None, traffic_measured_in_run=False,
-                     bytes_rule='SURVEY 8(d) minimum at 4 B / element: (input + output + weights) per launch, each read / written once',
-                     algorithmic_bytes_per_launch=round(by / max(nl, 1)), flops_per_launch_avg=fl / max(nl, 1),
-                     fp32_product_tflops=round(fl / sec / 1e12, 2), avg_launch_us=round(sec * 1e6 / max(nl, 1), 2),
-                     launches_per_step=nl // P, ms_per_step=round(sec * 1e3 / P, 3),
-                     measured_over='%d instrumented steps after the timed region of this mode' % P)
-            if default_cfg and not args.no_pmc:
-                sampled = sample_pmc_traffic(name, extra_args=('--dtype', 'f32', '--f32_matmul', matmul))
-                if sampled:
-                    per_launch = sampled['family_bytes_per_step'] / max(r['launches_per_step'], 1)
-                    r.update(traffic=round(per_launch), traffic_measured_in_run=True,
-                             traffic_source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this script in this mode (separate passes, FETCH x2)',
-                             traffic_kernel_dispatches_per_step=sampled['kernel_dispatches_per_step'],
-                             traffic_over_algorithmic=round(per_launch / r['algorithmic_bytes_per_launch'], 3),
-                             step_total_traffic_gb=round(sampled['step_total_bytes'] / 1e9, 2))
-            other = {k: dict(launches_per_step=d['launches'] // P, ms_per_step=round(d['ms'] / P, 3)) for k, d in sm.items() if k not in fams}
-            return dict(roofline=r, families=fams, other_kernels=other)
-        f32_mode = f32_run('exact')
-        f32_mode['step_mfma_frac'] = round(f32_mode['value'] * flop_img / (PEAK_F32_TFLOPS * 1e12), 4) if flop_img else None
-        parity_mode = f32_run('bf16x6_3', profile=True)
-        # bf16 MFMA work of the split step: 6 terms on the forward third of the FLOPs, 3 on the two backward thirds
-        parity_mode['step_bf16_mfma_frac'] = round(parity_mode['value'] * flop_img * 4.0 / (PEAK_BF16_TFLOPS * 1e12), 4) if flop_img else None
-        from simclr_amd import ops as _ops
-        _ops.set_f32_matmul('exact')
+        for key, dtype, matmul, profile in (('speed_mode', 'bf16', 'exact', True), ('f32_mode', 'f32', 'exact', False),
+                                            ('parity_mode_bf16x6', 'f32', 'bf16x6_3', False)):
+            if (dtype, matmul) != headline:
+                side[key] = side_run(dtype, matmul, profile)
+        _o.set_f32_matmul('exact')
 
     parity = None
     if world == 1 and not args.no_parity:
@@ -657,9 +678,10 @@ def main():
             del step_fn, data, model
         except NameError:
             pass
-        modes = [('bf16 (value)', 'bf16', 'exact')] if args.dtype == 'bf16' else [(args.f32_matmul, 'f32', args.f32_matmul)]
-        if args.dtype == 'bf16' and not args.no_f32:
-            modes += [('f32_mode', 'f32', 'exact'), ('parity_mode', 'f32', 'bf16x6_3')]
+        modes = [('value (%s)' % mode_label(*headline), headline[0], headline[1])]
+        if not args.no_f32:
+            modes += [(k, d, m) for k, d, m in (('speed_mode', 'bf16', 'exact'), ('f32_mode', 'f32', 'exact'), ('parity_mode_bf16x6', 'f32', 'bf16x6_3'))
+                      if (d, m) != headline]
         try:
             parity = measured_parity(dev, modes)
         except Exception as e:      # a failed side measurement must be visible in the line, not kill it
@@ -694,12 +716,23 @@ def main():
         except Exception as e:      # never let the side measurement break the benchmark line
             augment = dict(error=repr(e))
 
+    met = None
+    if parity and parity.get('modes'):
+        met = bool(next(iter(parity['modes'].values())).get('north_star_met'))
+    dtype_note = {'bf16': 'bf16 storage and MFMA operands, fp32 accumulation (narrower than the reference: misses north_star)',
+                  'f32': 'fp32 storage and accumulation; products: ' + {
+                      'exact': 'fp32-input MFMA', 'bf16x3': '3 bf16-piece MFMA terms', 'bf16x6': '6 bf16-piece MFMA terms',
+                      'bf16x6_3': '6 bf16-piece terms forward, 3 backward',
+                      'f16x3_3': '3 fp16-piece MFMA terms forward (11-bit pieces, ~2^-22 per product), 3 bf16-piece terms backward'}.get(args.f32_matmul, args.f32_matmul)}[args.dtype]
     line = {
         'metric': 'images/sec (whole node), ResNet-%d %dx%s SimCLR pretraining step @%dpx' % (
             args.resnet_depth, args.width_multiplier, '+SK' if args.sk_ratio > 0 else '', args.image_size),
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+        'dtype_detail': dtype_note, 'f32_matmul': args.f32_matmul if args.dtype == 'f32' else None,
+        # the headline mode's own parity measurement in this run (the `parity` block below): north_star = loss 1e-3 rel, embeddings 1e-5 abs
+        'north_star_met': met,
         'data': 'synthetic',
         'config': {'workload': 'ResNet-%d %dx%s, %dx%d, 2 views/image, per-GPU batch %d, global batch %d, '
                                'NT-Xent T=0.1 + linear-eval head + LARS, global BN%s, dp%d'
@@ -708,14 +741,16 @@ def main():
                                   global_batch, ', on-device blur' if args.use_blur else '', world),
                    'global_batch': global_batch, 'parallelism': 'dp%d' % world},
         'step_ms': percentiles(step_ms),
-        'step_mfma_frac': round(value * flop_img / (world * peak * 1e12), 4) if flop_img else None,
+        'step_mfma_frac': step_mfma_frac(value, *headline),
         'flop_per_image': flop_img, 'peak_hbm_gb': round(peak_hbm_gb, 2),
         'per_layer_bound_frac': round(value / (world * 22100.0), 4) if default_cfg and args.dtype == 'bf16' else None,
         'roofline': roofline,
+        'families': families,
         'ntxent': ntx,
         'kernels': kernels,
-        'f32_mode': f32_mode,
-        'parity_mode': parity_mode,
+        'speed_mode': side.get('speed_mode'),
+        'f32_mode': side.get('f32_mode'),
+        'parity_mode_bf16x6': side.get('parity_mode_bf16x6'),
         # measured in this run: every mode's training step against the reference-source fixtures (measured_parity above)
         'parity': parity,
         'allgather': coll,

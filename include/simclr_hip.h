@@ -15,6 +15,19 @@
  *     weights ("T" below).  Accumulation, statistics, losses and optimizer state are fp32/fp64.
  *   - layouts: activations NHWC, master conv weights HWIO fp32, dense weights [in,out] fp32
  *     (tf2/resnet.py:196-203, tf2/model.py:143-146).
+ *   - `dtype` may carry OPTION FIELDS above the low byte (fp32 storage only; entry points that
+ *     accept them say so):
+ *       SIMCLR_FMT_TERMS(t)  bits 12..19: the matrix arithmetic of THIS call (t = 0 exact fp32 MFMA,
+ *                            3 | 6 bf16-piece terms, 13 = three fp16-piece terms, forward only) -- the
+ *                            process-wide default of simclr_set_f32_matmul is then not consulted, so
+ *                            calls on different streams / threads can run different modes;
+ *       SIMCLR_FMT_PS_IN     the gradient operand (dy) of simclr_conv2d_dgrad / _dgrad_bn / _wgrad is
+ *                            in the PRE-SPLIT BLOCK FORMAT: same 4 bytes per element, but every 128-byte
+ *                            block of 32 channels holds eight 16-byte chunks of bf16 pieces -- chunk g
+ *                            (g < 4) = hi = bf16(x) of channels {4g..4g+3, 16+4g..16+4g+3}, chunk 4 + g =
+ *                            lo = bf16(x - hi) of the same channels -- so that the three-term GEMMs read
+ *                            their operand pieces without splitting anything in the k-loop;
+ *       SIMCLR_FMT_PS_OUT    simclr_bn_bwd_apply writes dx in that format (channels % 32 == 0).
  */
 #ifndef SIMCLR_HIP_H_
 #define SIMCLR_HIP_H_
@@ -27,13 +40,16 @@ extern "C" {
 
 #define SIMCLR_DT_F32 0
 #define SIMCLR_DT_BF16 1
+#define SIMCLR_FMT_PS_IN 0x100
+#define SIMCLR_FMT_PS_OUT 0x200
+#define SIMCLR_FMT_TERMS(t) (((t) + 1) << 12)
 
 typedef struct ihipStream_t* simclr_stream_t; /* == hipStream_t */
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 const char* simclr_last_error(void);
 int simclr_abi_version(void);
-/* lane-layout probes used by the GPU tests (0 mfma bf16 16x16x32, 1 mfma f32 16x16x4, 2 ds_read_tr16) */
+/* lane-layout probes used by the GPU tests (0 mfma bf16 16x16x32, 1 mfma f32 16x16x4, 2 ds_read_tr16, 3 mfma f16 16x16x32 incl. subnormal inputs) */
 int simclr_probe(int which, const void* a, const void* b, void* out, simclr_stream_t stream);
 
 /* ---- NT-Xent contrastive loss: tf2/objective.py:35-89 (add_contrastive_loss) ------------------ */
@@ -70,14 +86,27 @@ int simclr_lars_multi_tensor(const long long* table, int num_tensors, const long
                              int num_chunks, const float* lr_dev, float lr, float momentum,
                              float weight_decay, float eeta, int classic_momentum, int use_nesterov,
                              double* norms, simclr_stream_t stream);
+/* The other two branches of build_optimizer (tf2/model.py:31-34), same descriptor / chunk tables (row 2 = the slot; flags
+ * bit 0 = add l2 * w to the gradient: the derivative of add_weight_decay's loss term, tf2/model.py:62-69).
+ * simclr_sgd_multi_tensor: tf.keras.optimizers.SGD(lr, momentum, nesterov): accum = momentum * accum - lr * g;
+ * w += nesterov ? momentum * accum - lr * g : accum.  simclr_adam_multi_tensor: tf.keras.optimizers.Adam (the slot holds
+ * 2 * numel floats: m, then v); step = 1-based update count of the bias correction. */
+int simclr_sgd_multi_tensor(const long long* table, int num_tensors, const long long* chunks, int num_chunks,
+                            const float* lr_dev, float lr, float momentum, int use_nesterov, float l2, simclr_stream_t stream);
+int simclr_adam_multi_tensor(const long long* table, int num_tensors, const long long* chunks, int num_chunks,
+                             const float* lr_dev, float lr, float beta1, float beta2, float epsilon, long long step, float l2,
+                             simclr_stream_t stream);
 
 /* ---- convolution / dense: tf2/resnet.py:183-208 (Conv2dFixedPadding), tf2/model.py:143-154 ----- */
 /* Matrix arithmetic of the SIMCLR_DT_F32 convolution / dense launches (the reference's tf.nn.conv2d / tf.matmul on float32,
  * resnet.py:196-208, model.py:148-153): number of bf16 terms per fp32 product, for the forward GEMM and for the two backward
  * GEMMs (dgrad, wgrad).  0 (default) = exact fp32 MFMA; 3 = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi (~2^-17 per product);
  * 6 = every term of weight >= 2^-18 of a three-way split (fp32 level).  Storage, accumulation, statistics and every
- * elementwise kernel stay fp32; bf16 launches are unaffected.  Process-wide, not stream-ordered: set it between steps
- * (the one piece of process-global state in this ABI: two streams of one process cannot run different settings at once).
+ * elementwise kernel stay fp32; bf16 launches are unaffected.  fwd_terms = 13 (round 6): three FP16-piece terms
+ * (11-bit pieces: ~2^-22 per product, the accuracy of six bf16 terms at half the MFMA work; operands must lie within fp16's
+ * range -- BatchNorm outputs, images, weights do; an out-of-range operand gives inf / NaN, never a silently wrong value; the
+ * stem keeps six bf16 terms).  This call sets the process-wide DEFAULT only: a convolution / dense entry point whose `dtype`
+ * carries SIMCLR_FMT_TERMS(t) runs with t whatever the default is (the re-entrant form; simclr_amd/ops.py always sends it).
  * The setting is a LOWER bound on accuracy: the non-persistent fallback kernel (debug switch SIMCLR_NO_PERSISTENT, or more than
  * 64 N-tiles) always runs the exact fp32 MFMA whatever is selected here.
  * simclr_get_f32_matmul(0 | 1) returns the forward | backward setting. */

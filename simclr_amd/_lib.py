@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('SIMCLR_HIP_LIB') or os.path.join(_HERE, 'libsimclr_hi
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'simclr_hip.h')
 
 # bumped whenever an entry point's buffer-size contract or argument list changes (csrc/runtime.hip)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 DT_F32 = 0
 DT_BF16 = 1

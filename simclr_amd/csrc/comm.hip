@@ -17,6 +17,7 @@
 // the processes is the caller's job (simclr_amd/comm.py uses torch.distributed.all_gather_object).
 // RCCL stays the fallback and the transport of collectives A and B.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -28,6 +29,7 @@ struct CommP {
   int rank, world;
   int max_doubles;                  // payload capacity of a slot
   unsigned seq;
+  long long timeout_ticks;          // bound of the arrival wait in wall_clock64() ticks (constant-rate counter, 100 MHz on gfx9)
 };
 
 __device__ __forceinline__ size_t slot_bytes(int max_doubles) { return (size_t)max_doubles * 8 + kFlagBytes; }
@@ -56,10 +58,14 @@ __global__ __launch_bounds__(256) void stats_exchange(const CommP p, const doubl
   __syncthreads();
   if (tid < p.world) {
     const unsigned* flag = (const unsigned*)(p.peer[p.rank] + ((size_t)gen * p.world + tid) * sb);
-    long long spins = 0;
+    // Bounded by WALL CLOCK (an iteration count is clock- and contention-dependent), generously: a rank may lag by an
+    // input-pipeline stall, a checkpoint write or a first-step lazy load, all of which a collective library would simply wait out.
+    // Default 600 s -- the order of the collective library's own watchdog; SIMCLR_PEER_STATS_TIMEOUT_S overrides.
+    const long long t0 = wall_clock64();
+    int polls = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1ll << 26)) { atomicAdd(&bad, 1); break; }      // ~ 10 s
+      if ((++polls & 255) == 0 && wall_clock64() - t0 > p.timeout_ticks) { atomicAdd(&bad, 1); break; }
     }
   }
   __threadfence_system();
@@ -160,6 +166,13 @@ int simclr_comm_stats_allreduce(const double* in, double* out, int count, void* 
     p.peer[r] = (unsigned char*)peers[r];
   }
   p.rank = rank; p.world = world; p.max_doubles = max_doubles; p.seq = seq;
+  static const double timeout_s = getenv("SIMCLR_PEER_STATS_TIMEOUT_S") ? atof(getenv("SIMCLR_PEER_STATS_TIMEOUT_S")) : 600.0;
+  static const long long tick_hz = [] {            // wall_clock64() rate: hipDeviceAttributeWallClockRate is in kHz
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    return (long long)khz * 1000;
+  }();
+  p.timeout_ticks = (long long)((timeout_s > 0.001 ? timeout_s : 0.001) * (double)tick_hz);
   hipLaunchKernelGGL(stats_exchange, dim3(1), dim3(256), 0, stream, p, in, out, count, status);
   SIMCLR_CHECK_LAUNCH();
   return 0;

@@ -87,8 +87,14 @@ __device__ __forceinline__ long long ps_quad_offset(long long i) { return (i >> 
 template <bool F16, bool NT = false> __device__ __forceinline__ void ps_store_quad(void* base, long long i, const float* v) {
   u32x2 h, l;
   uint32_t a, b;
-  split_pair<F16>(v[0], v[1], a, b); h[0] = a; l[0] = b;
-  split_pair<F16>(v[2], v[3], a, b); h[1] = a; l[1] = b;
+  // The values are pinned in registers first: inlined next to its producer (x = s * t) the residual x - hi would otherwise be
+  // contracted into fma(s, t, -hi) -- the residual of the UNROUNDED product, a different (if slightly better) lo than the split of
+  // the fp32 value a plain store would have written.  The format is specified as exactly that split (HIP's __fsub_rn is a plain
+  // subtraction and contracts too).
+  float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+  asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+  split_pair<F16>(x0, x1, a, b); h[0] = a; l[0] = b;
+  split_pair<F16>(x2, x3, a, b); h[1] = a; l[1] = b;
   unsigned char* p = (unsigned char*)base + ps_quad_offset(i);
   if (NT) { __builtin_nontemporal_store(h, (u32x2*)p); __builtin_nontemporal_store(l, (u32x2*)(p + 64)); }
   else { *(u32x2*)p = h; *(u32x2*)(p + 64) = l; }

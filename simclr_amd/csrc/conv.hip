@@ -609,7 +609,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   // before it is stored -- y = act(bf16(conv) * scale + shift + res) with exactly the arithmetic of bn_apply (csrc/bn.hip),
   // so the convolution output itself never travels to HBM.  The statistics that scale / shift derive from come from a
   // first, store-free pass of the same convolution (STATS instantiation with y == nullptr).
-  static_assert(!FAPPLY || (sizeof(T) == 2 && MODE == MODE_FWD && !STATS && !BNEPI && !EXT), "fused BN-apply epilogue: forward bf16");
+  // (fp32 storage, round 6: the same epilogue on the fp32 accumulators in the register-direct path below -- the parity mode's block
+  // tails lose the convolution-output round trip too: 8 of a bottleneck block's 67 tensor passes)
+  static_assert(!FAPPLY || (MODE == MODE_FWD && !STATS && !BNEPI && !EXT), "fused BN-apply epilogue: forward, no statistics");
   static_assert(SPL == 0 || sizeof(T) == 4, "split-bf16 terms: fp32 storage only");
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
@@ -1283,6 +1285,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         if (off >= 0 && n < p.N) {
           T* dst = Y + off + n;
           float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+          if constexpr (FAPPLY && sizeof(T) == 4) {
+            // y = act(conv * scale + shift + res [* rscale + rshift]) with bn_apply<float>'s arithmetic (csrc/bn.hip) on the fp32
+            // accumulators: bitwise what conv -> HBM -> bn_apply produces; ReLU bits: one byte per 16-byte chunk = this lane's 4 channels
+            const int nl = wn * 64 + ni * 16 + g * 4;
+            const float4 sc = *(const float4*)(bnp + nl), sh = *(const float4*)(bnp + BN + nl);
+            float o[4] = {fmaf(v[0], sc.x, sh.x), fmaf(v[1], sc.y, sh.y), fmaf(v[2], sc.z, sh.z), fmaf(v[3], sc.w, sh.w)};
+            if (fa_res) {
+              const float4 r = *(const float4*)((const float*)p.bn_x + off + n);
+              if (fa_rbn) {
+                const float4 rs = *(const float4*)(bnp + 2 * BN + nl), rb = *(const float4*)(bnp + 3 * BN + nl);
+                o[0] += fmaf(r.x, rs.x, rb.x); o[1] += fmaf(r.y, rs.y, rb.y); o[2] += fmaf(r.z, rs.z, rb.z); o[3] += fmaf(r.w, rs.w, rb.w);
+              } else { o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+            }
+            if (fa_relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+            }
+            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+            if (fa_mask)
+              ((unsigned char*)p.bn_mask)[(off + n) >> 2] =
+                  (unsigned char)((o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u));
+            continue;
+          }
           if (EXT) {
             const float4 bi = *(const float4*)(bnp + 4 * BN + wn * 64 + ni * 16 + g * 4);
             v[0] += bi.x; v[1] += bi.y; v[2] += bi.z; v[3] += bi.w;
@@ -1420,6 +1445,7 @@ struct WgradP {
   const void* zero;   // 16 zero bytes (padding source for the direct-to-LDS loads)
   int diag;
   int split;     // fp32: 0 = exact fp32 MFMA, 3 / 6 = split-bf16 terms (simclr_set_f32_matmul)
+  int dy_ps;     // fp32, three terms: dy is in the pre-split block format (PSD instantiations)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -1677,10 +1703,22 @@ __global__ __launch_bounds__(256) void conv_wgrad(const WgradP p) {
 // MT (multi-tap k-tile, the stem: KW = 1, IC = 32 packed elements per kernel row, all 7 kernel rows in ONE 256-row k-tile so
 // that the gradient tensor is read once): every 16-byte chunk of a tile row has its OWN tap, so the tap offset is per lane
 // instead of per workgroup.  Needs 16-byte aligned sources (stride 2 on an even-width packed image: every pixel index even).
-template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false, bool MT = false, int SPL = 0>
+// PSD (fp32 storage, three bf16 terms): bit 0 = the gradient operand dy is in the pre-split block format (common.h; written by
+// simclr_bn_bwd_apply with SIMCLR_FMT_PS_OUT).  Its LDS tile then holds, per 128-byte block of 32 channels, two 32-byte runs of hi
+// pieces and two of lo pieces -- each run is a [pixel][16 channel] bf16 tile row, so the fragments come from ds_read_b64_tr_b16
+// exactly like the bf16 kernel's (2 + 2 transposing reads per fragment, no VALU), and lane group g holds pixels 8g..8g+7 of a
+// 32-pixel step; the activation operand (fp32, split in registers) is read with the same pixel assignment.  The 16 positions of
+// a run are channels {0-3, 16-19, 4-7, 20-23} / {8-11, 24-27, 12-15, 28-31} of the block: the slab store maps them back.
+template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN = 2, bool GRAM = false, bool MT = false, int SPL = 0, int PSD = 0>
 __global__ __launch_bounds__(WK * WNN * 64,
                              WK * WNN == 8 ? 1 : ((SPL == 0 && STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
 void conv_wgrad_dma(const WgradP p) {
+  static_assert(PSD == 0 || (PSD == 1 && SPL == 3 && sizeof(T) == 4 && !GRAM && !MT && BNW % 32 == 0), "pre-split dy: fp32 storage, three terms");
+  // LDS bank keys of the two tiles (XOR on the 32-byte blocks of a pixel row).  PSD: the dy tile takes the bf16 kernel's key (the 8
+  // pixel rows {8g+q, q<4} of a half-wave transposing read get 8 distinct keys); the fp32 activation tile is read 16 lanes x 4 bytes
+  // per lane group at pixels 8g+j, so the four groups need distinct 64-byte bank ranges: key = g << 1.
+  auto key_a = [](int px) __attribute__((always_inline)) { return PSD ? (((px >> 3) & 3) << 1) : px_key<T>(px); };
+  auto key_b = [](int px) __attribute__((always_inline)) { return PSD ? ((px & 3) | (((px >> 3) & 1) << 2)) : px_key<T>(px); };
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BR = BRM * 4 * EPC;           // pixels per reduction chunk
   constexpr int NW = WK * WNN;
@@ -1756,7 +1794,7 @@ void conv_wgrad_dma(const WgradP p) {
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int px = (wave * AJ + j) * A_RPI + lane / A_CPR, pc = lane % A_CPR;
-    const int lc = (((pc >> 1) ^ (px_key<T>(px) & (A_BLK - 1))) << 1) | (pc & 1);   // logical chunk held by this slot
+    const int lc = (((pc >> 1) ^ (key_a(px) & (A_BLK - 1))) << 1) | (pc & 1);   // logical chunk held by this slot
     const int m = c_begin * BR + px;
     a_m[j] = m;
     if (flat) {
@@ -1777,7 +1815,7 @@ void conv_wgrad_dma(const WgradP p) {
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int px = (wave * BJ + j) * B_RPI + lane / B_CPR, pc = lane % B_CPR;
-    const int lc = (((pc >> 1) ^ (px_key<T>(px) & (B_BLK - 1))) << 1) | (pc & 1);
+    const int lc = (((pc >> 1) ^ (key_b(px) & (B_BLK - 1))) << 1) | (pc & 1);
     const int m = c_begin * BR + px;
     b_m[j] = m;
     b_cok[j] = n0 + lc * EPC < p.N;
@@ -1843,6 +1881,8 @@ void conv_wgrad_dma(const WgradP p) {
     const int byte = ch * (int)sizeof(T);
     return px * RB + (((byte >> 5) ^ (px_key<T>(px) & (NBLK - 1))) << 5) + (byte & 31);
   };
+  auto a_off = [&](int px, int byte) -> int { return px * A_RB + (((byte >> 5) ^ (key_a(px) & (A_BLK - 1))) << 5) + (byte & 31); };
+  auto b_off = [&](int px, int byte) -> int { return px * B_RB + (((byte >> 5) ^ (key_b(px) & (B_BLK - 1))) << 5) + (byte & 31); };
   auto compute = [&](int stage) __attribute__((always_inline)) {
     if (DIAG(1)) return;
     const unsigned char* As = smem + stage * BUF;
@@ -1881,6 +1921,28 @@ void conv_wgrad_dma(const WgradP p) {
             acs[ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones),
                                                               __builtin_bit_cast(bf16x8, af[ki]), acs[ki], 0, 0, 0);
         }
+      }
+    } else if constexpr (PSD == 1) {
+      // pre-split dy: transposing reads of the hi / lo runs (bf16 pieces), activation split in registers; lane group g = pixels 8g..8g+7
+#pragma unroll
+      for (int ks = 0; ks < BR / 32; ++ks) {
+        const int px0 = ks * 32 + g * 8 + (fl >> 2);
+        mma_f32_chunks<NI, KI, true, 3, true, false>(&acc[0][0],
+            [&](int i, int h) {
+              const int nf = wn * NI + i;                              // 16-position run: block nf >> 1, run nf & 1; h = 0 hi, 1 lo
+              const int byte = (nf >> 1) * 128 + h * 64 + (nf & 1) * 32 + (fl & 3) * 8;
+              const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bs + b_off(px0, byte)));
+              const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Bs + b_off(px0 + 4, byte)));
+              const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+              return (u32x4){l2[0], l2[1], h2[0], h2[1]};
+            },
+            [&](int i, int h) {
+              u32x4 c;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                c[e] = *(const uint32_t*)(As + a_off(ks * 32 + g * 8 + h * 4 + e, (wk * (KI * 16) + i * 16 + fl) * 4));
+              return c;
+            });
       }
     } else if constexpr (SPL != 0) {
       // split-bf16 terms: lane group g holds pixels {4j + g : j = 0..7} of a 32-pixel step for both operands
@@ -1951,7 +2013,11 @@ void conv_wgrad_dma(const WgradP p) {
     const int kk = kk0 + wk * (KI * 16) + ki * 16 + fl;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wn * (NI * 16) + ni * 16 + g * 4;
+      int n = n0 + wn * (NI * 16) + ni * 16 + g * 4;
+      if constexpr (PSD == 1) {            // run position 4 g + reg of run nf -> channel (common.h block layout)
+        const int nf = wn * NI + ni, Q = 4 * (nf & 1) + g;
+        n = n0 + (nf >> 1) * 32 + (Q & 1) * 16 + (Q >> 1) * 4;
+      }
       if (kk < p.K && n < p.N)
         *(float4*)(slab + (long long)kk * p.N + n) =
             make_float4(acc[ki][ni][0], acc[ki][ni][1], acc[ki][ni][2], acc[ki][ni][3]);
@@ -2622,6 +2688,16 @@ __global__ void unpack_stem_dw(const float* __restrict__ src, float* __restrict_
 // device address of g_zero16 (looked up once); nullptr if the lookup fails -- entry points refuse to launch then
 // fp32 matrix arithmetic of the forward and of the two backward GEMMs (process-wide, simclr_set_f32_matmul)
 static int g_f32_terms_fwd = 0, g_f32_terms_bwd = 0;
+// Per-call override (re-entrant form): an entry point's `dtype` argument may carry the matrix arithmetic of THIS
+// call in bits 12..19 -- SIMCLR_FMT_TERMS(t) = (t + 1) << 12, t in {0, 3, 6, 13} -- in which case the process-wide default set by
+// simclr_set_f32_matmul is not consulted at all.  terms_of() returns the terms a call runs with and strips the field.
+static bool valid_terms(int t, bool fwd) { return t == 0 || t == 3 || t == 6 || (fwd && t == 13); }
+static int terms_of(int* dtype, bool fwd) {
+  const int f = (*dtype >> 12) & 0xff;
+  *dtype &= ~(0xff << 12);
+  if (f == 0) return fwd ? g_f32_terms_fwd : g_f32_terms_bwd;
+  return valid_terms(f - 1, fwd) ? f - 1 : -1;
+}
 
 // ---- which instantiation ran: ONE place that records every forward / dgrad launch decision ----------
 // SIMCLR_LAUNCH replaces hipLaunchKernelGGL inside launch_igemm_one: it writes the kernel's template-argument list (as spelled
@@ -2883,7 +2959,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
   p.m_tiles = ceil_div(p.M, 128);
   p.n_tiles = ceil_div(p.N, BN);
   if (p.M <= 0) return;
-  p.split = MODE == MODE_FWD ? g_f32_terms_fwd : g_f32_terms_bwd;
+  // p.split: set by the entry point (terms_of: the call's own terms or the process-wide default)
 #ifdef SIMCLR_DIAG
   { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
 #endif
@@ -3024,6 +3100,19 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       int fas = 0;
       if (p.bn_x && p.bn_mode && p.bn_mask && (p.N & 31) == 0) fas = p.bn_mean ? 2 : 1;
       { const char* e = getenv("SIMCLR_FAPPLY_SPECIAL"); if (e && atoi(e) == 0) fas = 0; }
+      if constexpr (sizeof(T) == 4 && MODE == MODE_FWD) {
+        // fp32 storage: generic options (FAS = 0); three fp16-piece terms with the pre-split weights, six bf16 terms, or exact fp32
+#define LF32(BNv)                                                                                                              \
+        do {                                                                                                                   \
+          if (psb && p.split == 13) SIMCLR_LAUNCH((conv_igemm_persistent<float, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 13, false, true>), dim3(pg), dim3(256), plds, stream, p); \
+          else if (p.split == 6) SIMCLR_LAUNCH((conv_igemm_persistent<float, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 6>), dim3(pg), dim3(256), plds, stream, p); \
+          else if (p.split == 3) SIMCLR_LAUNCH((conv_igemm_persistent<float, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 3>), dim3(pg), dim3(256), plds, stream, p); \
+          else SIMCLR_LAUNCH((conv_igemm_persistent<float, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true>), dim3(pg), dim3(256), plds, stream, p); \
+        } while (0)
+        if (BN == 64) LF32(64); else LF32(128);
+#undef LF32
+        return;
+      }
 #define LF(BNv)                                                                                                                \
       do {                                                                                                                     \
         if (fas == 1) SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE_FWD, 128, BNv, 4, 2, false, false, false, false, true, 0, false, false, 1>), dim3(pg), dim3(256), plds, stream, p); \
@@ -3130,6 +3219,7 @@ int launch_igemm(const ConvP& p0, hipStream_t stream) {
           }
       q.M = p.V * q.cls_h * q.cls_w;
       if (q.ntaps == 0 && p.accumulate) continue;   // nothing to add
+      if (q.ntaps == 0) q.x_ps = 0;                 // zero fill: the gathered tensor is not read at all
       launch_igemm_one<T, MODE>(q, stream);
     }
   return 0;
@@ -3177,6 +3267,8 @@ int simclr_stem_stats_slots(long long M) { return (int)min((M + 127) / 128, 2048
 int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int nslot, int V,
                       int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
                       int pad, int dtype, hipStream_t stream) {
+  const int terms = terms_of(&dtype, true);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_fwd: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_fwd: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cin % (8 * epc) == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 8 * epc);
@@ -3187,6 +3279,7 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd: at most 9 taps (got %dx%d)", KH, KW);
   SIMCLR_CHECK_ARG(y || (stats && dtype == SIMCLR_DT_BF16), "conv2d_fwd: y == NULL (statistics-only pass) needs stats and bf16");
   ConvP p = {};
+  p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = x; p.w = w_t; p.y = y; p.stats = stats; p.nslot = nslot;
@@ -3208,6 +3301,8 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
 int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* stats, int nslot, float* pivot, int V,
                               int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
                               int pad, int dtype, hipStream_t stream) {
+  const int terms = terms_of(&dtype, true);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_fwd_pivoted: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_F32, "conv2d_fwd_pivoted: fp32 only (dtype %d)", dtype);
   SIMCLR_CHECK_ARG(Cin % 32 == 0, "conv2d_fwd_pivoted: Cin=%d must be a multiple of 32", Cin);
   SIMCLR_CHECK_ARG(Cout % 4 == 0, "conv2d_fwd_pivoted: Cout=%d must be a multiple of 4", Cout);
@@ -3216,6 +3311,7 @@ int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* st
   SIMCLR_CHECK_ARG(x && w_t && y && stats && pivot && nslot > 0, "conv2d_fwd_pivoted: null argument");
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd_pivoted: at most 9 taps (got %dx%d)", KH, KW);
   ConvP p = {};
+  p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = x; p.w = w_t; p.y = y; p.stats = stats; p.nslot = nslot;
@@ -3237,9 +3333,9 @@ int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* st
   return 0;
 }
 
-// Forward conv with the BatchNorm apply of its consumer fused into the epilogue (bf16 only):
-//   y = act(bf16(conv(x)) * scale + shift + r),  r = res or res * rscale + rshift (a projection shortcut's own BatchNorm),
-//   relu_bits[i] bit e = (y[8 i + e] > 0)
+// Forward conv with the BatchNorm apply of its consumer fused into the epilogue (bf16, and since round 6 fp32 storage):
+//   y = act(T(conv(x)) * scale + shift + r),  r = res or res * rscale + rshift (a projection shortcut's own BatchNorm),
+//   relu_bits[i] bit e = (y[EPC i + e] > 0), one byte per 16-byte chunk of y (EPC = 8 bf16 / 4 fp32 elements)
 // -- bitwise what simclr_conv2d_fwd followed by simclr_bn_apply produces, without the convolution output ever reaching
 // memory.  scale / shift [Cout] come from the statistics of a first pass (simclr_conv2d_fwd with y == NULL: statistics
 // only) through simclr_bn_finalize.  res (nullable): residual [V,OH,OW,Cout]; relu_bits (nullable): uint8 [V*OH*OW*Cout/8].
@@ -3249,8 +3345,12 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
                                unsigned char* relu_bits, int V, int IH, int IW, int Cin,
                                int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dtype,
                                hipStream_t stream) {
-  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16, "conv2d_fwd_bn_apply: bf16 only (dtype %d)", dtype);
-  SIMCLR_CHECK_ARG(Cin % 64 == 0, "conv2d_fwd_bn_apply: Cin=%d must be a multiple of 64", Cin);
+  const int terms = terms_of(&dtype, true);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_fwd_bn_apply: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_fwd_bn_apply: bad dtype %d", dtype);
+  SIMCLR_CHECK_ARG(Cin % (dtype == SIMCLR_DT_BF16 ? 64 : 32) == 0, "conv2d_fwd_bn_apply: Cin=%d must be a multiple of %d", Cin, dtype == SIMCLR_DT_BF16 ? 64 : 32);
+  SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || (Cout <= 64 * 64 && !getenv("SIMCLR_NO_GLDS") && !getenv("SIMCLR_NO_PERSISTENT")),
+                   "conv2d_fwd_bn_apply: the fp32 epilogue lives in the persistent kernel only");
   SIMCLR_CHECK_ARG(Cout % 8 == 0, "conv2d_fwd_bn_apply: Cout=%d must be a multiple of 8", Cout);
   SIMCLR_CHECK_ARG(x && w_t && y && scale && shift, "conv2d_fwd_bn_apply: null argument");
   SIMCLR_CHECK_ARG((rscale == nullptr) == (rshift == nullptr) && (!rscale || res), "conv2d_fwd_bn_apply: rscale / rshift come together and need res");
@@ -3258,6 +3358,7 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd_bn_apply: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd_bn_apply: at most 9 taps (got %dx%d)", KH, KW);
   ConvP p = {};
+  (void)terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = x; p.w = w_t; p.y = y;
@@ -3266,7 +3367,9 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   p.M = V * OH * OW; p.K = KH * KW * Cin;
   p.fapply = 1; p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
   p.bn_mean = rscale; p.bn_rstd = rshift;
-  launch_igemm<uint16_t, MODE_FWD>(p, stream);
+  (void)terms;
+  if (dtype == SIMCLR_DT_F32) { p.split = terms; launch_igemm<float, MODE_FWD>(p, stream); }
+  else launch_igemm<uint16_t, MODE_FWD>(p, stream);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -3276,10 +3379,12 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
 int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulate, int V, int IH,
                         int IW, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad,
                         int dtype, hipStream_t stream) {
+  const int terms = terms_of(&dtype, false);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_dgrad: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   // dtype | SIMCLR_FMT_PS_IN (fp32, three bf16 backward terms, Cout a multiple of 32): dy is in the pre-split block format (common.h)
   const bool dy_ps = (dtype & SIMCLR_FMT_PS_IN) != 0;
   dtype &= 0xff;
-  SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && g_f32_terms_bwd == 3 && Cout % 32 == 0),
+  SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && terms == 3 && Cout % 32 == 0),
                    "conv2d_dgrad: a pre-split dy needs fp32 storage, three backward terms (simclr_set_f32_matmul) and Cout %% 32 == 0");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad: bad dtype %d", dtype);
@@ -3288,6 +3393,7 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9 && stride <= 2, "conv2d_dgrad: at most 9 taps and stride <= 2");
   ConvP p = {};
+  p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = dy; p.w = w_d; p.y = dx; p.stats = nullptr; p.nslot = 1; p.accumulate = accumulate;
@@ -3313,9 +3419,11 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
                            const float* bn_mean, const float* bn_rstd, int mask_mode, float* stats, int nslot,
                            int V, int IH, int IW, int Cin, int OH, int OW, int Cout, int KH, int KW,
                            int stride, int pad, int dtype, hipStream_t stream) {
+  const int terms = terms_of(&dtype, false);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_dgrad_bn: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   const bool dy_ps = (dtype & SIMCLR_FMT_PS_IN) != 0;          // see simclr_conv2d_dgrad
   dtype &= 0xff;
-  SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && g_f32_terms_bwd == 3 && Cout % 32 == 0),
+  SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && terms == 3 && Cout % 32 == 0),
                    "conv2d_dgrad_bn: a pre-split dy needs fp32 storage, three backward terms (simclr_set_f32_matmul) and Cout %% 32 == 0");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_bn: bad dtype %d", dtype);
@@ -3328,6 +3436,7 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 / 3 / 4 need bn_mask");
   SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn: mask_mode 2 needs scale/shift");
   ConvP p = {};
+  p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = dy; p.w = w_d; p.y = dx; p.stats = stats; p.nslot = nslot; p.accumulate = accumulate;
@@ -3356,6 +3465,8 @@ int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext,
                                const float* bn_shift, const float* bn_mean, const float* bn_rstd, int mask_mode,
                                float* stats, int nslot, int V, int H, int W, int Cin, int Cout, int dtype,
                                hipStream_t stream) {
+  const int terms = terms_of(&dtype, false);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_dgrad_bn_ext: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_bn_ext: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0 && Cin % (8 * epc) == 0, "conv2d_dgrad_bn_ext: Cin=%d / Cout=%d must be multiples of %d", Cin, Cout, 8 * epc);
@@ -3365,6 +3476,7 @@ int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext,
   SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn_ext: mask_mode 1 / 3 / 4 need bn_mask");
   SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn_ext: mask_mode 2 needs scale/shift");
   ConvP p = {};
+  p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = dm; p.w = w_ext; p.y = dx; p.stats = stats; p.nslot = nslot; p.accumulate = accumulate;
@@ -3384,12 +3496,15 @@ int simclr_conv2d_dgrad_bn_ext(const void* dm, const void* h, const void* w_ext,
 // BatchNorm whose conv input is not itself a BatchNorm output (the projection shortcut at a block entry).
 int simclr_conv2d_dgrad_ext(const void* dm, const void* h, const void* w_ext, const float* bias, void* dx, int accumulate,
                             int V, int H, int W, int Cin, int Cout, int dtype, hipStream_t stream) {
+  const int terms = terms_of(&dtype, false);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_dgrad_ext: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_dgrad_ext: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cout % (8 * epc) == 0 && Cin % (8 * epc) == 0, "conv2d_dgrad_ext: Cin=%d / Cout=%d must be multiples of %d", Cin, Cout, 8 * epc);
   SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "conv2d_dgrad_ext: M overflows int32");
   SIMCLR_CHECK_ARG(dm && h && w_ext && dx, "conv2d_dgrad_ext: null argument");
   ConvP p = {};
+  p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
   p.x = dm; p.w = w_ext; p.y = dx; p.stats = nullptr; p.nslot = 1; p.accumulate = accumulate;
@@ -3477,6 +3592,14 @@ size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int C
 int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace,
                         int V, int IH, int IW, int Cin, int pixpitch, int OH, int OW, int Cout, int KH,
                         int KW, int stride, int pad, int dtype, hipStream_t stream) {
+  const int terms = terms_of(&dtype, false);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_wgrad: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
+  // dtype | SIMCLR_FMT_PS_IN (fp32, three bf16 backward terms, Cin a multiple of 64, Cout of 32, 16-byte aligned pixels): dy is in
+  // the pre-split block format (common.h)
+  const bool dy_ps = (dtype & SIMCLR_FMT_PS_IN) != 0;
+  dtype &= 0xff;
+  SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && terms == 3 && Cin % 64 == 0 && Cout % 32 == 0 && (pixpitch * 4) % 16 == 0),
+                   "conv2d_wgrad: a pre-split dy needs fp32 storage, three backward terms, Cin %% 64 == 0 and Cout %% 32 == 0 (Cin=%d Cout=%d)", Cin, Cout);
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_wgrad: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cin % 32 == 0, "conv2d_wgrad: Cin=%d must be a multiple of 32", Cin);
   SIMCLR_CHECK_ARG(Cout % 8 == 0, "conv2d_wgrad: Cout=%d must be a multiple of 8", Cout);
@@ -3558,8 +3681,10 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   { const char* e = getenv("SIMCLR_WGRAD_XCD"); if (e && atoi(e) >= 0) p.xcd_map = atoi(e); }
 #endif
   p.zero = zero_page();
-  p.split = g_f32_terms_bwd;
+  p.split = terms;
+  p.dy_ps = dy_ps ? 1 : 0;
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d_wgrad: zero page symbol not found");
+  SIMCLR_CHECK_ARG(!dy_ps || (cfg != 0 && !stem_mt), "conv2d_wgrad: no pre-split kernel on the register-staged path");
   const int grid = p.k_tiles * p.n_tiles * (p.xcd_map ? ceil_div(p.splits, 8) * 8 : p.splits);
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
   const size_t lds = (size_t)(cfg == 0 ? 2 : stages) * br * (bkw + bnw) * esz;
@@ -3609,7 +3734,8 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   } else if (dtype != SIMCLR_DT_BF16) {
 #define LDS_(A, B)                                                                                                          \
     do {                                                                                                                     \
-      if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
+      if (p.split == 3 && p.dy_ps) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3, 1>), dim3(grid), dim3(256), lds, stream, p); \
+      else if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
       else if (p.split == 6) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 6>), dim3(grid), dim3(256), lds, stream, p); \
       else LD(float, A, B, 2, 2);                                                                                            \
     } while (0)
@@ -3706,6 +3832,8 @@ int simclr_small_gemm_nt_f32(const float* A, const float* B, float* C, int M, in
 int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats, int nslot, int V,
                          int HP, int WP, int OH, int OW, int Cout, int KHP, int KWP, int stride,
                          int dtype, hipStream_t stream) {
+  const int terms = terms_of(&dtype, true);
+  SIMCLR_CHECK_ARG(terms >= 0, "stem_conv_fwd: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "stem_conv_fwd: bad dtype %d", dtype);
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   StemP p = {};
@@ -3729,7 +3857,7 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
   } else {
     // fp32 storage: the forward terms of simclr_set_f32_matmul (0 = exact fp32 MFMA; SIMCLR_STEM_SPLIT=0 keeps the exact kernel)
     static const bool stem_split_on = !getenv("SIMCLR_STEM_SPLIT") || atoi(getenv("SIMCLR_STEM_SPLIT")) != 0;
-    const int spl = stem_split_on ? (g_f32_terms_fwd == 13 ? 6 : g_f32_terms_fwd) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
+    const int spl = stem_split_on ? (terms == 13 ? 6 : terms) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
 #define LSF(STv)                                                                                              \
     do {                                                                                                       \
       if (spl == 3) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 3>), grid, dim3(256), lds, stream, p);    \

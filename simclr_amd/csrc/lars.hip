@@ -12,6 +12,7 @@
 //   table[3*T + t] = numel       table[4*T + t] = flags (bit0 weight decay, bit1 adapt)
 // chunks[2*c] = tensor id, chunks[2*c+1] = element offset of the chunk.
 #include "common.h"
+#include <math.h>
 
 namespace {
 
@@ -118,11 +119,88 @@ __global__ __launch_bounds__(256) void lars_update(const long long* __restrict__
   }
 }
 
+// ---- the other two branches of build_optimizer (tf2/model.py:31-34) on the same descriptor / chunk tables ----------------
+// tf.keras.optimizers.SGD(lr, momentum, nesterov=True): accum = momentum * accum - lr * g;  w += momentum * accum - lr * g
+// (nesterov) or w += accum.  `l2` (flags bit 0): the gradient of add_weight_decay's loss term (tf2/model.py:62-69:
+// weight_decay * sum l2_loss(v) over the non-BatchNorm variables), added here as g + l2 * w instead of by a separate pass.
+__global__ __launch_bounds__(256) void sgd_update(const long long* __restrict__ table, int T, const long long* __restrict__ chunks,
+                                                  const float* __restrict__ lr_ptr, float lr_val, float momentum, int nesterov, float l2) {
+  const int t = (int)chunks[2 * blockIdx.x];
+  const long long off = chunks[2 * blockIdx.x + 1];
+  const int flags = (int)table[4 * T + t];
+  float* w = (float*)table[0 * T + t];
+  const float* g = (const float*)table[1 * T + t];
+  float* a = (float*)table[2 * T + t];
+  const long long numel = table[3 * T + t];
+  const float c = (flags & 1) ? l2 : 0.f;
+  const float lr = lr_ptr ? *lr_ptr : lr_val;
+  const long long end = min(numel, off + (long long)kChunk);
+  for (long long i = off + threadIdx.x; i < end; i += 256) {
+    const float wi = w[i];
+    const float gi = g[i] + c * wi;
+    const float na = momentum * a[i] - lr * gi;
+    w[i] = wi + (nesterov ? momentum * na - lr * gi : na);
+    a[i] = na;
+  }
+}
+
+// tf.keras.optimizers.Adam(lr) (beta_1 0.9, beta_2 0.999, epsilon 1e-7): m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2;
+// w -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) -- `corr` is that factor for this step (host, double).
+// The slot tensor of a variable is [2][numel]: m then v.
+__global__ __launch_bounds__(256) void adam_update(const long long* __restrict__ table, int T, const long long* __restrict__ chunks,
+                                                   const float* __restrict__ lr_ptr, float lr_val, float b1, float b2, float eps,
+                                                   float corr, float l2) {
+  const int t = (int)chunks[2 * blockIdx.x];
+  const long long off = chunks[2 * blockIdx.x + 1];
+  const int flags = (int)table[4 * T + t];
+  float* w = (float*)table[0 * T + t];
+  const float* g = (const float*)table[1 * T + t];
+  const long long numel = table[3 * T + t];
+  float* m = (float*)table[2 * T + t];
+  float* v = m + numel;
+  const float c = (flags & 1) ? l2 : 0.f;
+  const float lr_t = (lr_ptr ? *lr_ptr : lr_val) * corr;
+  const long long end = min(numel, off + (long long)kChunk);
+  for (long long i = off + threadIdx.x; i < end; i += 256) {
+    const float wi = w[i];
+    const float gi = g[i] + c * wi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 int simclr_lars_chunk_elems(void) { return kChunk; }
+
+// build_optimizer's 'momentum' branch (tf2/model.py:31-32): one launch over every trainable tensor, tables as for
+// simclr_lars_multi_tensor (row 2 = the accumulator slot, flags bit 0 = add l2 * w to the gradient).
+int simclr_sgd_multi_tensor(const long long* table, int num_tensors, const long long* chunks, int num_chunks,
+                            const float* lr_dev, float lr, float momentum, int use_nesterov, float l2, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(num_tensors > 0 && num_chunks > 0 && table && chunks, "sgd: empty / null tables");
+  hipLaunchKernelGGL(sgd_update, dim3(num_chunks), dim3(256), 0, stream, table, num_tensors, chunks, lr_dev, lr, momentum,
+                     use_nesterov, l2);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// build_optimizer's 'adam' branch (tf2/model.py:33-34).  step = the 1-based update count t of the bias correction; row 2 of
+// the table = a slot of 2 * numel floats (m, then v).
+int simclr_adam_multi_tensor(const long long* table, int num_tensors, const long long* chunks, int num_chunks,
+                             const float* lr_dev, float lr, float beta1, float beta2, float epsilon, long long step, float l2,
+                             hipStream_t stream) {
+  SIMCLR_CHECK_ARG(num_tensors > 0 && num_chunks > 0 && table && chunks && step >= 1, "adam: empty / null tables or step < 1");
+  const double corr = sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+  hipLaunchKernelGGL(adam_update, dim3(num_chunks), dim3(256), 0, stream, table, num_tensors, chunks, lr_dev, lr, beta1, beta2,
+                     epsilon, (float)corr, l2);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
 
 // norms: device double[2*num_chunks] scratch (per-chunk partial squared norms; every used entry is rewritten by the
 // call).  lr_dev may be NULL (then lr is used); a device-resident lr lets a captured hipGraph replay with a new

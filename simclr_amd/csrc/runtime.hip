@@ -68,7 +68,7 @@ __global__ void probe_ds_read_tr16(const uint16_t* in, const int* addr, uint16_t
 extern "C" {
 
 const char* simclr_last_error(void) { return g_err; }
-int simclr_abi_version(void) { return 7; }
+int simclr_abi_version(void) { return 8; }
 
 // which: 0 = mfma bf16 16x16x32, 1 = mfma f32 16x16x4, 2 = ds_read_b64_tr_b16, 3 = mfma f16 16x16x32 (fp16 bit patterns)
 int simclr_probe(int which, const void* a, const void* b, void* out, hipStream_t stream) {

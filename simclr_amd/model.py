@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from . import data_util, lars_optimizer, ops, resnet
+from . import data_util, lars_optimizer, ops, optimizers, resnet
 from .flags import FLAGS
 from .lars_optimizer import Variable
 from .resnet import RT, Act, Layer, PackedInput, scope
@@ -24,10 +24,11 @@ def build_optimizer(learning_rate):
             momentum=FLAGS.momentum,
             weight_decay=FLAGS.weight_decay,
             exclude_from_weight_decay=['batch_normalization', 'bias', 'head_supervised'])
-    elif FLAGS.optimizer in ('momentum', 'adam'):
-        raise NotImplementedError(
-            "optimizer=%r: only 'lars' (the reference default, tf2/run.py:163) is on the MI355X hot path"
-            % FLAGS.optimizer)
+    elif FLAGS.optimizer == 'momentum':                                                     # :31-32
+        # l2: the gradient of add_weight_decay's loss term for the non-LARS optimizers (:62-69), applied inside the update kernel
+        return optimizers.SGD(learning_rate, FLAGS.momentum, nesterov=True, l2=FLAGS.weight_decay)
+    elif FLAGS.optimizer == 'adam':                                                         # :33-34
+        return optimizers.Adam(learning_rate, l2=FLAGS.weight_decay)
     else:
         raise ValueError('Unknown optimizer {}'.format(FLAGS.optimizer))
 
@@ -267,7 +268,10 @@ class Model(Layer):
                              f'(got input shape {tuple(inputs.shape)})')
         if FLAGS.train_mode == 'finetune':
             raise NotImplementedError('train_mode=finetune is outside the pretraining hot path')
-        ops.select_f32_matmul()      # evaluation passes do not go through ops.begin_step
+        # (evaluation passes do not go through ops.begin_step.)  Inference mode normalises with the MOVING statistics, so nothing bounds the
+        # activations to fp16's range (a freshly initialised network's moving averages do not normalise at all): the split-fp16 forward is
+        # for training-mode BatchNorm only, an inference forward runs its fp32 products as six bf16 terms instead (same accuracy class).
+        ops.select_f32_matmul(inference=not training)
         if FLAGS.use_blur and training and FLAGS.train_mode == 'pretrain':
             # batch_random_blur on the device (tf2/model.py:255-258), fused over the k views
             inputs = data_util.batch_random_blur_tensor(inputs, FLAGS.image_size, FLAGS.image_size)

@@ -65,7 +65,34 @@ def _p(t):
     if t is None:
         return None
     assert t.is_cuda and t.is_contiguous(), 'need contiguous device tensor'
+    assert getattr(t, '_ps', None) is None, 'a pre-split tensor reached an operation that reads plain floats'
     return ctypes.c_void_p(t.data_ptr())
+
+
+# ---- pre-split block format (csrc/common.h): an fp32-typed tensor whose 128-byte blocks hold (hi, lo) 16-bit pieces -----------
+# Tensors in that format carry the Python attribute `_ps` ('b16' | 'f16'); only the operations that name it accept them (_pp).
+FMT_PS_IN, FMT_PS_OUT, FMT_PS_F16, FMT_PS_IN2 = 0x100, 0x200, 0x400, 0x800
+
+
+def ps_kind(t):
+    return getattr(t, '_ps', None) if t is not None else None
+
+
+def _pp(t):
+    """Pointer of a tensor that may be pre-split (the callee is told through the dtype flags)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'need contiguous device tensor'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ps_backward_enabled():
+    """Gradient tensors between a BatchNorm backward and the convolution in front of it in the pre-split format: fp32 storage,
+    three bf16 backward terms (FLAGS.f32_matmul in 'bf16x3' | 'bf16x6_3' | 'f16x3_3'), SIMCLR_PS_BWD != 0."""
+    import os
+    if os.environ.get('SIMCLR_PS_BWD', '1') in ('', '0') or os.environ.get('SIMCLR_F32_PRESPLIT', '1') in ('', '0'):
+        return False
+    return _TERMS[1] == 3
 
 
 def _s():
@@ -228,7 +255,7 @@ def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None, store=
     esz = x.element_size()
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, esz * (V * IH * IW * Cin + (M * Cout if store else 0) + K * Cout),
             lambda: lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0] if stats is not None else 0, V,
-                                     IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
+                                     IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x) | _tf(), _s()))
     return out
 
 
@@ -250,7 +277,7 @@ def conv2d_fwd_with_stats(x, w_t, KH, KW, stride, pad, OH, OW, stats):
     M, K = V * OH * OW, KH * KW * Cin
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, 4 * (V * IH * IW * Cin + M * Cout + K * Cout),
             lambda: lib().conv2d_fwd_pivoted(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0], _p(pivot), V, IH, IW, Cin, OH, OW,
-                                             Cout, KH, KW, stride, pad, dt(x), _s()))
+                                             Cout, KH, KW, stride, pad, dt(x) | _tf(), _s()))
     sums = torch.empty(2, Cout, device=x.device, dtype=torch.float64)
     lib().bn_reduce_slots_pivoted(_p(stats), stats.shape[0], Cout, _p(pivot), float(M), _p(sums), _s())
     return out, None, sums
@@ -258,22 +285,23 @@ def conv2d_fwd_with_stats(x, w_t, KH, KW, stride, pad, OH, OW, stats):
 
 def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=None, relu=True, want_bits=False,
                         rscale=None, rshift=None):
-    """y = act(bf16(conv(x)) * scale + shift + res) in ONE kernel (bf16): what conv2d_fwd + bn_apply produce, bit for
-    bit, without the convolution output travelling to memory.  Returns y or (y, relu_bits)."""
+    """y = act(T(conv(x)) * scale + shift + res) in ONE kernel (bf16; fp32 storage since round 6): what conv2d_fwd + bn_apply
+    produce, bit for bit, without the convolution output travelling to memory.  Returns y or (y, relu_bits)."""
     V, IH, IW, Cin = x.shape
     Cout = w_t.shape[0]
-    assert x.dtype == torch.bfloat16
     y = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
     M, K = V * OH * OW, KH * KW * Cin
-    bits = torch.empty(M, Cout // 8, device=x.device, dtype=torch.uint8) if want_bits else None
+    esz = x.element_size()
+    epc = 16 // esz                      # one mask byte per 16-byte chunk of y
+    bits = torch.empty(M, Cout // epc, device=x.device, dtype=torch.uint8) if want_bits else None
     # algorithmic bytes = SURVEY 8(d)'s strict count (input + output + weights); the residual read and the mask write of
     # the fused epilogue (bn3's own traffic) are counted under impl_bytes only
-    nb = 2 * (V * IH * IW * Cin + M * Cout + K * Cout)
+    nb = esz * (V * IH * IW * Cin + M * Cout + K * Cout)
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, nb,
-            impl_bytes=nb + (2 * M * Cout if res is not None else 0) + (M * Cout // 8 if want_bits else 0),
+            impl_bytes=nb + (esz * M * Cout if res is not None else 0) + (M * Cout // epc if want_bits else 0),
             fn=lambda: lib().conv2d_fwd_bn_apply(_p(x), _p(w_t), _p(y), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift),
                                               int(relu), _p(bits), V,
-                                              IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
+                                              IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x) | _tf(), _s()))
     return (y, bits) if want_bits else y
 
 
@@ -285,9 +313,11 @@ def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=Fals
         out = torch.empty(V, IH, IW, Cin, device=dy.device, dtype=dy.dtype)
     M, K = V * IH * IW, KH * KW * Cout
     esz = dy.element_size()
+    fmt = FMT_PS_IN if ps_kind(dy) else 0
+    assert ps_kind(dy) in (None, 'b16')
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + M * Cin + K * Cin),
-            lambda: lib().conv2d_dgrad(_p(dy), _p(w_d), _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout,
-                                       KH, KW, stride, pad, dt(dy), _s()))
+            lambda: lib().conv2d_dgrad(_pp(dy), _p(w_d), _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout,
+                                       KH, KW, stride, pad, dt(dy) | fmt | _tb(), _s()))
     return out
 
 
@@ -304,10 +334,10 @@ def conv2d_dgrad_bn(dy, w_d, KH, KW, pad, IH, IW, bn, out=None, accumulate=False
     esz = dy.element_size()
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + V * IH * IW * Cin + K * Cin),
             impl_bytes=esz * (V * OH * OW * Cout + (1 + (bn['mode'] != 4) + (bn['mode'] == 1) + int(accumulate)) * V * IH * IW * Cin + K * Cin),
-            fn=lambda: lib().conv2d_dgrad_bn(_p(dy), _p(w_d), _p(out), int(accumulate), _p(bn.get('x')), _p(bn.get('mask')),
+            fn=lambda: lib().conv2d_dgrad_bn(_pp(dy), _p(w_d), _p(out), int(accumulate), _p(bn.get('x')), _p(bn.get('mask')),
                                           _p(bn.get('scale')), _p(bn.get('shift')), _p(bn.get('mean')), _p(bn.get('rstd')),
                                           bn['mode'], _p(partial), partial.shape[0], V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
-                                          pad, dt(dy), _s()))
+                                          pad, dt(dy) | (FMT_PS_IN if ps_kind(dy) else 0) | _tb(), _s()))
     return out, partial
 
 
@@ -345,8 +375,8 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad, Cin=None, pixpitch=None, out=None, 
     M, K = V * OH * OW, KH * KW * Cin
     esz = x.element_size()
     _launch('conv_wgrad', 2.0 * M * K * Cout, esz * (V * IH * IW * pixpitch + M * Cout) + 4 * K * Cout,
-            lambda: lib().conv2d_wgrad(_p(x), _p(dy), _p(out), int(accumulate), _p(ws), V, IH, IW, Cin, pixpitch,
-                                       OH, OW, Cout, KH, KW, stride, pad, dt(x), _s()))
+            lambda: lib().conv2d_wgrad(_p(x), _pp(dy), _p(out), int(accumulate), _p(ws), V, IH, IW, Cin, pixpitch,
+                                       OH, OW, Cout, KH, KW, stride, pad, dt(x) | (FMT_PS_IN if ps_kind(dy) else 0) | _tb(), _s()))
     return out
 
 
@@ -381,7 +411,7 @@ def stem_conv_fwd(xp, w_s, geo, stride, stats=None):
     _launch('stem_conv_fwd', 2.0 * M * 147 * Cout, xp.element_size() * (xp.numel() + M * Cout),
             lambda: lib().stem_conv_fwd(_p(xp), _p(w_s), _p(y), _p(stats), stats.shape[0] if stats is not None else 0, V,
                                         geo['HP'], geo['WP'], geo['OH'], geo['OW'], Cout, geo['KHP'], geo['KWP'],
-                                        stride, dt(xp), _s()))
+                                        stride, dt(xp) | _tf(), _s()))
     return y
 
 
@@ -441,21 +471,42 @@ _ARENA = _StatsArena()
 F32_MATMUL_TERMS = {'exact': (0, 0), 'bf16x3': (3, 3), 'bf16x6': (6, 6), 'bf16x6_3': (6, 3), 'f16x3_3': (13, 3)}
 
 
+_TERMS = [0, 0]        # (forward, backward) terms every convolution / dense call of this module passes to the library
+
+
+def _tf():
+    """dtype field of a FORWARD call: this call's matrix arithmetic, SIMCLR_FMT_TERMS(t) = (t + 1) << 12 (csrc/conv.hip terms_of).
+    The library's process-wide default (simclr_set_f32_matmul) is never consulted by calls that carry the field: the C ABI is
+    re-entrant across threads / streams with different modes."""
+    return (_TERMS[0] + 1) << 12
+
+
+def _tb():
+    return (_TERMS[1] + 1) << 12
+
+
 def set_f32_matmul(mode):
-    """Matrix arithmetic of the fp32 convolution / dense kernels (FLAGS.f32_matmul; simclr_set_f32_matmul).  Process-wide."""
+    """Matrix arithmetic of the fp32 convolution / dense kernels (FLAGS.f32_matmul).  The mode is module state of THIS Python layer, sent
+    with every call (_tf / _tb); the library's own process-wide default is set too, for callers of the C ABI that pass no field."""
     if mode not in F32_MATMUL_TERMS:
         raise ValueError('f32_matmul must be one of %s, got %r' % (sorted(F32_MATMUL_TERMS), mode))
     fwd, bwd = F32_MATMUL_TERMS[mode]
+    _TERMS[0], _TERMS[1] = fwd, bwd
     L = lib()
     if (L.get_f32_matmul(0), L.get_f32_matmul(1)) != (fwd, bwd):
         L.set_f32_matmul(fwd, bwd)
 
 
-def select_f32_matmul():
+def select_f32_matmul(inference=False):
     """Apply FLAGS.f32_matmul -- for compute_dtype='f32' ONLY: with a bf16 encoder and head_dtype='f32' the fp32
-    projection / linear-eval heads exist to keep the loss gradient exact, so they always run the exact fp32-input MFMA."""
+    projection / linear-eval heads exist to keep the loss gradient exact, so they always run the exact fp32-input MFMA.
+    inference: a forward through the moving BatchNorm statistics -- 'f16x3_3' falls back to 'bf16x6_3' (fp16 pieces need O(1) operands,
+    which only batch statistics guarantee)."""
     from .flags import FLAGS
-    set_f32_matmul(getattr(FLAGS, 'f32_matmul', 'exact') if getattr(FLAGS, 'compute_dtype', 'f32') == 'f32' else 'exact')
+    mode = getattr(FLAGS, 'f32_matmul', 'exact') if getattr(FLAGS, 'compute_dtype', 'f32') == 'f32' else 'exact'
+    if inference and mode == 'f16x3_3':
+        mode = 'bf16x6_3'
+    set_f32_matmul(mode)
 
 
 def begin_step(device):
@@ -550,13 +601,18 @@ def bn_bwd_finalize(local_sums, global_sums, count, dgamma, dbeta, accumulate=Fa
     return c1, c2
 
 
-def bn_bwd_apply(dy, x, mask_src, scale, shift, mean, rstd, c1, c2, mask_mode, want_masked=False, out=None):
+def bn_bwd_apply(dy, x, mask_src, scale, shift, mean, rstd, c1, c2, mask_mode, want_masked=False, out=None, ps_out=False):
+    """ps_out (fp32, C % 32 == 0): dx in the pre-split block format with bf16 pieces (tagged `_ps`), for the data-gradient and
+    weight-gradient GEMMs of the convolution in front of this BatchNorm."""
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x) if out is None else out
     dmasked = torch.empty_like(x) if want_masked else None
+    ps_out = bool(ps_out) and x.dtype == torch.float32 and C % 32 == 0
     lib().bn_bwd_apply(_p(dy), _p(x), _p(mask_src), _p(scale), _p(shift), _p(mean), _p(rstd), _p(c1), _p(c2),
-                       rows, C, mask_mode, _p(dx), _p(dmasked), dt(x), _s())
+                       rows, C, mask_mode, _pp(dx), _p(dmasked), dt(x) | (FMT_PS_OUT if ps_out else 0), _s())
+    if ps_out:
+        dx._ps = 'b16'
     return dx, dmasked
 
 
@@ -814,7 +870,7 @@ def conv2d_dgrad_bn_ext(dm, h, wext, bias, bn, out=None, accumulate=False):
             fn=lambda: lib().conv2d_dgrad_bn_ext(_p(dm), _p(h), _p(wext), _p(bias), _p(out), int(accumulate), _p(bn['x']),
                                                  _p(bn.get('mask')), _p(bn.get('scale')), _p(bn.get('shift')), _p(bn['mean']),
                                                  _p(bn['rstd']), bn['mode'], _p(partial), partial.shape[0], V, H, W, K, N,
-                                                 dt(dm), _s()))
+                                                 dt(dm) | _tb(), _s()))
     return out, partial
 
 
@@ -862,5 +918,5 @@ def conv2d_dgrad_ext(dm, h, wext, bias, out=None, accumulate=False):
     _launch('conv_igemm_dgrad', 2.0 * M * N * K, esz * (M * N + M * K + N * K),
             impl_bytes=esz * (M * N + (2 + int(accumulate)) * M * K + (N + K) * K),
             fn=lambda: lib().conv2d_dgrad_ext(_p(dm), _p(h), _p(wext), _p(bias), _p(out), int(accumulate), V, H, W, K, N,
-                                              dt(dm), _s()))
+                                              dt(dm) | _tb(), _s()))
     return out

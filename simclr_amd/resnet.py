@@ -289,13 +289,16 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         assert s.get('masked'), 'fusion_info without mask_src needs a BN+ReLU layer'
         return dict(x=s['x'], scale=s['scale'], shift=s['shift'], mean=s['mean'], rstd=s['rstd'], mode=2)
 
-    def backward_fused(self, dm, partial, coeffs=None):
+    def backward_fused(self, dm, partial, coeffs=None, ps_for=None):
         """Second half of the backward when the reduce was fused into the producing dgrad: dm is the
         already-masked gradient, partial the per-channel (sum dm, sum dm*x^) slots.  coeffs: (c1, c2) if
-        `bwd_finalize_many` already exchanged / finalised the sums together with another layer's."""
+        `bwd_finalize_many` already exchanged / finalised the sums together with another layer's.
+        ps_for: the convolution whose backward is the ONLY consumer of the result -- if its GEMMs take it, dx is written in the
+        pre-split block format (fp32 parity mode: no operand splitting in their k-loops)."""
         s = self.saved
         c1, c2 = coeffs if coeffs is not None else self._bwd_finalize(partial, s['count'])
-        dx, _ = ops.bn_bwd_apply(dm, s['x'], None, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2, 0)
+        dx, _ = ops.bn_bwd_apply(dm, s['x'], None, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2, 0,
+                                 ps_out=_ps_grad_ok(ps_for))
         self.saved = None
         return dx
 
@@ -325,9 +328,10 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         s = self.saved
         return ops.bn_bwd_reduce(dy, s['x'], mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], mask_mode)
 
-    def backward(self, dy, mask_src=None, mask_mode=None, want_masked=False, coeffs=None):
+    def backward(self, dy, mask_src=None, mask_mode=None, want_masked=False, coeffs=None, ps_for=None):
         """dy: gradient wrt this layer's (activated) output.  Returns (dx, dy_masked).
-        coeffs: (c1, c2) when the reduce + statistic exchange was already done (bwd_reduce + bwd_finalize_many)."""
+        coeffs: (c1, c2) when the reduce + statistic exchange was already done (bwd_reduce + bwd_finalize_many).
+        ps_for: see backward_fused."""
         s = self.saved
         if mask_mode is None:
             # plain BN+ReLU: the ReLU mask is recomputed from x*scale+shift (exactly (y > 0)),
@@ -341,9 +345,20 @@ class BatchNormRelu(Layer):  # tf2/resnet.py:31-78
         else:
             c1, c2 = coeffs
         dx, dmasked = ops.bn_bwd_apply(dy, x, mask_src, s['scale'], s['shift'], s['mean'], s['rstd'], c1, c2,
-                                       mask_mode, want_masked=want_masked)
+                                       mask_mode, want_masked=want_masked, ps_out=_ps_grad_ok(ps_for))
         self.saved = None
         return dx, dmasked
+
+
+def _ps_grad_ok(conv):
+    """May the gradient handed to `conv.backward` be in the pre-split block format (csrc/common.h)?  fp32 storage with three bf16
+    backward terms, a plain (not stem, not channel-padded) convolution on the LDS-DMA weight-gradient path."""
+    if conv is None or RT.dtype != torch.float32 or not isinstance(conv, Conv2dFixedPadding):
+        return False
+    sv = conv.saved
+    if sv is None or 'packed' in sv or conv.kernel is None or conv.padded or not conv.kernel.trainable:
+        return False
+    return conv.cin_p % 64 == 0 and conv.cout_p % 32 == 0 and ops.ps_backward_enabled()
 
 
 def _conv3_fused_level():
@@ -781,7 +796,7 @@ class _Shortcut(Layer):
         return d
 
     def backward(self, d_sum, coeffs=None):
-        d_raw, _ = self.bn.backward(d_sum, mask_mode=0, coeffs=coeffs)
+        d_raw, _ = self.bn.backward(d_sum, mask_mode=0, coeffs=coeffs, ps_for=self.conv)
         d = self.conv.backward(d_raw)
         if self.resnet_d:
             d = ops.avgpool2_bwd(d, self._hw[0], self._hw[1], self.strides)
@@ -800,7 +815,7 @@ def _block_entry(block, inputs, training):
     return raw_sc.t, sc_bn, block.bn1(raw1, training)
 
 
-def _block_tail_backward(block, bn_tail, dout, dout_partial):
+def _block_tail_backward(block, bn_tail, dout, dout_partial, conv_tail=None):
     """Backward of relu(bn_tail(h) + shortcut): returns (dh, dx_shortcut_path).  When the tail's reduce arrived fused
     (dout_partial) and the block has a projection shortcut, the two BatchNorm backward reductions -- same upstream
     gradient -- share one statistics exchange."""
@@ -809,11 +824,11 @@ def _block_tail_backward(block, bn_tail, dout, dout_partial):
         if block.shortcut is not None:
             sc_part = block.shortcut.bn.bwd_reduce(dsum, mask_mode=0)
             co_t, co_s = bwd_finalize_many([(bn_tail, dout_partial), (block.shortcut.bn, sc_part)])
-            dh = bn_tail.backward_fused(dout, dout_partial, coeffs=co_t)
+            dh = bn_tail.backward_fused(dout, dout_partial, coeffs=co_t, ps_for=conv_tail)
             return dh, block.shortcut.backward(dsum, coeffs=co_s)
-        dh = bn_tail.backward_fused(dout, dout_partial)
+        dh = bn_tail.backward_fused(dout, dout_partial, ps_for=conv_tail)
     else:
-        dh, dsum = bn_tail.backward(dout, mask_src=block.out, mask_mode=1, want_masked=True)
+        dh, dsum = bn_tail.backward(dout, mask_src=block.out, mask_mode=1, want_masked=True, ps_for=conv_tail)
     dx = block.shortcut.backward(dsum) if block.shortcut is not None else dsum
     return dh, dx
 
@@ -845,10 +860,10 @@ class ResidualBlock(Layer):  # tf2/resnet.py:314-382
         """dout_partial given: dout is already ReLU-masked and the tail BN's reduce is done (fused into
         the next block's dgrad).  prev_tail: tail_info() of the block feeding this one -- its reduce is
         fused into this block's last dgrad.  Returns (dx, partial-or-None)."""
-        dh, dx = _block_tail_backward(self, self.bn2, dout, dout_partial)
+        dh, dx = _block_tail_backward(self, self.bn2, dout, dout_partial, self.conv2)
         self.out = None
         dm1, part1 = self.conv2.backward(dh, fuse_bn=self.bn1.fusion_info())
-        dh1 = self.bn1.backward_fused(dm1, part1)
+        dh1 = self.bn1.backward_fused(dm1, part1, ps_for=self.conv1)
         if prev_tail is not None and self.conv1.strides == 1:
             return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
         self.conv1.backward(dh1, dx_out=dx, accumulate=True)
@@ -909,7 +924,15 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
         if self.conv3.kernel is None:
             self.conv3.build(h.c, h.t.shape[-1])
         level = _conv3_fused_level()
-        return (training and not getattr(self, 'is_final', False) and RT.dtype == torch.bfloat16
+        # fp32 storage (round 6): the same fusion where one Gram tile spans conv3's input channels (ops.gram_supported: K = 64 / 128,
+        # i.e. the 56^2 and 28^2 blocks, which carry 3/4 of the tail bytes); SIMCLR_CONV3_FUSED_F32=0 keeps conv3 -> HBM -> bn_apply
+        if RT.dtype != torch.bfloat16:
+            import os
+            if os.environ.get('SIMCLR_CONV3_FUSED_F32', '1') in ('', '0') or not _conv3_stats_from_gram():
+                return False
+            if not ops.gram_supported(self.conv3.cin_p, RT.dtype):
+                return False
+        return (training and not getattr(self, 'is_final', False)
                 and self._foldable() and _bn_s2_enabled() and (level >= 2 or (level == 1 and sc_bn is None)))
 
     def tail_info(self):
@@ -935,33 +958,33 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
             dm2, part2 = self.conv3.backward_folded(dout, self.bn3, dout_partial, fuse_bn=self.bn2.fusion_info(),
                                                     s2_from_gemm=_bn_s2_enabled())
             self.bn3.saved = None
-            dh2 = self.bn2.backward_fused(dm2, part2)
+            dh2 = self.bn2.backward_fused(dm2, part2, ps_for=self.conv2)
             if self.conv2.strides == 1:
                 dm1, part1 = self.conv2.backward(dh2, fuse_bn=self.bn1.fusion_info())
-                dh1 = self.bn1.backward_fused(dm1, part1)
+                dh1 = self.bn1.backward_fused(dm1, part1, ps_for=self.conv1)
             else:
-                dh1, _ = self.bn1.backward(self.conv2.backward(dh2))
+                dh1, _ = self.bn1.backward(self.conv2.backward(dh2), ps_for=self.conv1)
             if prev_tail is not None:
                 return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
             self.conv1.backward(dh1, dx_out=dx, accumulate=True)
             return dx, None
-        dh3, dx = _block_tail_backward(self, self.bn3, dout, dout_partial)
+        dh3, dx = _block_tail_backward(self, self.bn3, dout, dout_partial, self.conv3)
         self.out = None
         if self.sk is not None:
             dsk = self.conv3.backward(dh3)
             if self.sk.strides == 1:
                 dm1, part1 = self.sk.backward(dsk, fuse_bn=self.bn1.fusion_info())
-                dh1 = self.bn1.backward_fused(dm1, part1)
+                dh1 = self.bn1.backward_fused(dm1, part1, ps_for=self.conv1)
             else:
-                dh1, _ = self.bn1.backward(self.sk.backward(dsk))
+                dh1, _ = self.bn1.backward(self.sk.backward(dsk), ps_for=self.conv1)
         else:
             dm2, part2 = self.conv3.backward(dh3, fuse_bn=self.bn2.fusion_info())
-            dh2 = self.bn2.backward_fused(dm2, part2)
+            dh2 = self.bn2.backward_fused(dm2, part2, ps_for=self.conv2)
             if self.conv2.strides == 1:
                 dm1, part1 = self.conv2.backward(dh2, fuse_bn=self.bn1.fusion_info())
-                dh1 = self.bn1.backward_fused(dm1, part1)
+                dh1 = self.bn1.backward_fused(dm1, part1, ps_for=self.conv1)
             else:
-                dh1, _ = self.bn1.backward(self.conv2.backward(dh2))
+                dh1, _ = self.bn1.backward(self.conv2.backward(dh2), ps_for=self.conv1)
         if prev_tail is not None:
             return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
         self.conv1.backward(dh1, dx_out=dx, accumulate=True)

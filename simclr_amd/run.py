@@ -242,6 +242,16 @@ def synthetic_eval_batches(batch, image_size, num_classes, device, seed=0, pool=
         i += 1
 
 
+def _check_device_health(strategy):
+    """Synchronise and raise if any in-kernel bounded wait of this process ever timed out: the peer-mapped SyncBN exchange
+    (comm.PeerStats: NaN-poisoned statistics) or a split-tail partner of the persistent convolution grid (wrong tile)."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if strategy is not None:
+        strategy.check_health(wait=True)
+    ops.check_split_tail_health()
+
+
 def perform_evaluation(model, data, eval_steps, ckpt, strategy, model_dir=None):
     """tf2/run.py:348-432: restore `ckpt` (weights + global step), run `eval_steps` batches through
     model(features, training=False), accumulate eval/label_top_1_accuracy, eval/label_top_5_accuracy and
@@ -377,11 +387,16 @@ def main(argv):
             for v in step_fn.metrics.values():
                 v.reset_states()
         if manager is not None and (step % checkpoint_steps == 0 or step == train_steps):   # :640-648 (every steps_per_loop)
+            # A timed-out statistics exchange poisons that step's statistics -- and the weights -- with NaN, and the per-step
+            # health check only sees the PREVIOUS step's copy: synchronise and inspect the sticky device counters NOW, so that a
+            # poisoned state is never written as `latest` (nor rotates a good checkpoint out).  Raises -> nothing is saved.
+            _check_device_health(strategy)
             # every replica records the new checkpoint (same name everywhere), replica 0 alone writes it: otherwise
             # the other replicas' `latest_checkpoint` would still name the resume point in train_then_eval
             manager.save(step, write=rank0)
             if strategy is not None:
                 dist.barrier()
+    _check_device_health(strategy)       # time-outs of the last steps are reported too (the loop may end between two log intervals)
     if FLAGS.mode == 'train_then_eval' and manager is not None:                           # :657-660
         edata = synthetic_eval_batches(FLAGS.eval_batch_size // R, FLAGS.image_size, num_classes, RT.device, seed=100 + rep)
         result = perform_evaluation(model, edata, eval_steps, manager.latest_checkpoint, strategy, FLAGS.model_dir)

@@ -869,6 +869,85 @@ def _ref64_conv(x, w, dy, k, s, pad, OH, OW, vchunk):
         yield v0, v1, y, dx, dw
 
 
+def ps_decode(t, kind='b16'):
+    """Pre-split block format (simclr_amd/csrc/common.h) -> float64: per 128-byte block of 32 channels, 16-byte chunk g < 4 holds the hi
+    pieces of channels {4g..4g+3, 16+4g..16+4g+3}, chunk 4 + g their lo pieces; value = hi + lo.  Returns (value, hi, lo)."""
+    C = t.shape[-1]
+    raw = t.detach().contiguous().view(torch.int16).reshape(-1, C // 32, 8, 8).cpu()
+    pt = torch.bfloat16 if kind == 'b16' else torch.float16
+    pieces = raw.view(pt).double()                              # [rows, blocks, chunk, 8]
+    ch = torch.tensor([[4 * g + i if i < 4 else 16 + 4 * g + i - 4 for i in range(8)] for g in range(4)])      # [4, 8] -> channel in block
+    hi = torch.zeros(raw.shape[0], C // 32, 32, dtype=torch.float64)
+    lo = torch.zeros_like(hi)
+    hi[:, :, ch.reshape(-1)] = pieces[:, :, :4].reshape(raw.shape[0], C // 32, 32)
+    lo[:, :, ch.reshape(-1)] = pieces[:, :, 4:].reshape(raw.shape[0], C // 32, 32)
+    shp = tuple(t.shape)
+    return (hi + lo).reshape(shp), hi.reshape(shp), lo.reshape(shp)
+
+
+def check_ps_backward(V, H, Cin, Cout, k, stride, seed=0, matmul='bf16x3'):
+    """The pre-split gradient path of the fp32 parity mode (round 6): simclr_bn_bwd_apply writes dx as (hi, lo) bf16 pieces per 128-byte
+    block, and the data-gradient / weight-gradient GEMMs of the convolution in front of that BatchNorm read the pieces without splitting
+    anything in their k-loops.  Checked: the stored pieces are exactly bf16(dx) and bf16(dx - hi) of the plain kernel's dx; the data
+    gradient (plain, and with the fused BatchNorm-backward reduce) is BITWISE the in-register-split result; the weight gradient (different
+    pixel order inside a k-step) against float64 of the three-term operands."""
+    ops.set_f32_matmul(matmul)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        pad = (k - 1) // 2
+        OH = (H + (k - 1) - k) // stride + 1
+        OW = (H + (k - 1) - k) // stride + 1
+        rnd = lambda shape, sc=1.0: torch.randn(shape, device=DEV, generator=g) * sc
+        x = rnd((V, H, H, Cin))
+        w = rnd((k, k, Cin, Cout), (k * k * Cin) ** -0.5)
+        w_d = ops.prep_weights(w, 1, torch.float32)
+        # a BatchNorm backward apply over the conv OUTPUT geometry [V, OH, OW, Cout] produces the gradient the conv's backward consumes
+        dy_in = rnd((V, OH, OW, Cout), 1e-3)
+        xc = rnd((V, OH, OW, Cout), 1.5) + 0.3
+        scale = torch.rand(Cout, device=DEV, generator=g) + 0.2
+        shift = 0.3 * rnd((Cout,))
+        mean = 0.2 * rnd((Cout,))
+        rstd = 0.5 + torch.rand(Cout, device=DEV, generator=g)
+        c1 = 1e-4 * rnd((Cout,))
+        c2 = 1e-4 * rnd((Cout,))
+        dx_plain, _ = ops.bn_bwd_apply(dy_in, xc, None, scale, shift, mean, rstd, c1, c2, 2)
+        dx_ps, _ = ops.bn_bwd_apply(dy_in, xc, None, scale, shift, mean, rstd, c1, c2, 2, ps_out=True)
+        assert ops.ps_kind(dx_ps) == 'b16'
+        tag = 'V%d %dx%d %d->%d k%d s%d' % (V, H, H, Cin, Cout, k, stride)
+        val, hi, lo = ps_decode(dx_ps)
+        ref = dx_plain.double().cpu()
+        hi_ref = dx_plain.bfloat16().double().cpu()
+        lo_ref = (dx_plain - dx_plain.bfloat16().float()).bfloat16().double().cpu()
+        res = [_res('ps_pieces_hi ' + tag, hi, hi_ref, 0.0), _res('ps_pieces_lo ' + tag, lo, lo_ref, 0.0),
+               _res('ps_value ' + tag, val, ref, 2.0 ** -16)]
+        # data gradient: bitwise the in-register split
+        d_plain = ops.conv2d_dgrad(dx_plain, w_d, k, k, stride, pad, H, H)
+        d_ps = ops.conv2d_dgrad(dx_ps, w_d, k, k, stride, pad, H, H)
+        res.append(_res('ps_dgrad_bitwise ' + tag, d_ps, d_plain, 0.0))
+        if stride == 1:
+            bn_x = rnd((V, H, H, Cin), 1.5) + 0.3
+            bn = dict(x=bn_x, mask=None, scale=torch.rand(Cin, device=DEV, generator=g) - 0.4, shift=0.3 * rnd((Cin,)),
+                      mean=0.2 * rnd((Cin,)), rstd=0.5 + torch.rand(Cin, device=DEV, generator=g), mode=2)
+            m_plain, p_plain = ops.conv2d_dgrad_bn(dx_plain, w_d, k, k, pad, H, H, bn)
+            m_ps, p_ps = ops.conv2d_dgrad_bn(dx_ps, w_d, k, k, pad, H, H, bn)
+            res.append(_res('ps_dgrad_bn_bitwise ' + tag, m_ps, m_plain, 0.0))
+            res.append(_res('ps_dgrad_bn_sums_bitwise ' + tag, ops.bn_reduce_slots(p_ps), ops.bn_reduce_slots(p_plain), 0.0))
+        # weight gradient: float64 of the exact operands (the three-term gate of check_conv), and close to the plain kernel
+        dw_plain = ops.conv2d_wgrad(x, dx_plain, k, k, stride, pad)
+        dw_ps = ops.conv2d_wgrad(x, dx_ps, k, k, stride, pad)
+        torch.cuda.synchronize()
+        xr = x.double().permute(0, 3, 1, 2)
+        wr = w.double().requires_grad_(True)
+        pe = (k - 1) - pad
+        yr = F.conv2d(F.pad(xr, (pad, pe, pad, pe)), wr.permute(3, 2, 0, 1), stride=stride)
+        yr.backward(dx_plain.double().permute(0, 3, 1, 2))
+        res.append(_res('ps_wgrad_vs_f64 ' + tag, dw_ps.view(k, k, Cin, Cout), wr.grad, 4e-5))
+        res.append(_res('ps_wgrad_vs_plain ' + tag, dw_ps, dw_plain, 4e-5))
+        return res
+    finally:
+        ops.set_f32_matmul('exact')
+
+
 def check_conv_bench_path(V, H, Cin, Cout, k, stride, dtype, seed=0, nsample=4096, bn_case=None, bwd_tol_scale=1.0,
                           rounded_stats=False):
     """Forward / dgrad / wgrad (and, for stride 1, the fused dgrad + BN-backward reduce) at BASELINE cfg2 layer
@@ -1205,6 +1284,81 @@ def check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f3
     gate('fixed_update_relnorm', (num / (den + 1e-300)) ** 0.5, 0.5 if emu else 1e-2)
     bm = max(rel(v.value, ns64[v.name]) for v in model.variables if v.name in ns64)
     gate('fixed_bn_moving_worst_rel', bm, 1e-2 if emu else 1e-5)
+    return res
+
+
+def check_step_at_baseline_size(depth=50, image_size=224, batch=128, f32_matmul='f16x3_3', sk_ratio=0.0, width_multiplier=1,
+                                num_classes=1000, seed=0, forward_only=False, lr=0.1, weight_decay=1e-6):
+    """parity at BASELINE.json sizes -- the persistent-grid / split-tail / tile decisions of the BENCH shapes end to end in
+    the fast parity mode.  One product step (or, forward_only, one training forward) against the torch-CPU float32 oracle (float64 of these
+    sizes does not fit the suite's budget; the fp32 oracle's own distance from float64 is ~1e-6 on these quantities, tests at batch 32):
+    loss <= 1e-3 relative and l2-normalised embeddings <= 1e-5 absolute (north_star's tolerances), gradient 1 - cos <= 1e-5 and relative
+    L2 <= 5e-3 over all trainable tensors.  Reference initialisation, image-like inputs."""
+    from collections import OrderedDict
+    from oracle.model_torch import Config, init_model, single_step_losses, train_step
+    from simclr_amd import model as model_lib
+    from simclr_amd.flags import FLAGS
+    from simclr_amd.resnet import RT
+    from simclr_amd.run import make_single_step
+    cfg = Config(resnet_depth=depth, image_size=image_size, num_classes=num_classes, weight_decay=weight_decay, sk_ratio=sk_ratio,
+                 width_multiplier=width_multiplier)
+    params, state = init_model(cfg, seed=seed, randomize_bn=False)
+    g = torch.Generator().manual_seed(seed + 1)
+    images = structured_images(batch, image_size, 2, g)
+    labels = torch.nn.functional.one_hot(torch.randint(0, num_classes, (batch,), generator=g), num_classes).float()
+    if forward_only:
+        with torch.no_grad():
+            t32 = single_step_losses(cfg, params, state, images, labels)
+    else:
+        momenta = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+        _, _, _, t32 = train_step(cfg, params, state, momenta, images, labels, lr)
+    FLAGS.reset()
+    FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='f32', use_blur=False, weight_decay=weight_decay,
+                 train_batch_size=batch, f32_matmul=f32_matmul, sk_ratio=sk_ratio, width_multiplier=width_multiplier)
+    RT.reset()
+    RT.device = torch.device(DEV)
+    model = model_lib.Model(num_classes)
+    with torch.no_grad():
+        model(torch.zeros(2, image_size, image_size, 6, device=DEV), training=True)
+    allv = dict(params); allv.update(state)
+    for v in model.variables:
+        v.value.copy_(allv[v.name].to(DEV))
+    RT.weights_version += 1
+    tag = 'R%d%s%s %dpx b%d f32/%s%s' % (depth, '' if width_multiplier == 1 else ' %dx' % width_multiplier, ' SK' if sk_ratio > 0 else '',
+                                         image_size, batch, f32_matmul, ' forward' if forward_only else '')
+    res = []
+
+    def gate(name, err, tol):
+        res.append(dict(name='%s %s' % (name, tag), err=float(err), tol=float(tol), scale=1.0, ok=bool(err <= tol), nbad=0, numel=1))
+
+    if forward_only:
+        from simclr_amd import objective as obj_lib
+        ops.begin_step(torch.device(DEV))
+        proj, sup = model(images.to(DEV), training=True)
+        con, _, _ = obj_lib.add_contrastive_loss(proj, hidden_norm=True, temperature=FLAGS.temperature, strategy=None)
+        torch.cuda.synchronize()
+        gate('baseline_con_loss_rel', abs(float(con.value.reshape(-1)[0]) - float(t32['con_loss'])) / abs(float(t32['con_loss'])), 1e-3)
+        gate('baseline_embeddings_abs', float((con.normalized.double().cpu() - t32['z'].double()).abs().max()), 1e-5)
+        gate('baseline_sup_logits_rel', float((sup.dense().double().cpu() - t32['sup_logits'].double()).abs().max()) /
+             (float(t32['sup_logits'].double().abs().max()) + 1e-30), 1e-3)
+        ops.end_step()
+    else:
+        step_fn = make_single_step(model, model_lib.build_optimizer(lr), None)
+        out = step_fn(images.to(DEV), {'labels': labels.to(DEV)})
+        torch.cuda.synchronize()
+        gate('baseline_con_loss_rel', abs(float(out['con_loss'].value.reshape(-1)[0]) - float(t32['con_loss'])) / abs(float(t32['con_loss'])), 1e-3)
+        gate('baseline_sup_loss_rel', abs(float(out['sup_loss'].value.reshape(-1)[0]) - float(t32['sup_loss'])) / abs(float(t32['sup_loss'])), 1e-3)
+        gate('baseline_embeddings_abs', float((out['con_loss'].normalized.double().cpu() - t32['z'].detach().double()).abs().max()), 1e-5)
+        keys = list(params.keys())
+        byname = {v.name: v for v in model._flat_order}
+        g32 = torch.cat([(t32['grads'][k] if t32['grads'][k] is not None else torch.zeros_like(params[k])).double().reshape(-1) for k in keys])
+        gm = torch.cat([byname[k].grad.double().reshape(-1).cpu() for k in keys])
+        gate('baseline_grad_1-cos', 1.0 - float((gm * g32).sum() / gm.norm() / g32.norm()), 1e-5)
+        gate('baseline_grad_relnorm', float((gm - g32).norm() / g32.norm()), 5e-3)
+    del model
+    FLAGS.reset()
+    RT.reset()
+    torch.cuda.empty_cache()
     return res
 
 
@@ -1554,6 +1708,45 @@ def check_conv_fwd_bn_apply(V, H, Cin, Cout, k=1, stride=1, with_res=True, relu=
     sc_ = float(ref.abs().max())
     res_l.append(dict(name='fwd_bn_apply_value ' + tag, err=err, tol=2.0 ** -7 * sc_, scale=sc_, ok=bool(err <= 2.0 ** -7 * sc_), nbad=0, numel=y.numel()))
     return res_l
+
+
+def check_conv_fwd_bn_apply_f32(V, H, Cin, Cout, matmul='f16x3_3', with_res=True, relu=True, res_bn=False, seed=0):
+    """Round 6: the fused bottleneck tail in fp32 storage -- simclr_conv2d_fwd_bn_apply(SIMCLR_DT_F32) applies bn_apply's arithmetic to
+    the fp32 accumulators in the convolution's epilogue: output and ReLU bit mask (one byte per 4 channels) BIT-IDENTICAL to
+    conv2d_fwd -> bn_apply in the same matrix arithmetic."""
+    ops.set_f32_matmul(matmul)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        x = torch.randn(V, H, H, Cin, device=DEV, generator=g)
+        w = torch.randn(1, 1, Cin, Cout, device=DEV, generator=g) * Cin ** -0.5
+        res = torch.randn(V, H, H, Cout, device=DEV, generator=g) if with_res else None
+        gamma = torch.rand(Cout, device=DEV, generator=g) + 0.5
+        beta = 0.2 * torch.randn(Cout, device=DEV, generator=g)
+        w_t = ops.prep_weights(w, 0, torch.float32)
+        M = V * H * H
+        st = ops.conv_stats(M, Cout, DEV)
+        c = ops.conv2d_fwd(x, w_t, 1, 1, 1, 0, H, H, stats=st)
+        mm, mv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        _, _, scale, shift = ops.bn_finalize(None, M, gamma, beta, mm, mv, 0.9, partial=st)
+        rs = (torch.rand(Cout, device=DEV, generator=g) + 0.5) if res_bn else None
+        rb = (0.3 * torch.randn(Cout, device=DEV, generator=g)) if res_bn else None
+        y_ref, bits_ref = (ops.bn_apply(c, scale, shift, relu, res=res, rscale=rs, rshift=rb, want_bits=True) if relu
+                           else (ops.bn_apply(c, scale, shift, relu, res=res, rscale=rs, rshift=rb), None))
+        out = ops.conv2d_fwd_bn_apply(x, w_t, 1, 1, 1, 0, H, H, scale, shift, res=res, relu=relu, want_bits=relu, rscale=rs, rshift=rb)
+        y, bits = out if relu else (out, None)
+        torch.cuda.synchronize()
+        tag = 'V%d %dx%d %d->%d f32/%s res%d relu%d resbn%d' % (V, H, H, Cin, Cout, matmul, int(with_res), int(relu), int(res_bn))
+
+        def same(name, a, b):
+            ok = bool(torch.equal(a, b))
+            nbad = 0 if ok else int((a != b).sum())
+            return dict(name='fwd_bn_apply_f32_%s %s' % (name, tag), err=float(nbad), tol=0.0, scale=0.0, ok=ok, nbad=nbad, numel=a.numel())
+        out_l = [same('y', y_ref.view(torch.int32), y.view(torch.int32))]
+        if relu:
+            out_l.append(same('bits', bits_ref.reshape(-1), bits.reshape(-1)))
+        return out_l
+    finally:
+        ops.set_f32_matmul('exact')
 
 
 def check_conv_pivoted_stats(V, H, Cin, Cout, k, stride, offset=300.0, seed=0, matmul='exact'):

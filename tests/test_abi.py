@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in sig:
         assert hasattr(dll, name), 'libsimclr_hip.so does not export %s' % name
     L = _lib.lib()
-    assert L.abi_version() == _lib.ABI_VERSION == 7 and L.lars_chunk_elems() == 8192
+    assert L.abi_version() == _lib.ABI_VERSION == 8 and L.lars_chunk_elems() == 8192
     assert L.ntxent_workspace_bytes(512, 512, 128) > 0
     assert L.conv2d_wgrad_workspace_bytes(8, 56, 56, 64, 64, 3, 3, _lib.DT_BF16) > 0
 

@@ -97,8 +97,23 @@ def test_parity_mode_and_ntxent_accounting_fields():
     import inspect
     b = _bench()
     src = inspect.getsource(b.main)
-    for needle in ('split_mode_roofline', "'families'", 'bf16_terms', 'traffic_measured_in_run', "kernels=7", 'us_events_in_step',
+    for needle in ('split_roofline', "'families'", 'mfma_terms', 'traffic_measured_in_run', "kernels=7", 'us_events_in_step',
                    'rccl_ranks_seen', 'rank_devices', 'stat_transport'):
-        assert needle in src.replace('families=fams', "'families'"), needle
+        assert needle in src, needle
     csrc = inspect.getsource(b.cpu_baseline)
     assert 'warm=3' in csrc and 'min_steps=10' in csrc
+
+
+def test_headline_is_the_tolerance_meeting_mode():
+    """with no flags the top-level value / dtype / roofline of the line belong to the fastest mode that meets
+    north_star's tolerances (fp32 storage, three fp16-piece terms forward, three bf16-piece terms backward); the bf16 speed mode is a
+    `speed_mode` sub-block, and the line says whether its own in-run parity measurement met the tolerances."""
+    import inspect
+    import re
+    b = _bench()
+    src = inspect.getsource(b.main)
+    assert re.search(r"'--dtype', default='f32'", src) and re.search(r"'--f32_matmul', default='f16x3_3'", src)
+    for needle in ("'speed_mode'", "'north_star_met'", "'f32_mode'", "'parity_mode_bf16x6'", "'dtype_detail'"):
+        assert needle in src, needle
+    from simclr_amd import ops
+    assert ops.F32_MATMUL_TERMS['f16x3_3'] == (13, 3)

@@ -120,6 +120,16 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case, matmul):
     _assert(gc.check_conv_bench_path(V, H, Cin, Cout, k, s, F32, bn_case=bn_case, bwd_tol_scale=2.0))
 
 
+@pytest.mark.parametrize('V,H,Cin,Cout,k,s', [(3, 14, 64, 128, 3, 1), (2, 16, 64, 256, 1, 2), (2, 15, 128, 64, 3, 2), (130, 1, 128, 64, 1, 1),
+                                              (64, 56, 256, 64, 1, 1), (64, 28, 128, 128, 3, 1), (2, 9, 192, 96, 3, 1), (5, 7, 512, 2048, 1, 1)])
+def test_conv_backward_with_presplit_gradient(V, H, Cin, Cout, k, s):
+    """Round 6: the gradient between a BatchNorm backward and the convolution in front of it kept as (hi, lo) bf16 pieces per 128-byte block
+    (csrc/common.h): pieces exact, data gradient bitwise the in-register split, weight gradient (transposing LDS reads) within the
+    three-term gate."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_ps_backward(V, H, Cin, Cout, k, s))
+
+
 def _reference_fixtures():
     import importlib.util
     spec = importlib.util.spec_from_file_location('make_reference_golden', os.path.join(os.path.dirname(__file__), 'golden', 'make_reference_golden.py'))
@@ -451,6 +461,33 @@ def test_train_step_resnet50_224_batch32_fast_parity_mode(matmul):
     res = gc.check_train_step_fixed(depth=50, image_size=224, batch=32, compute_dtype='f32', f32_matmul=matmul)
     for r in res:
         print('%-60s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
+    _assert(res)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('V,H,Cin,Cout,matmul,res_bn', [(8, 28, 128, 512, 'f16x3_3', False), (3, 56, 64, 256, 'f16x3_3', True),
+                                                         (5, 14, 64, 256, 'bf16x6_3', False), (2, 9, 128, 96, 'exact', True),
+                                                         (64, 56, 64, 256, 'f16x3_3', False)])
+def test_conv_fused_bn_apply_tail_f32(V, H, Cin, Cout, matmul, res_bn):
+    """The fused bottleneck tail (conv3 + bn3 + shortcut + ReLU + mask bits, tf2/resnet.py:470-487) in fp32 storage: bitwise the
+    unfused conv -> bn_apply."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_conv_fwd_bn_apply_f32(V, H, Cin, Cout, matmul=matmul, res_bn=res_bn))
+
+
+@pytest.mark.parametrize('case', ['r50_224_b128', 'r50_2x_sk_224_b16', 'r152_3x_sk_224_b2_forward'])
+def test_parity_at_baseline_sizes(case):
+    """the bench shapes end to end in the fast parity mode (fp32 storage, three fp16-piece terms forward, three
+    bf16-piece terms backward, pre-split gradients) against the torch-CPU float32 oracle: one ResNet-50 / 224 px step at batch 128 (256
+    views: persistent grids walk several tiles per workgroup), one ResNet-50 2x + SK step at 224 px / batch 16 (cfg4's widths), and the
+    ResNet-152 3x + SK training forward at real width / batch 2 (cfg5: 795 M parameters)."""
+    from tests import gpu_checks as gc
+    kw = dict(r50_224_b128=dict(depth=50, batch=128),
+              r50_2x_sk_224_b16=dict(depth=50, batch=16, sk_ratio=0.0625, width_multiplier=2),
+              r152_3x_sk_224_b2_forward=dict(depth=152, batch=2, sk_ratio=0.0625, width_multiplier=3, forward_only=True))[case]
+    res = gc.check_step_at_baseline_size(image_size=224, **kw)
+    for r in res:
+        print('%-70s err=%.3e tol=%.3e' % (r['name'], r['err'], r['tol']))
     _assert(res)
     torch.cuda.empty_cache()
 
