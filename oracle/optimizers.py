@@ -33,6 +33,6 @@ def adam_apply(w, g, m, v, lr, t, beta_1=0.9, beta_2=0.999, epsilon=1e-7, l2=0.0
     omb1, omb2 = float(np.float32(1.0) - np.float32(beta_1)), float(np.float32(1.0) - np.float32(beta_2))
     m = b1 * m + omb1 * g
     v = b2 * v + omb2 * g * g
-    lr_t = lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+    lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)        # beta_power = pow(float32(beta), t) in the TensorFlow kernel
     w = w - lr_t * m / (np.sqrt(v) + epsilon)
     return w, m, v

@@ -1245,6 +1245,62 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         }
       }
       }   // eh
+    } else if constexpr (FAPPLY) {
+    // ---- fp32 fused BatchNorm-apply epilogue: y = act(conv * scale + shift + res [* rscale + rshift]) with bn_apply<float>'s arithmetic
+    // (csrc/bn.hip) on the fp32 accumulators -- bitwise what conv -> HBM -> bn_apply produces.  All residual operands of the tile are
+    // requested up front (one memory round trip per tile, not one per fragment); ReLU bits: one byte per 16-byte chunk = one lane's 4
+    // channels, the 4 lane groups of a fragment row hold 4 consecutive bytes -> one 4-byte store.
+    long long offs[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) offs[mi] = row_off(m0 + wm * (MI * 16) + mi * 16 + fl);
+    const bool n16 = (p.N & 15) == 0;
+    constexpr int MB = 1;                        // fragment rows per batch of residual loads (16 registers in flight; 2 rows spill)
+#pragma unroll
+    for (int mb = 0; mb < MI; mb += MB) {
+    float4 rr[MI][NI];
+    if (fa_res) {
+#pragma unroll
+      for (int mi = mb; mi < mb + MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int n = n0 + wn * 64 + ni * 16 + g * 4;
+          const bool ok = offs[mi] >= 0 && n < p.N;
+          rr[mi][ni] = *(const float4*)((const float*)p.bn_x + (ok ? offs[mi] + n : 0));      // masked lanes read (and ignore) element 0
+        }
+    }
+#pragma unroll
+    for (int mi = mb; mi < mb + MB; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int nl = wn * 64 + ni * 16 + g * 4, n = n0 + nl;
+        const bool ok = offs[mi] >= 0 && n < p.N;
+        const float4 sc = *(const float4*)(bnp + nl), sh = *(const float4*)(bnp + BN + nl);
+        float o[4] = {fmaf(acc[ni][mi][0], sc.x, sh.x), fmaf(acc[ni][mi][1], sc.y, sh.y), fmaf(acc[ni][mi][2], sc.z, sh.z), fmaf(acc[ni][mi][3], sc.w, sh.w)};
+        if (fa_res) {
+          const float4 r = rr[mi][ni];
+          if (fa_rbn) {
+            const float4 rs = *(const float4*)(bnp + 2 * BN + nl), rb = *(const float4*)(bnp + 3 * BN + nl);
+            o[0] += fmaf(r.x, rs.x, rb.x); o[1] += fmaf(r.y, rs.y, rb.y); o[2] += fmaf(r.z, rs.z, rb.z); o[3] += fmaf(r.w, rs.w, rb.w);
+          } else { o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+        }
+        if (fa_relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+        }
+        if (ok) *(float4*)(Y + offs[mi] + n) = make_float4(o[0], o[1], o[2], o[3]);
+        if (fa_mask) {
+          const unsigned bits = (o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u);
+          if (n16) {       // validity is uniform over the 4 lane groups of a row when N is a multiple of 16
+            const unsigned b1 = __shfl(bits, lane + 16, 64), b2 = __shfl(bits, lane + 32, 64), b3 = __shfl(bits, lane + 48, 64);
+            if (ok && g == 0) *(unsigned*)((unsigned char*)p.bn_mask + ((offs[mi] + n) >> 2)) = bits | (b1 << 8) | (b2 << 16) | (b3 << 24);
+          } else if (ok) {
+            ((unsigned char*)p.bn_mask)[(offs[mi] + n) >> 2] = (unsigned char)bits;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the next batch's 32 load registers are not live before this batch has been stored
+    }   // mb
     } else {
     // ---- fp32 parity mode: registers -> NHWC (4 consecutive channels per lane), no LDS, no barrier
     float4 pvt[NI];                                   // pivoted statistics: this lane's 4 x NI pivots, once per tile
@@ -1285,29 +1341,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         if (off >= 0 && n < p.N) {
           T* dst = Y + off + n;
           float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-          if constexpr (FAPPLY && sizeof(T) == 4) {
-            // y = act(conv * scale + shift + res [* rscale + rshift]) with bn_apply<float>'s arithmetic (csrc/bn.hip) on the fp32
-            // accumulators: bitwise what conv -> HBM -> bn_apply produces; ReLU bits: one byte per 16-byte chunk = this lane's 4 channels
-            const int nl = wn * 64 + ni * 16 + g * 4;
-            const float4 sc = *(const float4*)(bnp + nl), sh = *(const float4*)(bnp + BN + nl);
-            float o[4] = {fmaf(v[0], sc.x, sh.x), fmaf(v[1], sc.y, sh.y), fmaf(v[2], sc.z, sh.z), fmaf(v[3], sc.w, sh.w)};
-            if (fa_res) {
-              const float4 r = *(const float4*)((const float*)p.bn_x + off + n);
-              if (fa_rbn) {
-                const float4 rs = *(const float4*)(bnp + 2 * BN + nl), rb = *(const float4*)(bnp + 3 * BN + nl);
-                o[0] += fmaf(r.x, rs.x, rb.x); o[1] += fmaf(r.y, rs.y, rb.y); o[2] += fmaf(r.z, rs.z, rb.z); o[3] += fmaf(r.w, rs.w, rb.w);
-              } else { o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
-            }
-            if (fa_relu) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
-            }
-            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-            if (fa_mask)
-              ((unsigned char*)p.bn_mask)[(off + n) >> 2] =
-                  (unsigned char)((o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u));
-            continue;
-          }
           if (EXT) {
             const float4 bi = *(const float4*)(bnp + 4 * BN + wn * 64 + ni * 16 + g * 4);
             v[0] += bi.x; v[1] += bi.y; v[2] += bi.z; v[3] += bi.w;
@@ -3857,10 +3890,14 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
   } else {
     // fp32 storage: the forward terms of simclr_set_f32_matmul (0 = exact fp32 MFMA; SIMCLR_STEM_SPLIT=0 keeps the exact kernel)
     static const bool stem_split_on = !getenv("SIMCLR_STEM_SPLIT") || atoi(getenv("SIMCLR_STEM_SPLIT")) != 0;
-    const int spl = stem_split_on ? (terms == 13 ? 6 : terms) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
+    // (13 = three fp16-piece terms, both operands split in registers: images lie in [0, 1], and the stem's weights -- fan-in 147, |w| ~ 0.1 --
+    // keep ~2^-21 relative in their unscaled lo pieces; SIMCLR_STEM_F16=0 keeps six bf16 terms)
+    static const bool stem_f16_on = !getenv("SIMCLR_STEM_F16") || atoi(getenv("SIMCLR_STEM_F16")) != 0;
+    const int spl = stem_split_on ? ((terms == 13 && !stem_f16_on) ? 6 : terms) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
 #define LSF(STv)                                                                                              \
     do {                                                                                                       \
-      if (spl == 3) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 3>), grid, dim3(256), lds, stream, p);    \
+      if (spl == 13) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 13>), grid, dim3(256), lds, stream, p);  \
+      else if (spl == 3) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 3>), grid, dim3(256), lds, stream, p);    \
       else if (spl == 6) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 6>), grid, dim3(256), lds, stream, p); \
       else hipLaunchKernelGGL((stem_conv_fwd<float, STv>), grid, dim3(256), lds, stream, p);                   \
     } while (0)

@@ -19,11 +19,12 @@ def test_oracle_sgd_and_adam_hand_derived():
     w, m, v = oo.adam_apply([1.0], [0.5], [0.0], [0.0], 0.001, 1)
     # (1 - beta) is formed in float32, as in the TensorFlow kernel: 1 - 0.9f = 0.100000024, 1 - 0.999f = 0.00099998713
     assert abs(m[0] - 0.05) < 2e-8 and abs(v[0] - 0.00025) < 2e-8 and abs(v[0] / 0.00025 - 1 + 1.2875e-5) < 1e-7
-    want = 1.0 - 0.001 * (np.sqrt(0.001) / 0.1) * m[0] / (np.sqrt(v[0]) + 1e-7)
+    b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))
+    want = 1.0 - 0.001 * (np.sqrt(1 - b2) / (1 - b1)) * m[0] / (np.sqrt(v[0]) + 1e-7)
     assert abs(w[0] - want) < 1e-15 and abs(w[0] - (1.0 - 0.001)) < 1e-7          # the first Adam step moves by ~lr
     # second step: the bias correction moves with t
     w2, m2, v2 = oo.adam_apply(w, [0.25], m, v, 0.001, 2)
-    lr_t = 0.001 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    lr_t = 0.001 * np.sqrt(1 - b2 ** 2) / (1 - b1 ** 2)
     assert abs(m2[0] - (0.9 * 0.05 + 0.1 * 0.25)) < 1e-7
     assert abs(w2[0] - (w[0] - lr_t * m2[0] / (np.sqrt(v2[0]) + 1e-7))) < 1e-15
 
