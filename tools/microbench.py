@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--what', default='conv,bn,ntxent,lars')
     ap.add_argument('--out', default='gpurun_out/microbench.json')
+    ap.add_argument('--ps', action='store_true', help='--dtype f32 with three backward terms: time dgrad / wgrad on a pre-split gradient operand')
     ap.add_argument('--f32_matmul', default='exact', help="--dtype f32: matrix arithmetic (ops.set_f32_matmul), e.g. bf16x6_3 = the parity mode")
     args = ap.parse_args()
     if args.dtype != 'bf16':
@@ -75,6 +76,10 @@ def main():
             dx = torch.empty(V, H, H, Cin, device=dev, dtype=dt)
             dw = torch.empty(k * k * Cin, Cout, device=dev)
             stats = ops.conv_stats(V * OH * OH, Cout, dev)
+            if args.ps and dt == torch.float32 and Cout % 32 == 0 and Cin % 64 == 0:
+                # the gradient operand as the BatchNorm backward hands it over in the parity mode: pre-split (hi, lo) bf16 pieces
+                one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+                dy, _ = ops.bn_bwd_apply(dy, dy, None, one, zero, zero, one, zero, zero, 0, ps_out=True)
             t_f = timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=stats, out=y), args.iters)
             t_n = timeit(lambda: ops.conv2d_fwd(x, w_t, k, k, s, pad, OH, OH, stats=None, out=y), args.iters)
             t_d = timeit(lambda: ops.conv2d_dgrad(dy, w_d, k, k, s, pad, H, H, out=dx), args.iters)
