@@ -57,6 +57,10 @@ int simclr_probe(int which, const void* a, const void* b, void* out, simclr_stre
 int simclr_l2norm_fwd(const float* x, float* z, float* inv, int rows, int D, simclr_stream_t stream);
 int simclr_l2norm_bwd(const float* z, const float* inv, const float* dz, float* dx, int rows, int D,
                       simclr_stream_t stream);
+/* Matrix arithmetic of the sweeps (round 6, opt-in): the D argument of simclr_ntxent_fwd / _bwd may carry SIMCLR_FMT_TERMS(13) --
+ * every fp32 product of S = Q K^T and of dF += T^T dS then runs as three fp16-piece MFMA terms (~2^-22 per product, i.e.
+ * ~2^-22 / T on the logits) instead of the fp32-input MFMA (1/16 of the 16-bit rate).  Only for l2-NORMALISED rows (|z| <= 1 lies
+ * in fp16's range; tf2/objective.py:53-54 hidden_norm=True); both calls of one loss must use the same setting. */
 size_t simclr_ntxent_workspace_bytes(int n, int N, int D);
 /* objective.py:55-87 + metrics.py:28-31.  z_local [2n,D] = [hidden1;hidden2] of this replica,
  * z_all [2N,D] = [hidden1_large;hidden2_large] (objective.py:60-61), N = R*n, rank = replica id

@@ -21,6 +21,7 @@
 // streamed rows per 16x16 tile -> the online softmax is lane-local; only the final
 // merge over the 4 lane groups needs shuffles (xor 16, 32).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -68,6 +69,75 @@ __device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ 
   }
 }
 
+// ---- split-fp16 sweeps (round 6, opt-in: D argument carries SIMCLR_FMT_TERMS(13)) ------------------------------------------------
+// The sweeps are bound by the fp32-input matrix pipe (v_mfma_f32_16x16x4_f32: 1/16 of the 16-bit rate).  l2-normalised rows
+// (tf2/objective.py:53-54) lie in [-1, 1] -- inside fp16's range -- so every fp32 product can run as THREE fp16-piece terms
+// (x = hi + lo, 11-bit pieces: hi*hi + hi*lo + lo*hi, ~2^-22 per product; csrc/conv.hip mma_f32_chunks has the argument) on
+// v_mfma_f32_16x16x32_f16: the logits carry ~2^-22 / T absolute error, three decimal orders inside the 2e-5 fixture gates at T = 0.1.
+// The streamed tile sits in LDS PRE-SPLIT (common.h block format per 128-byte block, 16-byte slots XOR-swizzled by the row): the
+// S = Q K^T fragments are two 16-byte reads (hi, lo) per 32-element k-step, the transposed fragments of the second product
+// (dF += T^T dS) come from ds_read_b64_tr_b16 on the hi / lo runs, and dS is split in registers.  Not for un-normalised inputs.
+typedef __attribute__((ext_vector_type(8))) _Float16 nt_f16x8;
+typedef __attribute__((ext_vector_type(4))) short nt_s16x4;
+typedef __attribute__((address_space(3))) nt_s16x4 nt_lds_s16x4;
+__device__ __forceinline__ f32x4 nt_mma_f16(const u32x4& a, const u32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nt_f16x8, a), __builtin_bit_cast(nt_f16x8, b), c, 0, 0, 0);
+}
+// byte offset of 16-byte slot `slot` (block * 8 + t) of row r in a pre-split LDS tile of D floats per row
+template <int D> __device__ __forceinline__ int ps_slot(int r, int slot) { return r * (D * 4) + ((slot ^ (r & 15)) << 4); }
+// one 16-byte fp32 chunk (channels 4c..4c+3 of row r) -> its hi quad and lo quad in the pre-split tile
+template <int D> __device__ __forceinline__ void ps_put(unsigned char* lds, int r, int c, const float4& v) {
+  uint32_t h0, l0, h1, l1;
+  split_pair<true>(v.x, v.y, h0, l0);
+  split_pair<true>(v.z, v.w, h1, l1);
+  const int b = c >> 3, cc = c & 7;
+  unsigned char* p = lds + ps_slot<D>(r, b * 8 + (cc & 3)) + (cc >> 2) * 8;
+  *(u32x2*)p = (u32x2){h0, h1};
+  *(u32x2*)(lds + ps_slot<D>(r, b * 8 + 4 + (cc & 3)) + (cc >> 2) * 8) = (u32x2){l0, l1};
+}
+template <int D>
+__device__ __forceinline__ void tile_store_ps(float* lds, const float4* pf, int tid) {
+  constexpr int C = D / 4;
+#pragma unroll
+  for (int j = 0; j < kTile * C / 256; ++j) {
+    const int idx = tid + j * 256;
+    ps_put<D>((unsigned char*)lds, idx / C, idx % C, pf[j]);
+  }
+}
+template <int D>
+__device__ __forceinline__ void load_tile_ps(float* lds, const float* __restrict__ src, int row0, int nrows_total, int tid) {
+  constexpr int C = D / 4;
+  for (int idx = tid; idx < kTile * C; idx += 256) {
+    const int r = idx / C, c = idx % C;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < nrows_total) v = *(const float4*)(src + (size_t)(row0 + r) * D + c * 4);
+    ps_put<D>((unsigned char*)lds, r, c, v);
+  }
+}
+// this lane's fixed-row operand of 32-element k-step s (floats 32 s + 4 g .. and 32 s + 16 + 4 g ..) as fp16 pieces
+__device__ __forceinline__ void split_fixed(const float4& a, const float4& b, u32x4& hi, u32x4& lo) {
+  uint32_t h, l;
+  split_pair<true>(a.x, a.y, h, l); hi[0] = h; lo[0] = l;
+  split_pair<true>(a.z, a.w, h, l); hi[1] = h; lo[1] = l;
+  split_pair<true>(b.x, b.y, h, l); hi[2] = h; lo[2] = l;
+  split_pair<true>(b.z, b.w, h, l); hi[3] = h; lo[3] = l;
+}
+// S fragment (16 streamed rows x 16 fixed rows) of one sub-tile from the pre-split tile: acc[r] = <T[sub*16 + 4g + r], F[fl]>
+template <int D>
+__device__ __forceinline__ f32x4 s_frag_f16(const float* lds, int trow, int g, const u32x4* ffh, const u32x4* ffl) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const unsigned char* base = (const unsigned char*)lds;
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s) {
+    const u32x4 th = *(const u32x4*)(base + ps_slot<D>(trow, s * 8 + g));
+    const u32x4 tl = *(const u32x4*)(base + ps_slot<D>(trow, s * 8 + 4 + g));
+    acc = nt_mma_f16(tl, ffh[s], acc);
+    acc = nt_mma_f16(th, ffl[s], acc);
+    acc = nt_mma_f16(th, ffh[s], acc);
+  }
+  return acc;
+}
+
 // online (max,sum) merge in the base-2 domain
 __device__ __forceinline__ void ml_merge(float& m, float& l, float m2, float l2) {
   float mn = fmaxf(m, m2);
@@ -84,7 +154,7 @@ __device__ __forceinline__ void arg_merge(float& v, int& i, float v2, int i2) {
 // part[split][row][8] = {m0, l0, m1, l1, pos, argval, argidx(bits), 0}
 //   set0 = key cols [0,N), set1 = key cols [N,2N); values are logits*log2(e).
 // ------------------------------------------------------------------------------
-template <int D>
+template <int D, bool F16 = false>
 __global__ __launch_bounds__(256) void ntxent_fwd_partial(
     const float* __restrict__ zq, const float* __restrict__ zk, int n, int N, int rank,
     float scale2 /* log2(e)/T */, int tiles_per_split, float* __restrict__ part, int rows_pad) {
@@ -104,6 +174,11 @@ __global__ __launch_bounds__(256) void ntxent_fwd_partial(
   }
   float m0 = -INFINITY, l0 = 0.f, m1 = -INFINITY, l1 = 0.f, pos = -INFINITY, av = -INFINITY;
   int ai = 0x7fffffff;
+  u32x4 ffh[D / 32], ffl[D / 32];
+  if constexpr (F16) {
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) split_fixed(ff[2 * s], ff[2 * s + 1], ffh[s], ffl[s]);
+  }
 
   const int tile_begin = blockIdx.y * tiles_per_split;
   const int ntiles = (two_N + kTile - 1) / kTile;
@@ -112,13 +187,16 @@ __global__ __launch_bounds__(256) void ntxent_fwd_partial(
   if (tile_begin < tile_end) tile_fetch<D>(pf, zk, tile_begin * kTile, two_N, tid);
   for (int kt = tile_begin; kt < tile_end; ++kt) {
     __syncthreads();
-    tile_store<D>(lds, pf, tid);
+    if constexpr (F16) tile_store_ps<D>(lds, pf, tid); else tile_store<D>(lds, pf, tid);
     __syncthreads();
     if (kt + 1 < tile_end) tile_fetch<D>(pf, zk, (kt + 1) * kTile, two_N, tid);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const int trow = sub * 16 + fl;
+      if constexpr (F16) {
+        acc = s_frag_f16<D>(lds, trow, g, ffh, ffl);
+      } else {
 #pragma unroll
       for (int s = 0; s < D / 16; ++s) {
         float4 tf = *(const float4*)(lds + trow * D + (((4 * s + g) ^ (trow & 15)) * 4));
@@ -126,6 +204,7 @@ __global__ __launch_bounds__(256) void ntxent_fwd_partial(
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf.y, ff[s].y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf.z, ff[s].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf.w, ff[s].w, acc, 0, 0, 0);
+      }
       }
       const int col0 = kt * kTile + sub * 16 + g * 4;
 #pragma unroll
@@ -246,7 +325,7 @@ __global__ __launch_bounds__(256) void ntxent_reduce_out(const float* __restrict
 // applied by the combine kernel.  The query-fixed instance also accumulates the
 // contrast-entropy term of tf2/metrics.py:33-35 (a rows, ab block only).
 // ------------------------------------------------------------------------------
-template <int D, bool FIXED_IS_QUERY>
+template <int D, bool FIXED_IS_QUERY, bool F16 = false>
 __device__ __forceinline__ void ntxent_bwd_sweep_body(
     float* lds, const float* __restrict__ fixed_mat, int fixed_rows, const float* __restrict__ stream_mat,
     int stream_rows, int n, int N, int rank, float scale2, const float* __restrict__ row_stats,
@@ -279,14 +358,81 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
   const int tile_end = min(ntiles, tile_begin + tiles_per_split);
   // (prefetching one tile ahead into registers, as the forward sweep does, was measured SLOWER here: on top of the 32 + 32
   // accumulator / fixed-row registers it costs a wave of occupancy or spills -- cfg3 shape 183 -> 193 us, profiles/r03_notes.md)
+  u32x4 ffh[D / 32], ffl[D / 32];
+  if constexpr (F16) {
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) split_fixed(ff[2 * s], ff[2 * s + 1], ffh[s], ffl[s]);
+  }
+  // dS of one 16 x 16 fragment from its logits (acc): softmax - onehot(pos), masked column -> 0; entropy term of the ab block
+  auto ds_of = [&](const f32x4& acc, int kt, int sub, float* ds) __attribute__((always_inline)) {
+    const int s0 = kt * kTile + sub * 16 + g * 4;  // streamed row of acc[0]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = acc[r] * scale2;
+      int q, col, mask_col, pos_col;
+      float lse, lse_ab;
+      if (FIXED_IS_QUERY) {
+        q = f; col = s0 + r; mask_col = f_mask; pos_col = f_pos; lse = f_lse; lse_ab = f_lse_ab;
+      } else {
+        q = s0 + r; col = f;
+        row_cols(q, n, N, rank, mask_col, pos_col);
+        lse = stats_s[2 * (sub * 16 + g * 4 + r)];
+        lse_ab = 0.f;
+      }
+      float d = 0.f;
+      if (q < two_n && col < two_N && col != mask_col) {
+        d = exp2f(t - lse);
+        if (col == pos_col) d -= 1.f;
+        if (FIXED_IS_QUERY && q < n && col >= N) {
+          float pab = exp2f(t - lse_ab);
+          ent -= pab * __logf(pab + 1e-8f);
+        }
+      }
+      ds[r] = d;
+    }
+  };
   for (int kt = tile_begin; kt < tile_end; ++kt) {
     __syncthreads();
-    load_tile<D>(lds, stream_mat, kt * kTile, stream_rows, tid);
+    if constexpr (F16) load_tile_ps<D>(lds, stream_mat, kt * kTile, stream_rows, tid);
+    else load_tile<D>(lds, stream_mat, kt * kTile, stream_rows, tid);
     if (!FIXED_IS_QUERY && tid < 2 * kTile) {
       int qq = kt * kTile + (tid >> 1);
       stats_s[tid] = (qq < two_n) ? row_stats[2 * qq + (tid & 1)] : 0.f;
     }
     __syncthreads();
+    if constexpr (F16) {
+      const unsigned char* base = (const unsigned char*)lds;
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        float dsa[4], dsb[4];
+        ds_of(s_frag_f16<D>(lds, (2 * sp) * 16 + fl, g, ffh, ffl), kt, 2 * sp, dsa);
+        ds_of(s_frag_f16<D>(lds, (2 * sp + 1) * 16 + fl, g, ffh, ffl), kt, 2 * sp + 1, dsb);
+        // dS of the 32 streamed rows of this sub-tile pair as fp16 pieces: k-slots 0..3 = rows 4g.. of the first, 4..7 of the second
+        u32x4 dh, dl;
+        { uint32_t h, l;
+          split_pair<true>(dsa[0], dsa[1], h, l); dh[0] = h; dl[0] = l;
+          split_pair<true>(dsa[2], dsa[3], h, l); dh[1] = h; dl[1] = l;
+          split_pair<true>(dsb[0], dsb[1], h, l); dh[2] = h; dl[2] = l;
+          split_pair<true>(dsb[2], dsb[3], h, l); dh[3] = h; dl[3] = l; }
+        // dF^T[position][fixed] += sum_streamed T[streamed][position] * dS[streamed][fixed]: the transposed T fragments of run R
+        // (16 positions of block R >> 1, run R & 1; hi then lo plane) come from ds_read_b64_tr_b16, rows 4g + (fl >> 2) of either sub-tile
+        const int ra = (2 * sp) * 16 + 4 * g + (fl >> 2), rb = ra + 16;
+#pragma unroll
+        for (int R = 0; R < D / 16; ++R) {
+          const int slot = (R >> 1) * 8 + 2 * (R & 1) + ((fl & 3) >> 1), half = (fl & 1) * 8;
+          const nt_s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((nt_lds_s16x4*)(base + ps_slot<D>(ra, slot) + half));
+          const nt_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((nt_lds_s16x4*)(base + ps_slot<D>(rb, slot) + half));
+          const nt_s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((nt_lds_s16x4*)(base + ps_slot<D>(ra, slot + 4) + half));
+          const nt_s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((nt_lds_s16x4*)(base + ps_slot<D>(rb, slot + 4) + half));
+          const u32x2 x0 = __builtin_bit_cast(u32x2, a0), x1 = __builtin_bit_cast(u32x2, a1);
+          const u32x2 y0 = __builtin_bit_cast(u32x2, b0), y1 = __builtin_bit_cast(u32x2, b1);
+          const u32x4 th = (u32x4){x0[0], x0[1], x1[0], x1[1]}, tl = (u32x4){y0[0], y0[1], y1[0], y1[1]};
+          dacc[R] = nt_mma_f16(tl, dh, dacc[R]);
+          dacc[R] = nt_mma_f16(th, dl, dacc[R]);
+          dacc[R] = nt_mma_f16(th, dh, dacc[R]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -300,31 +446,7 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf.w, ff[s].w, acc, 0, 0, 0);
       }
       float ds[4];
-      const int s0 = kt * kTile + sub * 16 + g * 4;  // streamed row of acc[0]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float t = acc[r] * scale2;
-        int q, col, mask_col, pos_col;
-        float lse, lse_ab;
-        if (FIXED_IS_QUERY) {
-          q = f; col = s0 + r; mask_col = f_mask; pos_col = f_pos; lse = f_lse; lse_ab = f_lse_ab;
-        } else {
-          q = s0 + r; col = f;
-          row_cols(q, n, N, rank, mask_col, pos_col);
-          lse = stats_s[2 * (sub * 16 + g * 4 + r)];
-          lse_ab = 0.f;
-        }
-        float d = 0.f;
-        if (q < two_n && col < two_N && col != mask_col) {
-          d = exp2f(t - lse);
-          if (col == pos_col) d -= 1.f;
-          if (FIXED_IS_QUERY && q < n && col >= N) {
-            float pab = exp2f(t - lse_ab);
-            ent -= pab * __logf(pab + 1e-8f);
-          }
-        }
-        ds[r] = d;
-      }
+      ds_of(acc, kt, sub, ds);
       // dF^T[d][fixed] += sum_streamed T[streamed][d] * dS[streamed][fixed]
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) {
@@ -337,12 +459,19 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
         }
       }
     }
+    }
   }
   if (f < fixed_rows) {
     float* gp = gpart + ((size_t)blockIdx.y * rows_pad + f) * D;
 #pragma unroll
-    for (int dt = 0; dt < D / 16; ++dt)
-      *(float4*)(gp + dt * 16 + 4 * g) = make_float4(dacc[dt][0], dacc[dt][1], dacc[dt][2], dacc[dt][3]);
+    for (int dt = 0; dt < D / 16; ++dt) {
+      int d0 = dt * 16 + 4 * g;
+      if constexpr (F16) {       // run dt of the pre-split tile: position 4 g + reg -> channel (common.h block layout)
+        const int Q = 4 * (dt & 1) + g;
+        d0 = (dt >> 1) * 32 + (Q & 1) * 16 + (Q >> 1) * 4;
+      }
+      *(float4*)(gp + d0) = make_float4(dacc[dt][0], dacc[dt][1], dacc[dt][2], dacc[dt][3]);
+    }
   }
   if (FIXED_IS_QUERY) {
     ent += __shfl_xor(ent, 16, 64);
@@ -353,7 +482,7 @@ __device__ __forceinline__ void ntxent_bwd_sweep_body(
 
 // Both sweeps in ONE launch: blockIdx.z = 0 query-fixed (gradient wrt the local rows + the entropy term),
 // blockIdx.z = 1 key-fixed (gradient wrt the gathered rows).  They are independent, so they share the chip.
-template <int D>
+template <int D, bool F16 = false>
 __global__ __launch_bounds__(256) void ntxent_bwd_sweeps(
     const float* __restrict__ z_local, const float* __restrict__ z_all, int n, int N, int rank, float scale2,
     const float* __restrict__ row_stats, int tiles_k, int tiles_q, float* __restrict__ gq, int rows_pad_q,
@@ -361,11 +490,11 @@ __global__ __launch_bounds__(256) void ntxent_bwd_sweeps(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (blockIdx.z == 0) {
     if ((int)blockIdx.x >= gxq || (int)blockIdx.y >= gyq) return;
-    ntxent_bwd_sweep_body<D, true>(lds, z_local, 2 * n, z_all, 2 * N, n, N, rank, scale2, row_stats, tiles_k, gq,
+    ntxent_bwd_sweep_body<D, true, F16>(lds, z_local, 2 * n, z_all, 2 * N, n, N, rank, scale2, row_stats, tiles_k, gq,
                                    rows_pad_q, epart);
   } else {
     if ((int)blockIdx.x >= gxk || (int)blockIdx.y >= gyk) return;
-    ntxent_bwd_sweep_body<D, false>(lds, z_all, 2 * N, z_local, 2 * n, n, N, rank, scale2, row_stats, tiles_q, gk,
+    ntxent_bwd_sweep_body<D, false, F16>(lds, z_all, 2 * N, z_local, 2 * n, n, N, rank, scale2, row_stats, tiles_q, gk,
                                     rows_pad_k, (float*)nullptr);
   }
 }
@@ -450,29 +579,36 @@ __global__ void ntxent_logits_ab_kernel(const float* __restrict__ zq, const floa
   }
 }
 
-struct Plan { int rows_pad_q, rows_pad_k, qsplit, ksplit, tiles_q, tiles_k; };
+// fks / ftiles_k: key split of the FORWARD sweep (target ~512 workgroups); ksplit / qsplit: splits of the two backward sweeps (target
+// ~256 workgroups each: their partial gradients are [split][rows][D] floats that the combine kernel re-reads -- fewer, longer ranges
+// measured faster: cfg3 shape 101 -> 92 us with the split-fp16 sweeps, 178 -> 177 exact; the forward prefers 512: 43 vs 56 us).
+struct Plan { int rows_pad_q, rows_pad_k, qsplit, ksplit, tiles_q, tiles_k, fks, ftiles_k; };
 Plan make_plan(int n, int N) {
   Plan p;
   const int qtiles = ceil_div(2 * n, kTile), ktiles = ceil_div(2 * N, kTile);
   p.rows_pad_q = qtiles * kTile;
   p.rows_pad_k = ktiles * kTile;
-  // split the streamed dimension so that roughly >= 512 workgroups exist
-  int ks = max(1, min(ktiles, 512 / max(1, qtiles)));
+  static const int wgs_f = getenv("SIMCLR_NTX_WGS") ? max(64, atoi(getenv("SIMCLR_NTX_WGS"))) : 512;      // A/B runs
+  static const int wgs_b = getenv("SIMCLR_NTX_WGS_BWD") ? max(64, atoi(getenv("SIMCLR_NTX_WGS_BWD"))) : 256;
+  int fs = max(1, min(ktiles, wgs_f / max(1, qtiles)));
+  p.ftiles_k = ceil_div(ktiles, fs);
+  p.fks = ceil_div(ktiles, p.ftiles_k);
+  int ks = max(1, min(ktiles, wgs_b / max(1, qtiles)));
   p.tiles_k = ceil_div(ktiles, ks);
   p.ksplit = ceil_div(ktiles, p.tiles_k);
-  int qs = max(1, min(qtiles, 512 / max(1, ktiles)));
+  int qs = max(1, min(qtiles, wgs_b / max(1, ktiles)));
   p.tiles_q = ceil_div(qtiles, qs);
   p.qsplit = ceil_div(qtiles, p.tiles_q);
   return p;
 }
+// workspace layout: [forward partials | gq | gk | entropy partials | row terms]
+size_t off_gq(const Plan& p) { return (size_t)p.fks * p.rows_pad_q * kPartStride; }
+size_t off_gk(const Plan& p, int D) { return off_gq(p) + (size_t)p.ksplit * p.rows_pad_q * D; }
+size_t off_ep(const Plan& p, int D) { return off_gk(p, D) + (size_t)p.qsplit * p.rows_pad_k * D; }
+size_t off_rowterm(const Plan& p, int D) { return off_ep(p, D) + (size_t)p.ksplit * p.rows_pad_q; }
 size_t ws_floats(int n, int N, int D) {
   Plan p = make_plan(n, N);
-  size_t part = (size_t)p.ksplit * p.rows_pad_q * kPartStride;
-  size_t gq = (size_t)p.ksplit * p.rows_pad_q * D;
-  size_t gk = (size_t)p.qsplit * p.rows_pad_k * D;
-  size_t ep = (size_t)p.ksplit * p.rows_pad_q;
-  size_t rowterm = (size_t)2 * p.rows_pad_q;
-  return part + gq + gk + ep + rowterm;
+  return off_rowterm(p, D) + (size_t)2 * p.rows_pad_q;
 }
 
 }  // namespace
@@ -499,6 +635,11 @@ int simclr_l2norm_bwd(const float* z, const float* inv, const float* dz, float* 
 int simclr_ntxent_fwd(const float* z_local, const float* z_all, int n, int N, int D, int rank,
                       float temperature, float* out, float* row_stats, void* workspace,
                       hipStream_t stream) {
+  // D may carry SIMCLR_FMT_TERMS(13) (bits 12..19): the sweeps' fp32 products as three fp16-piece terms -- for l2-NORMALISED rows only
+  const int terms = ((D >> 12) & 0xff) - 1;
+  D &= 0xfff;
+  SIMCLR_CHECK_ARG(terms == -1 || terms == 0 || terms == 13, "ntxent_fwd: matrix arithmetic must be exact (0) or three fp16 terms (13)");
+  const bool f16 = terms == 13;
   SIMCLR_CHECK_ARG(n > 0 && N >= n && N % n == 0, "ntxent_fwd: need N = R*n (n=%d N=%d)", n, N);
   SIMCLR_CHECK_ARG(rank >= 0 && rank < N / n, "ntxent_fwd: rank %d out of range", rank);
   SIMCLR_CHECK_ARG(D == 64 || D == 128 || D == 256, "ntxent_fwd: D must be 64/128/256 (got %d)", D);
@@ -506,17 +647,20 @@ int simclr_ntxent_fwd(const float* z_local, const float* z_all, int n, int N, in
   Plan p = make_plan(n, N);
   float* part = (float*)workspace;
   const float scale2 = kLog2e / temperature;
-  dim3 grid(p.rows_pad_q / kTile, p.ksplit);
+  dim3 grid(p.rows_pad_q / kTile, p.fks);
   const size_t lds = (size_t)kTile * D * sizeof(float);
 #define LAUNCH_FWD(DD)                                                                          \
-  hipLaunchKernelGGL((ntxent_fwd_partial<DD>), grid, dim3(256), lds, stream, z_local, z_all, n, \
-                     N, rank, scale2, p.tiles_k, part, p.rows_pad_q)
+  do {                                                                                          \
+    if (f16) hipLaunchKernelGGL((ntxent_fwd_partial<DD, true>), grid, dim3(256), lds, stream, z_local, z_all, n, \
+                                N, rank, scale2, p.ftiles_k, part, p.rows_pad_q);               \
+    else hipLaunchKernelGGL((ntxent_fwd_partial<DD>), grid, dim3(256), lds, stream, z_local, z_all, n, \
+                            N, rank, scale2, p.ftiles_k, part, p.rows_pad_q);                   \
+  } while (0)
   if (D == 64) LAUNCH_FWD(64); else if (D == 128) LAUNCH_FWD(128); else LAUNCH_FWD(256);
 #undef LAUNCH_FWD
   SIMCLR_CHECK_LAUNCH();
-  float* rowterm = part + (size_t)p.ksplit * p.rows_pad_q * kPartStride + (size_t)p.ksplit * p.rows_pad_q * D +
-                   (size_t)p.qsplit * p.rows_pad_k * D + (size_t)p.ksplit * p.rows_pad_q;
-  hipLaunchKernelGGL(ntxent_finalize_rows, dim3(ceil_div(2 * n, 16)), dim3(256), 0, stream, part, p.ksplit, p.rows_pad_q,
+  float* rowterm = part + off_rowterm(p, D);
+  hipLaunchKernelGGL(ntxent_finalize_rows, dim3(ceil_div(2 * n, 16)), dim3(256), 0, stream, part, p.fks, p.rows_pad_q,
                      n, N, rank, row_stats, rowterm);
   hipLaunchKernelGGL(ntxent_reduce_out, dim3(1), dim3(256), 0, stream, rowterm, n, out);
   SIMCLR_CHECK_LAUNCH();
@@ -530,21 +674,30 @@ int simclr_ntxent_fwd(const float* z_local, const float* z_all, int n, int N, in
 int simclr_ntxent_bwd(const float* z_local, const float* z_all, int n, int N, int D, int rank,
                       float temperature, const float* row_stats, float grad_scale, float* dz_local,
                       float* dz_all, float* out, void* workspace, hipStream_t stream) {
+  const int terms = ((D >> 12) & 0xff) - 1;          // see simclr_ntxent_fwd
+  D &= 0xfff;
+  SIMCLR_CHECK_ARG(terms == -1 || terms == 0 || terms == 13, "ntxent_bwd: matrix arithmetic must be exact (0) or three fp16 terms (13)");
+  const bool f16 = terms == 13;
   SIMCLR_CHECK_ARG(n > 0 && N >= n && N % n == 0, "ntxent_bwd: need N = R*n (n=%d N=%d)", n, N);
   SIMCLR_CHECK_ARG(D == 64 || D == 128 || D == 256, "ntxent_bwd: D must be 64/128/256 (got %d)", D);
   Plan p = make_plan(n, N);
   float* part = (float*)workspace;
-  float* gq = part + (size_t)p.ksplit * p.rows_pad_q * kPartStride;
-  float* gk = gq + (size_t)p.ksplit * p.rows_pad_q * D;
-  float* ep = gk + (size_t)p.qsplit * p.rows_pad_k * D;
+  float* gq = part + off_gq(p);
+  float* gk = part + off_gk(p, D);
+  float* ep = part + off_ep(p, D);
   const float scale2 = kLog2e / temperature;
   const size_t lds = (size_t)(kTile * D + 2 * kTile) * sizeof(float);
   dim3 gridq(p.rows_pad_q / kTile, p.ksplit), gridk(p.rows_pad_k / kTile, p.qsplit);
   dim3 gridb(max(gridq.x, gridk.x), max(gridq.y, gridk.y), 2);
 #define LAUNCH_BWD(DD)                                                                                       \
-  hipLaunchKernelGGL((ntxent_bwd_sweeps<DD>), gridb, dim3(256), lds, stream, z_local, z_all, n, N, rank, scale2, \
-                     row_stats, p.tiles_k, p.tiles_q, gq, p.rows_pad_q, gk, p.rows_pad_k, ep, (int)gridq.x,    \
-                     (int)gridq.y, (int)gridk.x, (int)gridk.y)
+  do {                                                                                                       \
+    if (f16) hipLaunchKernelGGL((ntxent_bwd_sweeps<DD, true>), gridb, dim3(256), lds, stream, z_local, z_all, n, N, rank, scale2, \
+                                row_stats, p.tiles_k, p.tiles_q, gq, p.rows_pad_q, gk, p.rows_pad_k, ep, (int)gridq.x, \
+                                (int)gridq.y, (int)gridk.x, (int)gridk.y);                                   \
+    else hipLaunchKernelGGL((ntxent_bwd_sweeps<DD>), gridb, dim3(256), lds, stream, z_local, z_all, n, N, rank, scale2, \
+                            row_stats, p.tiles_k, p.tiles_q, gq, p.rows_pad_q, gk, p.rows_pad_k, ep, (int)gridq.x, \
+                            (int)gridq.y, (int)gridk.x, (int)gridk.y);                                       \
+  } while (0)
   if (D == 64) LAUNCH_BWD(64); else if (D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(256);
 #undef LAUNCH_BWD
   SIMCLR_CHECK_LAUNCH();

@@ -65,6 +65,9 @@ _DEFS = [
                                   "backward (forward at fp32 level, gradients at ~2^-17); 'f16x3_3' = 3 split-FP16 terms forward (11-bit pieces: ~2^-22 per "
                                   "product at half the MFMA work of six bf16 terms), 3 bf16 terms backward -- the fast parity mode.  Ignored (exact) when "
                                   "compute_dtype='bf16': fp32 heads on a bf16 encoder always run the exact fp32-input MFMA."),
+    ('ntxent_matmul', 'exact', str, "MI355X build: matrix arithmetic of the fused NT-Xent sweeps: 'exact' = fp32-input MFMA (default); 'f16x3' = "
+                                     "three fp16-piece MFMA terms per product (l2-normalised hiddens lie in fp16's range; ~2^-22 / temperature on "
+                                     "the logits) -- 2-3x faster at the 8-GPU shape, opt-in."),
     ('head_dtype', 'same', str, "MI355X build: dtype of the projection / supervised heads: 'same' (= compute_dtype) or 'f32' "
                                 "(the heads are 0.2 % of the FLOPs; fp32 there keeps the loss gradient exact)."),
 ]

@@ -11,6 +11,7 @@ fused contrast accuracy / entropy (tf2/metrics.py:28-35); call `.dense()` for re
 import torch
 
 from . import ops
+from .flags import FLAGS
 from .comm import collectives_on, gather_hidden, num_replicas, replica_id, scatter_hidden_grad
 from .resnet import RT
 
@@ -122,11 +123,13 @@ def add_contrastive_loss(hidden, hidden_norm=True, temperature=1.0, strategy=Non
     if overlap is not None:
         overlap()
     z_all = pending()
-    out, row_stats, ws = ops.ntxent_fwd(z, z_all, rank, temperature)
+    # FLAGS.ntxent_matmul='f16x3' (opt-in): the sweeps' fp32 products as three fp16-piece MFMA terms -- l2-normalised rows only
+    split = bool(hidden_norm) and getattr(FLAGS, 'ntxent_matmul', 'exact') == 'f16x3'
+    out, row_stats, ws = ops.ntxent_fwd(z, z_all, rank, temperature, split=split)
     state = {'done': False, 'dz_local': None, 'slot': None}
 
     def backward_start(grad_scale=1.0):
-        dz_local, dz_all = ops.ntxent_bwd(z, z_all, rank, temperature, row_stats, grad_scale, out, ws)
+        dz_local, dz_all = ops.ntxent_bwd(z, z_all, rank, temperature, row_stats, grad_scale, out, ws, split=split)
         state['done'] = True
         state['dz_local'] = dz_local
         state['slot'] = scatter_hidden_grad(dz_all, strategy, async_op=True)   # transpose of the concat, asynchronous
@@ -146,7 +149,7 @@ def add_contrastive_loss(hidden, hidden_norm=True, temperature=1.0, strategy=Non
 
     def ensure_entropy():
         if not state['done']:
-            ops.ntxent_bwd(z, z_all, rank, temperature, row_stats, 0.0, out, ws)
+            ops.ntxent_bwd(z, z_all, rank, temperature, row_stats, 0.0, out, ws, split=split)
             state['done'] = True
 
     loss = _Loss(out[0:1], backward, backward_start, backward_finish)

@@ -139,7 +139,9 @@ def ntxent_workspace(n, N, D, device):
     return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
 
 
-def ntxent_fwd(z_local, z_all, rank, temperature, ws=None):
+def ntxent_fwd(z_local, z_all, rank, temperature, ws=None, split=False):
+    """split: three fp16-piece MFMA terms per fp32 product in the sweeps (SIMCLR_FMT_TERMS(13) in the D argument) -- for
+    l2-normalised rows; default = exact fp32-input MFMA."""
     n, D = z_local.shape[0] // 2, z_local.shape[1]
     N = z_all.shape[0] // 2
     assert z_local.dtype == torch.float32 and z_all.dtype == torch.float32
@@ -150,12 +152,12 @@ def ntxent_fwd(z_local, z_all, rank, temperature, ws=None):
     out = step_scalars(4, z_local.device)
     row_stats = torch.empty(2 * n, 2, device=z_local.device, dtype=torch.float32)
     _launch('ntxent_fwd', 8.0 * n * N * D, 4.0 * (2 * n + 2 * N) * D,
-            lambda: lib().ntxent_fwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(out), _p(row_stats),
+            lambda: lib().ntxent_fwd(_p(z_local), _p(z_all), n, N, D | ((14 << 12) if split else 0), rank, float(temperature), _p(out), _p(row_stats),
                                      _p(ws), _s()))
     return out, row_stats, ws
 
 
-def ntxent_bwd(z_local, z_all, rank, temperature, row_stats, grad_scale, out, ws):
+def ntxent_bwd(z_local, z_all, rank, temperature, row_stats, grad_scale, out, ws, split=False):
     n, D0 = z_local.shape[0] // 2, z_local.shape[1]
     N = z_all.shape[0] // 2
     z_local, z_all = _ntxent_pad(z_local), _ntxent_pad(z_all)
@@ -164,7 +166,7 @@ def ntxent_bwd(z_local, z_all, rank, temperature, row_stats, grad_scale, out, ws
     dz_all = torch.empty_like(z_all)
     # bytes: the fused forward+backward I/O of SURVEY 8(d): read h_local + h_all, write dH_local + dH_all
     _launch('ntxent_bwd', 16.0 * n * N * D, 2.0 * (2 * n + 2 * N) * D * 4,
-            lambda: lib().ntxent_bwd(_p(z_local), _p(z_all), n, N, D, rank, float(temperature), _p(row_stats),
+            lambda: lib().ntxent_bwd(_p(z_local), _p(z_all), n, N, D | ((14 << 12) if split else 0), rank, float(temperature), _p(row_stats),
                                      float(grad_scale), _p(dz_local), _p(dz_all), _p(out), _p(ws), _s()))
     if D != D0:
         dz_local, dz_all = dz_local[:, :D0].contiguous(), dz_all[:, :D0].contiguous()

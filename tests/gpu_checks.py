@@ -97,7 +97,8 @@ def probe_ds_read_tr16():
 
 
 # ------------------------------------------------------------------ NT-Xent
-def check_ntxent(n, R, D=128, temperature=0.1, rank=0, seed=3, hidden_norm=True):
+def check_ntxent(n, R, D=128, temperature=0.1, rank=0, seed=3, hidden_norm=True, split=False):
+    """split: the sweeps' fp32 products as three fp16-piece MFMA terms (opt-in mode, l2-normalised rows) -- same gates."""
     g = np.random.default_rng(seed)
     hs = [g.standard_normal((2 * n, D)).astype(np.float32) for _ in range(R)]
     losses, grads = ont.contrastive_loss_and_grad(hs, hidden_norm, temperature)
@@ -118,13 +119,13 @@ def check_ntxent(n, R, D=128, temperature=0.1, rank=0, seed=3, hidden_norm=True)
     if hidden_norm:
         zref = ont.l2_normalize(hs[rank].astype(np.float64))
         res.append(_res('l2norm_fwd n=%d' % n, zs[rank], zref, 0, 1e-6))
-    out, row_stats, ws = ops.ntxent_fwd(zs[rank], z_all, rank, temperature)
+    out, row_stats, ws = ops.ntxent_fwd(zs[rank], z_all, rank, temperature, split=split)
     # total gradient wrt rank's hidden = local part + sum over replicas q of dz_all_q[rank slot]
     dz_local_r = None
     dz_slot = torch.zeros(2 * n, D, device=DEV)
     for q in range(R):
-        o_q, rs_q, ws_q = ops.ntxent_fwd(zs[q], z_all, q, temperature)
-        dl, da = ops.ntxent_bwd(zs[q], z_all, q, temperature, rs_q, 1.0 / R, o_q, ws_q)
+        o_q, rs_q, ws_q = ops.ntxent_fwd(zs[q], z_all, q, temperature, split=split)
+        dl, da = ops.ntxent_bwd(zs[q], z_all, q, temperature, rs_q, 1.0 / R, o_q, ws_q, split=split)
         if q == rank:
             dz_local_r = dl
             out = o_q
@@ -135,7 +136,7 @@ def check_ntxent(n, R, D=128, temperature=0.1, rank=0, seed=3, hidden_norm=True)
     dh = ops.l2norm_bwd(zs[rank], invs[rank], dz) if hidden_norm else dz
     torch.cuda.synchronize()
     o = out.cpu().double()
-    tag = 'n=%d R=%d D=%d T=%g rank=%d' % (n, R, D, temperature, rank)
+    tag = 'n=%d R=%d D=%d T=%g rank=%d%s' % (n, R, D, temperature, rank, ' f16x3' if split else '')
     res.append(_res('ntxent_loss ' + tag, o[0], loss_r, 1e-5))
     res.append(_res('ntxent_acc ' + tag, o[1], acc_ref, 0, 1e-6))
     res.append(_res('ntxent_entropy ' + tag, o[2], ent_ref, 1e-4, 1e-6))

@@ -44,9 +44,12 @@ def test_ntxent_closed_forms():
 @pytest.mark.parametrize('n,R,D,rank', [(64, 1, 128, 0), (96, 1, 64, 0), (32, 4, 128, 2), (512, 1, 128, 0),
                                         (64, 2, 256, 1), (100, 1, 128, 0), (512, 8, 128, 5),
                                         (64, 1, 96, 0), (48, 2, 200, 1), (40, 1, 16, 0)])   # widths that run zero-padded
-def test_ntxent_vs_oracle(n, R, D, rank):
+@pytest.mark.parametrize('split', [False, True])
+def test_ntxent_vs_oracle(n, R, D, rank, split):
+    """split=True: the opt-in split-fp16 sweeps (FLAGS.ntxent_matmul='f16x3': three fp16-piece MFMA terms per product, pre-split LDS tile,
+    transposing reads for the second product) against the same float64 oracle at the same gates."""
     from tests import gpu_checks as gc
-    _assert(gc.check_ntxent(n, R, D=D, rank=rank))
+    _assert(gc.check_ntxent(n, R, D=D, rank=rank, split=split))
 
 
 def test_ntxent_no_norm_temperature_one():
@@ -138,11 +141,14 @@ def _reference_fixtures():
     return m, dict(np.load(m.OUT_NPZ))
 
 
-def test_ntxent_kernels_match_the_reference_source_fixtures():
+@pytest.mark.parametrize('ntxent_matmul', ['exact', 'f16x3'])
+def test_ntxent_kernels_match_the_reference_source_fixtures(ntxent_matmul):
     """simclr_amd.objective.add_contrastive_loss (fused NT-Xent kernels) against tests/golden/reference_pin.npz -- the outputs of
     tf2/objective.py:35-89 itself, executed on oracle/tfshim.py: loss, logits_ab, labels, the metrics of tf2/metrics.py:28-35 and
     d loss / d hidden (central differences of the reference function)."""
     from simclr_amd import objective
+    from simclr_amd.flags import FLAGS
+    FLAGS.update(ntxent_matmul=ntxent_matmul)          # 'f16x3': the split-fp16 sweeps (cases with hidden_norm only), same 2e-5 gates
     m, ref = _reference_fixtures()
     for i, c in enumerate(m.NTX):
         h = m._rng(c['seed']).standard_normal((2 * c['n'], c['d']))
@@ -159,6 +165,7 @@ def test_ntxent_kernels_match_the_reference_source_fixtures():
         g = ref['ntx%d_grad_fd' % i]
         assert np.abs(dh.double().cpu().numpy() - g).max() <= 3e-4 * np.abs(g).max() + 1e-7, tag
         assert abs(acc - float(ref['ntx%d_acc' % i])) <= 1e-6 and abs(ent - float(ref['ntx%d_entropy' % i])) <= 2e-4, (tag, acc, ent)
+    FLAGS.update(ntxent_matmul='exact')
 
 
 def test_lars_kernels_match_the_reference_source_fixtures():

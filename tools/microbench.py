@@ -243,14 +243,15 @@ def main():
             za = torch.nn.functional.normalize(torch.randn(2 * N, D, device=dev), dim=1)
             za[:n] = zl[:n]; za[N:N + n] = zl[n:]
             ws = ops.ntxent_workspace(n, N, D, dev)
-            out, rs, _ = ops.ntxent_fwd(zl, za, 0, 0.1, ws)
-            t_f = timeit(lambda: ops.ntxent_fwd(zl, za, 0, 0.1, ws), args.iters)
-            t_b = timeit(lambda: ops.ntxent_bwd(zl, za, 0, 0.1, rs, 1.0, out, ws), args.iters)
             fl = 24.0 * n * N * D
             by = 2.0 * (2 * n + 2 * N) * D * 4
-            print('ntxent n=%d N=%d: fwd %.0f us bwd %.0f us | fused fwd+bwd %.1f TF/s (24nND), algorithmic %.1f GB/s' % (
-                n, N, t_f, t_b, fl / (t_f + t_b) / 1e6, by / (t_f + t_b) / 1e3), flush=True)
-            res.append(dict(layer='ntxent n%d N%d' % (n, N), fwd_us=t_f, bwd_us=t_b, flops=fl, bytes=by))
+            for split in (False, True):        # exact fp32-input MFMA sweeps | the opt-in split-fp16 sweeps (FLAGS.ntxent_matmul='f16x3')
+                out, rs, _ = ops.ntxent_fwd(zl, za, 0, 0.1, ws, split=split)
+                t_f = timeit(lambda: ops.ntxent_fwd(zl, za, 0, 0.1, ws, split=split), args.iters)
+                t_b = timeit(lambda: ops.ntxent_bwd(zl, za, 0, 0.1, rs, 1.0, out, ws, split=split), args.iters)
+                print('ntxent n=%d N=%d %s: fwd %.0f us bwd %.0f us | fused fwd+bwd %.1f TF/s (24nND), algorithmic %.1f GB/s' % (
+                    n, N, 'f16x3' if split else 'exact', t_f, t_b, fl / (t_f + t_b) / 1e6, by / (t_f + t_b) / 1e3), flush=True)
+                res.append(dict(layer='ntxent n%d N%d%s' % (n, N, ' f16x3' if split else ''), fwd_us=t_f, bwd_us=t_b, flops=fl, bytes=by))
     if 'lars' in what:
         from simclr_amd.lars_optimizer import LARSOptimizer, Variable
         sizes = []

@@ -34,52 +34,60 @@ def main():
             for r in csv.DictReader(fh):
                 rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?'), r.get('Stream_Id', '?')))
     rows.sort()
-    is_coll = lambda n: ('nccl' in n.lower()) or ('rccl' in n.lower())
-    skip = lambda n: 'aug_' in n or 'at::native' in n or 'FillFunctor' in n
-    coll = [r for r in rows if is_coll(r[2])]
-    comp = [r for r in rows if not is_coll(r[2]) and not skip(r[2])]
-    # union of compute intervals
+    skip = lambda n: 'aug_' in n
+    rows = [r for r in rows if not skip(r[2])]
+    # streams: the launch stream carries the compute kernels; every other stream with recurring work is a communicator's stream.
+    # On ONE rank RCCL executes a collective as a device-to-device copy (__amd_rocclr_copyBuffer) or nothing at all (in-place), and the
+    # SyncBN moments go through csrc/comm.hip's stats_exchange / the library: what the trace shows is therefore the STREAM STRUCTURE --
+    # which work runs beside the compute stream and how much of it is covered by compute kernels -- not ring kernels.
+    from collections import Counter, defaultdict
+    per_stream = Counter((r[3], r[4]) for r in rows)
+    main = per_stream.most_common(1)[0][0]
+    comp = [r for r in rows if (r[3], r[4]) == main]
+    side = defaultdict(list)
+    for r in rows:
+        if (r[3], r[4]) != main:
+            side[(r[3], r[4])].append(r)
     merged = []
-    for s, e, *_ in comp:
-        if merged and s <= merged[-1][1]:
-            merged[-1][1] = max(merged[-1][1], e)
+    for s_, e_, *_ in comp:
+        if merged and s_ <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], e_)
         else:
-            merged.append([s, e])
+            merged.append([s_, e_])
     import bisect
     starts = [m[0] for m in merged]
 
-    def overlap(s, e):
-        i = max(0, bisect.bisect_right(starts, s) - 1)
+    def overlap(s_, e_):
+        i = max(0, bisect.bisect_right(starts, s_) - 1)
         tot = 0
-        while i < len(merged) and merged[i][0] < e:
-            tot += max(0, min(e, merged[i][1]) - max(s, merged[i][0]))
+        while i < len(merged) and merged[i][0] < e_:
+            tot += max(0, min(e_, merged[i][1]) - max(s_, merged[i][0]))
             i += 1
         return tot
 
-    def kind(n):
-        for k in ('AllGather', 'ReduceScatter', 'AllReduce', 'Broadcast', 'SendRecv'):
-            if k.lower() in n.lower():
-                return k
-        return 'other'
-    by = {}
-    for s, e, n, q, st in coll:
-        d = by.setdefault(kind(n), dict(launches=0, ns=0, hidden_ns=0, queues=set(), streams=set(), longest_us=0.0))
-        d['launches'] += 1
-        d['ns'] += e - s
-        d['hidden_ns'] += overlap(s, e)
-        d['queues'].add(q); d['streams'].add(st)
-        d['longest_us'] = max(d['longest_us'], (e - s) / 1e3)
     span = (rows[-1][1] - rows[0][0]) if rows else 0
     out = dict(source='rocprofv3 --kernel-trace of bench.py under SIMCLR_FORCE_COLLECTIVES=1 (one rank, every collective issued)',
-               steps=args.steps, compute_kernels=len(comp), collective_kernels=len(coll),
-               compute_queues=sorted({r[3] for r in comp}), collective_queues=sorted({r[3] for r in coll}),
-               compute_busy_ms_per_step=round(sum(m[1] - m[0] for m in merged) / 1e6 / args.steps, 3),
-               trace_span_ms=round(span / 1e6, 3), collectives={})
-    for k, d in sorted(by.items()):
-        out['collectives'][k] = dict(launches_per_step=round(d['launches'] / args.steps, 2), us_per_step=round(d['ns'] / 1e3 / args.steps, 1),
-                                     hidden_behind_compute_frac=round(d['hidden_ns'] / max(d['ns'], 1), 4),
-                                     exposed_us_per_step=round((d['ns'] - d['hidden_ns']) / 1e3 / args.steps, 1),
-                                     longest_kernel_us=round(d['longest_us'], 1), queues=sorted(d['queues']), streams=sorted(d['streams']))
+               note='one rank: RCCL runs each collective as a device copy on its communicator stream (no ring kernels); the table shows the '
+                    'stream structure and how much of the side-stream work is covered by compute kernels of the launch stream',
+               steps=args.steps, launch_stream=dict(queue=main[0], stream=main[1], kernels=len(comp),
+                                                    busy_ms_per_step=round(sum(m[1] - m[0] for m in merged) / 1e6 / args.steps, 3)),
+               trace_span_ms=round(span / 1e6, 3), side_streams={})
+    t_first = comp[0][0] if comp else 0
+    init = {}
+    for key, rs in sorted(side.items(), key=lambda kv: -len(kv[1])):
+        if max(r[1] for r in rs) <= t_first:          # finished before the first compute kernel: communicator set-up (ncclCommInit)
+            init['queue %s / stream %s' % key] = dict(kernels=len(rs), kinds=dict(Counter(r[2].split('(')[0][:40] for r in rs).most_common(3)))
+            continue
+        if len(rs) < args.steps:          # one-off work
+            continue
+        ns = sum(r[1] - r[0] for r in rs)
+        hid = sum(overlap(r[0], r[1]) for r in rs)
+        names = Counter(r[2].split('(')[0][:60] for r in rs)
+        out['side_streams']['queue %s / stream %s' % key] = dict(
+            launches_per_step=round(len(rs) / args.steps, 1), us_per_step=round(ns / 1e3 / args.steps, 1),
+            covered_by_compute_frac=round(hid / max(ns, 1), 4), exposed_us_per_step=round((ns - hid) / 1e3 / args.steps, 1),
+            longest_us=round(max(r[1] - r[0] for r in rs) / 1e3, 1), kernels=dict(names.most_common(4)))
+    out['set_up_streams'] = init
     print(json.dumps(out, indent=1))
     if args.out:
         os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
