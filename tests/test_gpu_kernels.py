@@ -124,7 +124,8 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case, matmul):
 
 
 @pytest.mark.parametrize('V,H,Cin,Cout,k,s', [(3, 14, 64, 128, 3, 1), (2, 16, 64, 256, 1, 2), (2, 15, 128, 64, 3, 2), (130, 1, 128, 64, 1, 1),
-                                              (64, 56, 256, 64, 1, 1), (64, 28, 128, 128, 3, 1), (2, 9, 192, 96, 3, 1), (5, 7, 512, 2048, 1, 1)])
+                                              (64, 56, 256, 64, 1, 1), (64, 28, 128, 128, 3, 1), (2, 9, 192, 96, 3, 1), (5, 7, 512, 2048, 1, 1),
+                                              (1024, 14, 256, 256, 3, 1)])      # the last one: split tail of the persistent grid (8 parts)
 def test_conv_backward_with_presplit_gradient(V, H, Cin, Cout, k, s):
     """Round 6: the gradient between a BatchNorm backward and the convolution in front of it kept as (hi, lo) bf16 pieces per 128-byte block
     (csrc/common.h): pieces exact, data gradient bitwise the in-register split, weight gradient (transposing LDS reads) within the
