@@ -69,6 +69,14 @@ class _Lib:
                 'libsimclr_hip.so not found at %s -- build it with '
                 '`python -c "import __graft_entry__ as g; g.build()"` or simclr_amd/csrc/build.sh. '
                 'There is no CPU fallback.' % LIB_PATH)
+        # ONE HIP runtime per process: PyTorch ships its own libamdhip64 and owns the device context, streams and allocations this library
+        # is handed.  Loaded first, its runtime is the one our DT_NEEDED entry resolves to; loaded second (library first, torch later), the
+        # process ends up with two runtimes and every launch of ours fails with "no ROCm-capable device is detected" (seen when build()
+        # and smoke() ran in one process, round 6).
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pragma: no cover
+            pass
         self._dll = ctypes.CDLL(LIB_PATH)
         self.signatures = parse_header()
         for name, (restype, argtypes) in self.signatures.items():

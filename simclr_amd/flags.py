@@ -7,6 +7,10 @@ module-level `FLAGS` namespace.  TPU flags are accepted and ignored.
 """
 import argparse
 
+# The product default of f32_matmul is the fast tolerance-meeting mode.  SIMCLR_DEFAULT_F32_MATMUL overrides the DEFAULT only (tests/conftest.py
+# sets it to 'exact': the test-suite pins the arithmetic it tests explicitly and calibrated its fp32 gates on the exact fp32-input MFMA).
+_F32_MATMUL_DEFAULT = __import__('os').environ.get('SIMCLR_DEFAULT_F32_MATMUL', 'f16x3_3')
+
 _DEFS = [
     # (name, default, type, help)                                      tf2/run.py line
     ('learning_rate', 0.3, float, 'Initial learning rate per batch size of 256.'),      # :37
@@ -58,8 +62,11 @@ _DEFS = [
     ('color_jitter_strength', 1.0, float, 'The strength of color jittering.'),           # :232
     ('use_blur', True, bool, 'Whether or not to use Gaussian blur for augmentation during pretraining.'),  # :236
     # build-specific (not in the reference)
-    ('compute_dtype', 'bf16', str, "MI355X build: activation/compute dtype, 'bf16' (speed) or 'f32' (parity)."),
-    ('f32_matmul', 'exact', str, "MI355X build, compute_dtype='f32' only: matrix arithmetic of the fp32 convolutions / dense layers. "
+    # Defaults (round 6): the mode whose outputs meet north_star's tolerances against the reference TF2 path (loss 1e-3 relative, normalised
+    # embeddings 1e-5 absolute) -- fp32 storage, three fp16-piece MFMA terms forward, three bf16-piece terms backward.  --compute_dtype=bf16
+    # is the opt-in speed mode: bf16 storage is narrower than the reference's fp32 and misses those tolerances (4.5e-3 / 2.3e-2 measured).
+    ('compute_dtype', 'f32', str, "MI355X build: activation/compute dtype, 'f32' (parity, default) or 'bf16' (speed; narrower than the reference)."),
+    ('f32_matmul', _F32_MATMUL_DEFAULT, str, "MI355X build, compute_dtype='f32' only: matrix arithmetic of the fp32 convolutions / dense layers. "
                                   "'exact' = fp32-input MFMA (1/16 of the bf16 rate); 'bf16x3' / 'bf16x6' = every fp32 product as 3 / 6 "
                                   "bf16 MFMA terms with fp32 accumulation (fp32 storage everywhere); 'bf16x6_3' = 6 terms forward, 3 "
                                   "backward (forward at fp32 level, gradients at ~2^-17); 'f16x3_3' = 3 split-FP16 terms forward (11-bit pieces: ~2^-22 per "
@@ -80,6 +87,15 @@ class _Flags:
     def reset(self):
         for name, default, _, _ in _DEFS:
             setattr(self, name, default)
+
+    def set_default(self, name, value):
+        """Change the DEFAULT of a flag for this process (what reset() restores) -- test harnesses that calibrate on a specific mode."""
+        for i, (n, _, typ, hlp) in enumerate(_DEFS):
+            if n == name:
+                _DEFS[i] = (n, value, typ, hlp)
+                setattr(self, name, value)
+                return
+        raise AttributeError('Unknown flag %r' % name)
 
     def flag_values_dict(self):
         return {name: getattr(self, name) for name, _, _, _ in _DEFS}

@@ -175,3 +175,16 @@ def test_instantiation_table_matches_the_committed_one():
     assert r.stdout == want, 'the (layer class -> instantiation) table changed: regenerate profiles/r05_instantiations.txt with tools/instantiation_table.py and review the diff'
     rows = [l for l in want.splitlines() if l and not l.startswith('#')]
     assert len(rows) > 200 and any('conv_igemm_wide' in l for l in rows) and any('elt=4' in l and ', 6>' in l for l in rows)
+
+
+def test_product_defaults_are_the_tolerance_meeting_mode():
+    """a user who switches to this package gets the mode whose outputs meet north_star's tolerances -- fp32 storage,
+    three fp16-piece terms forward / three bf16-piece terms backward -- unless they opt into the bf16 speed mode.  (The test session itself
+    overrides the f32_matmul DEFAULT to 'exact' through SIMCLR_DEFAULT_F32_MATMUL: checked in a clean subprocess.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != 'SIMCLR_DEFAULT_F32_MATMUL'}
+    out = subprocess.run([sys.executable, '-c', 'from simclr_amd.flags import FLAGS; print(FLAGS.compute_dtype, FLAGS.f32_matmul, FLAGS.ntxent_matmul)'],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['f32', 'f16x3_3', 'exact']
