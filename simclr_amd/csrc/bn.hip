@@ -552,7 +552,7 @@ int simclr_bn_apply(const void* x, const float* scale, const float* shift, const
   // bit0: non-temporal loads / stores.  Default ON since round 5: interleaved three-fold A/B on one box (profiles/r05_notes.md section 8),
   // ms per training step: ResNet-50 63.19 -> 62.63, fp32 parity mode 186.5 -> 184.3 -- the streamed tensors are far larger than L2 / MALL
   // and are next read by a different kernel, so keeping them out of the caches leaves those to the convolutions' re-reads.
-  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 1;   // bit0: non-temporal policy
+  constexpr int cfg = 1;   // bit0: non-temporal policy, bit1: one chunk per thread (settled: rounds 5 and 6 A/B, the switch SIMCLR_BN_CFG is gone)
   const bool nt = (cfg & 1) != 0;
   const int cpr = C / epc;
   const long long nchunks = rows * cpr;
@@ -622,7 +622,7 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply: C=%d must be a multiple of %d", C, epc);
   SIMCLR_CHECK_ARG(!ps_out || (dtype == SIMCLR_DT_F32 && C % 32 == 0), "bn_bwd_apply: pre-split output needs fp32 storage and C %% 32 == 0 (C=%d)", C);
-  static const int cfg = getenv("SIMCLR_BN_CFG") ? atoi(getenv("SIMCLR_BN_CFG")) : 1;      // see simclr_bn_apply
+  constexpr int cfg = 1;      // see simclr_bn_apply
   const bool nt = (cfg & 1) != 0;
   const int cpr = C / epc;
   const long long nchunks = rows * cpr;

@@ -2875,7 +2875,7 @@ static bool igemm_split_tail(ConvP& p, int grid, int units, int unit_steps, size
   if (P > max_parts) P = max_parts;
   // at least `min_steps` k-steps per part: a part must be worth its exchange (64 - 256 KB written through + re-read, one
   // acquire on the owner: 3 - 6 us, i.e. several k-steps)
-  static const int min_steps = getenv("SIMCLR_IGEMM_SPLIT_MINSTEPS") ? atoi(getenv("SIMCLR_IGEMM_SPLIT_MINSTEPS")) : 8;
+  constexpr int min_steps = 8;
   int max_parts_u = (units * unit_steps) / (min_steps > 0 ? min_steps : 1);      // parts are whole units
   if (max_parts_u > units) max_parts_u = units;
   if (P > max_parts_u) P = max_parts_u;
@@ -3660,7 +3660,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     const int tiles = q.ci_tiles * q.co_tiles;
     const int grid3 = tiles * ceil_div(q.splits, 8) * 8;
     const size_t stage3 = (size_t)(q.hpp + 64) * 128;
-    static const bool ring3 = !getenv("SIMCLR_WGRAD3_STAGES") || atoi(getenv("SIMCLR_WGRAD3_STAGES")) != 2;
+    constexpr bool ring3 = true;          // three-deep ring wherever two workgroups of it fit a CU (round 3: -0.1 ms per step)
     if (ring3 && 2 * 3 * stage3 <= 160 * 1024)
       hipLaunchKernelGGL(conv_wgrad3x3_bf16<3>, dim3(grid3), dim3(256), 3 * stage3, stream, q);
     else
@@ -3676,7 +3676,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   wgrad_tile(Cin, Cout, dtype, p.M, KH * KW, &bkw, &bnw);
   if ((pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0 && bkw == 256) { bkw = 128; bnw = 128; }
   // stem (packed input, 32 elements per kernel row): all kernel rows in ONE 256-row k-tile, so dY is read once
-  static const bool stem_mt_on = !getenv("SIMCLR_STEM_WGRAD_MT") || atoi(getenv("SIMCLR_STEM_WGRAD_MT")) != 0;
+  constexpr bool stem_mt_on = true;
   const bool stem_mt = stem_mt_on && bkw == 32 && Cin == 32 && p.K <= 256 && Cout <= 64;
   if (stem_mt) { bkw = 256; bnw = 64; }
   // kernel variant: 1 = LDS-DMA ring, 64-pixel chunks x 2 stages; 2 = 32-pixel chunks x 3 stages for the
@@ -3724,7 +3724,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
 #define LW(TT, A, B) hipLaunchKernelGGL((conv_wgrad<TT, A, B>), dim3(grid), dim3(256), lds, stream, p)
 #define LD(TT, A, B, M_, S_) hipLaunchKernelGGL((conv_wgrad_dma<TT, A, B, M_, S_>), dim3(grid), dim3(256), lds, stream, p)
   // stem over LDS-DMA: stride 2 on an even-width packed image makes every source 16-byte aligned
-  static const bool stem_dma_on = !getenv("SIMCLR_STEM_WGRAD_DMA") || atoi(getenv("SIMCLR_STEM_WGRAD_DMA")) != 0;
+  constexpr bool stem_dma_on = true;
   const bool stem_dma = stem_mt && stem_dma_on && dtype == SIMCLR_DT_BF16 && KW == 1 && pad == 0 && stride % 2 == 0 && IW % 2 == 0 &&
                         pixpitch == 4 && Cin == 32;
   // fp32 stem under split-bf16 terms: a packed pixel is 4 floats = 16 bytes, so every source of the multi-tap k-tile is 16-byte
@@ -3881,7 +3881,7 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
   const size_t lds = 64 * (p.KP * esz + 16) + 4 * 64 * 2 * sizeof(float) + (esz == 2 ? 128 * 64 * 2 : 0);
   dim3 grid(min(p.m_tiles, 2048), ceil_div(Cout, 64));
   if (dtype == SIMCLR_DT_BF16) {
-    static const bool unroll_on = !getenv("SIMCLR_STEM_UNROLL") || atoi(getenv("SIMCLR_STEM_UNROLL")) != 0;
+    constexpr bool unroll_on = true;
     if (unroll_on && KWP * 4 == 32 && p.KP == 7 * 32) {      // one k-step = one padded kernel row, 7 rows
       if (stats) hipLaunchKernelGGL((stem_conv_fwd<uint16_t, true, 7>), grid, dim3(256), lds, stream, p);
       else hipLaunchKernelGGL((stem_conv_fwd<uint16_t, false, 7>), grid, dim3(256), lds, stream, p);
@@ -3891,8 +3891,8 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
     // fp32 storage: the forward terms of simclr_set_f32_matmul (0 = exact fp32 MFMA; SIMCLR_STEM_SPLIT=0 keeps the exact kernel)
     static const bool stem_split_on = !getenv("SIMCLR_STEM_SPLIT") || atoi(getenv("SIMCLR_STEM_SPLIT")) != 0;
     // (13 = three fp16-piece terms, both operands split in registers: images lie in [0, 1], and the stem's weights -- fan-in 147, |w| ~ 0.1 --
-    // keep ~2^-21 relative in their unscaled lo pieces; SIMCLR_STEM_F16=0 keeps six bf16 terms)
-    static const bool stem_f16_on = !getenv("SIMCLR_STEM_F16") || atoi(getenv("SIMCLR_STEM_F16")) != 0;
+    // keep ~2^-21 relative in their unscaled lo pieces; -0.8 ms per step against six bf16 terms, profiles/r06_notes.md)
+    constexpr bool stem_f16_on = true;
     const int spl = stem_split_on ? ((terms == 13 && !stem_f16_on) ? 6 : terms) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
 #define LSF(STv)                                                                                              \
     do {                                                                                                       \

@@ -588,8 +588,7 @@ Plan make_plan(int n, int N) {
   const int qtiles = ceil_div(2 * n, kTile), ktiles = ceil_div(2 * N, kTile);
   p.rows_pad_q = qtiles * kTile;
   p.rows_pad_k = ktiles * kTile;
-  static const int wgs_f = getenv("SIMCLR_NTX_WGS") ? max(64, atoi(getenv("SIMCLR_NTX_WGS"))) : 512;      // A/B runs
-  static const int wgs_b = getenv("SIMCLR_NTX_WGS_BWD") ? max(64, atoi(getenv("SIMCLR_NTX_WGS_BWD"))) : 256;
+  constexpr int wgs_f = 512, wgs_b = 256;      // sweep in profiles/r06_notes.md section 7 (256 / 384 / 512 / 768 / 1024)
   int fs = max(1, min(ktiles, wgs_f / max(1, qtiles)));
   p.ftiles_k = ceil_div(ktiles, fs);
   p.fks = ceil_div(ktiles, p.ftiles_k);

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void l2_loss_f32(const float* __restrict__ x, 
 // a capped grid striding through the tensor (tools/probes/hbm_probe.hip); the kernels keep their grid-stride
 // loops for tensors beyond 2^30 threads
 int grid_for(long long n) {
-  static const long long cap = getenv("SIMCLR_GRID_CAP") ? atoll(getenv("SIMCLR_GRID_CAP")) : (1ll << 22);
+  constexpr long long cap = 1ll << 22;
   return (int)max(1ll, min(cap, (n + 255) / 256));
 }
 

@@ -31,7 +31,6 @@ from .flags import FLAGS
 from .lars_optimizer import Variable
 
 BATCH_NORM_EPSILON = 1e-5  # tf2/resnet.py:28
-_PREP_PER_LAYER = __import__('os').environ.get('SIMCLR_PREP_BATCH', '1') == '0'   # A/B: one weight-copy launch per layer
 
 
 # --------------------------------------------------------------------------- runtime context
@@ -454,7 +453,7 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
         else:
             # first refresh of a layer (lazy build during the first forward) or a layer outside the registry (built under
             # an earlier RT.reset()): its own launch; afterwards every version bump refreshes ALL layers with one launch
-            if _PREP_PER_LAYER or self._version < 0 or not any(r() is self for r in RT.convs):
+            if self._version < 0 or not any(r() is self for r in RT.convs):
                 self.w_t, self.w_d = ops.prep_weights_pair(w, RT.dtype, cin_p=self.cin_p, cout_p=self.cout_p)
             else:
                 RT.refresh_conv_weights()

@@ -171,8 +171,8 @@ def test_instantiation_table_matches_the_committed_one():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'instantiation_table.py')], capture_output=True, text=True, timeout=300,
                        env={k: v for k, v in os.environ.items() if not k.startswith('SIMCLR_')})
     assert r.returncode == 0, r.stderr[-2000:]
-    want = open(os.path.join(root, 'profiles', 'r05_instantiations.txt')).read()
-    assert r.stdout == want, 'the (layer class -> instantiation) table changed: regenerate profiles/r05_instantiations.txt with tools/instantiation_table.py and review the diff'
+    want = open(os.path.join(root, 'profiles', 'r06_instantiations.txt')).read()
+    assert r.stdout == want, 'the (layer class -> instantiation) table changed: regenerate profiles/r06_instantiations.txt with tools/instantiation_table.py and review the diff'
     rows = [l for l in want.splitlines() if l and not l.startswith('#')]
     assert len(rows) > 200 and any('conv_igemm_wide' in l for l in rows) and any('elt=4' in l and ', 6>' in l for l in rows)
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """(layer class -> kernel instantiation) table of the forward / data-gradient convolution launches.
 
-    python tools/instantiation_table.py [--views 1024] [--out profiles/r05_instantiations.txt]
+    python tools/instantiation_table.py [--views 1024] [--out profiles/r06_instantiations.txt]
 
 Runs WITHOUT a GPU: with SIMCLR_DRY_RUN=1 the convolution entry points of libsimclr_hip.so take every launch decision
 (launch_igemm_one: tile shape, halo window, wide eight-phase tile, split tail, pre-split weights, compile-time epilogue
@@ -47,7 +47,7 @@ LAYERS = [
     ('head dense 2048->128', 1, 2048, 128, 1, 1, 1),
 ]
 FAKE = ctypes.c_void_p(1 << 20)          # never dereferenced in a dry run
-MODES = [('bf16', 1, (0, 0)), ('f32 exact', 0, (0, 0)), ('f32 bf16x6_3', 0, (6, 3))]
+MODES = [('bf16', 1, (0, 0)), ('f32 exact', 0, (0, 0)), ('f32 bf16x6_3', 0, (6, 3)), ('f32 f16x3_3', 0, (13, 3))]
 
 
 def rows(views):
