@@ -379,6 +379,9 @@ size_t simclr_comm_mailbox_bytes(int world, int max_doubles);
 int simclr_comm_create(int world, int max_doubles, void** mailbox, void* ipc_handle_64);
 int simclr_comm_open(const void* ipc_handle_64, void** mapped);
 int simclr_comm_close(void* mapped);
+/* Wall-clock bound (seconds) of the arrival wait of the exchanges launched after this call; <= 0 restores the default (600 s or
+ * SIMCLR_PEER_STATS_TIMEOUT_S).  Process-wide; used for the short-bounded set-up self-test. */
+int simclr_comm_set_timeout(double seconds);
 int simclr_comm_destroy(void* mailbox);
 /* out[i] = sum_r in_r[i] (rank order), count <= max_doubles fp64 values; peers: HOST array of `world` mapped mailboxes
  * (peers[rank] = own); seq = 1, 2, ... identical on all ranks per exchange; status (nullable device int, zeroed once by the

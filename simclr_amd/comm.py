@@ -56,9 +56,13 @@ class PeerStats:
             self._mailbox = mailbox.value
         except Exception as e:      # noqa: BLE001 -- any local failure must reach the collective decision below
             err = repr(e)
+        import socket
         infos = [None] * world
-        dist.all_gather_object(infos, (err, bytes(handle)), group=group)
-        self._agree([i[0] for i in infos], 'create')
+        dist.all_gather_object(infos, (err, bytes(handle), socket.gethostname()), group=group)
+        # hipIpc handles only mean something on the exporting host: ranks on different hosts keep the collective library
+        hosts = {i[2] for i in infos}
+        host_err = ('ranks span %d hosts: %s' % (len(hosts), sorted(hosts))) if len(hosts) > 1 else None
+        self._agree([i[0] or host_err for i in infos], 'create')
         # stage 2: map every peer's mailbox
         self._peers = (ctypes.c_void_p * world)()
         err = None
@@ -84,6 +88,7 @@ class PeerStats:
         self.exchanges = 0
         # stage 3: self-test -- rank r contributes (r + 1) * (i + 1) at index i; the sum is known in closed form
         err = None
+        L.comm_set_timeout(float(os.environ.get('SIMCLR_PEER_SELFTEST_TIMEOUT_S', '20')))     # a mapping that does not deliver is found in seconds
         try:
             tri = world * (world + 1) // 2
             for k in range(self.SELF_TEST_EXCHANGES):
@@ -98,6 +103,7 @@ class PeerStats:
             self.exchanges = 0
         except Exception as e:      # noqa: BLE001
             err = repr(e)
+        L.comm_set_timeout(0.0)             # training-time bound: minutes (SIMCLR_PEER_STATS_TIMEOUT_S, default 600 s)
         errs = [None] * world
         dist.all_gather_object(errs, err, group=group)
         self._agree(errs, 'self-test')
@@ -242,6 +248,22 @@ class Strategy:
             return self.peer_stats.all_reduce_sum(tensor)
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.stat_group)
         return tensor
+
+    def close(self):
+        """Release the peer-mapped mailbox and its hipIpc mappings (tests re-create strategies several times per process)."""
+        ps, self.peer_stats = self.peer_stats, None
+        if ps is not None:
+            try:
+                torch.cuda.synchronize()
+            except Exception:      # noqa: BLE001
+                pass
+            ps.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def check_health(self, wait=False):
         """Once per step (run.make_single_step): a timed-out peer-mapped exchange of an earlier step raises here."""

@@ -143,6 +143,11 @@ int simclr_comm_open(const void* ipc_handle_64, void** mapped) {
   *mapped = ptr;
   return 0;
 }
+// Bound of the arrival wait of the exchanges launched AFTER this call, in seconds; <= 0: back to the default (600 s, or
+// SIMCLR_PEER_STATS_TIMEOUT_S).  The set-up self-test of simclr_amd/comm.py runs with a short bound so that a mailbox that was
+// mapped but does not deliver (another host's handle, a stale mapping) is found in seconds, not after the training-time bound.
+static double g_timeout_s = 0.0;
+int simclr_comm_set_timeout(double seconds) { g_timeout_s = seconds; return 0; }
 int simclr_comm_close(void* mapped) { return hipIpcCloseMemHandle(mapped) == hipSuccess ? 0 : 3; }
 int simclr_comm_destroy(void* mailbox) { return hipFree(mailbox) == hipSuccess ? 0 : 2; }
 
@@ -166,7 +171,7 @@ int simclr_comm_stats_allreduce(const double* in, double* out, int count, void* 
     p.peer[r] = (unsigned char*)peers[r];
   }
   p.rank = rank; p.world = world; p.max_doubles = max_doubles; p.seq = seq;
-  static const double timeout_s = getenv("SIMCLR_PEER_STATS_TIMEOUT_S") ? atof(getenv("SIMCLR_PEER_STATS_TIMEOUT_S")) : 600.0;
+  const double timeout_s = g_timeout_s > 0.0 ? g_timeout_s : (getenv("SIMCLR_PEER_STATS_TIMEOUT_S") ? atof(getenv("SIMCLR_PEER_STATS_TIMEOUT_S")) : 600.0);
   static const long long tick_hz = [] {            // wall_clock64() rate: hipDeviceAttributeWallClockRate is in kHz
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -26,9 +27,21 @@ void simclr_set_error(const char* fmt, ...);
     }                                               \
   } while (0)
 
+// SIMCLR_DRY_RUN=1 (tools/instantiation_table.py, a machine without a GPU): launch DECISIONS only -- nothing reaches the device and
+// no launch status is checked.  Read once per process and announced loudly on stderr: a variable that leaks into a real run must
+// not silently turn every convolution into a no-op.
+static inline bool simclr_dry_run() {
+  static const int on = [] {
+    const char* e = getenv("SIMCLR_DRY_RUN");
+    const int v = (e && e[0] == '1') ? 1 : 0;
+    if (v) fprintf(stderr, "[simclr] SIMCLR_DRY_RUN=1: kernel launches are SKIPPED and unchecked in this process (decision table mode)\n");
+    return v;
+  }();
+  return on != 0;
+}
 #define SIMCLR_CHECK_LAUNCH()                                        \
   do {                                                               \
-    { const char* d__ = getenv("SIMCLR_DRY_RUN"); if (d__ && d__[0] == '1') break; }  /* decisions only: no device (conv.hip) */ \
+    if (simclr_dry_run()) break;           /* decisions only: no device (conv.hip) */ \
     hipError_t e__ = hipGetLastError();                              \
     if (e__ != hipSuccess) {                                         \
       simclr_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, \

@@ -2739,7 +2739,7 @@ static int terms_of(int* dtype, bool fwd) {
 // the benchmark models on a machine without a GPU, dumps (layer class -> instantiation) to profiles/, and a CPU test asserts
 // that the table has not changed behind anybody's back.  simclr_conv2d_last_instantiation() returns the record.
 static char g_last_inst[512] = "";
-static bool dry_run() { const char* e = getenv("SIMCLR_DRY_RUN"); return e && e[0] == '1'; }
+static bool dry_run() { return simclr_dry_run(); }
 template <typename T, int MODE> static void record_inst(const char* kern, unsigned grid, unsigned block, size_t lds, const ConvP& p) {
   snprintf(g_last_inst, sizeof(g_last_inst), "%s elt=%d role=%s grid=%u block=%u lds=%zu m_tiles=%d n_tiles=%d tail_parts=%d", kern,
            (int)sizeof(T), MODE == MODE_FWD ? "fwd" : "dgrad", grid, block, lds, p.m_tiles, p.n_tiles, p.rem_parts);
@@ -2942,6 +2942,12 @@ static int split_tail_timeouts(unsigned* host_total) {
       return 2;
     }
     total += v;
+    // After a time-out the late producer may still publish its flag: it would be taken for the partner of a LATER launch (or hipGraph
+    // replay) that uses the slot.  The caller has synchronised (see above), so nothing is in flight: clear the flags, keep the counter.
+    if (v != 0 && hipMemset(g_split_scratch[i].flags, 0, g_split_scratch[i].nflags * sizeof(unsigned)) != hipSuccess) {
+      simclr_set_error("conv2d_split_tail_timeouts: %s", hipGetErrorString(hipGetLastError()));
+      return 2;
+    }
   }
   *host_total = total;
   return 0;
