@@ -578,9 +578,12 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvP p) {
 #ifndef SIMCLR_BN64_WPE
 #define SIMCLR_BN64_WPE 3   // waves per SIMD of the 64-wide bf16 instantiations: 3 workgroups per CU (a few spilled dwords) beat 2 (profiles/r02_notes.md)
 #endif
+// (launch bounds: the 64-wide tiles are sized for THREE workgroups per CU -- igemm_persistent_grid gives them 768 workgroups -- in bf16
+// and, since round 6, in the fp32 three-term instantiations with pre-split weights (<= 168 VGPRs, no spills): with two resident the third
+// third of the persistent grid started when the first finished, 152.9 -> 151.2 ms per parity-mode step, three interleaved pairs)
 template <typename T, int MODE, int BM, int BN, int NW, int STAGES, bool STATS, bool BNEPI, bool EXT = false,
           bool WIN = false, bool FAPPLY = false, int SPL = 0, bool TAIL = false, bool PSB = false, int FAS = 0, int EPS = 0, bool PSX = false>
-__global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && sizeof(T) == 2) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 && (sizeof(T) == 2 || SPL == 13 || (SPL == 3 && PSB))) ? SIMCLR_BN64_WPE : 2) void conv_igemm_persistent(const ConvP p) {
   // EPS (bf16 BNEPI only): the mask mode and the accumulate flag of the fused BatchNorm-backward-reduce epilogue as compile-time
   // constants -- EPS - 1 = 2 * (mode == 4) + accumulate for the modes a ResNet step uses (2: mask recomputed from the BatchNorm
   // input, 4: mask bits, sum(dm) only).  0: read from the kernel arguments.

@@ -42,7 +42,8 @@ def _worker(rank, world, port, q, backend='gloo'):
         from simclr_amd.resnet import RT
         from simclr_amd.run import make_single_step
 
-        depth, image_size, b, num_classes, lr, wd = 18, 32, 8, 10, 0.1, 1e-4
+        depth, image_size, b, num_classes, lr, wd = int(os.environ.get('SIMCLR_TEST_DEPTH', '18')), 32, 8, 10, 0.1, 1e-4
+        matmul = os.environ.get('SIMCLR_TEST_F32_MATMUL', 'exact')
         cfg = Config(resnet_depth=depth, image_size=image_size, num_classes=num_classes, weight_decay=wd)
         params, state = init_model(cfg, seed=0, randomize_bn=False)
         g = torch.Generator().manual_seed(5)
@@ -51,7 +52,7 @@ def _worker(rank, world, port, q, backend='gloo'):
         def run_step():
             FLAGS.reset()
             FLAGS.update(resnet_depth=depth, image_size=image_size, compute_dtype='f32', use_blur=False,
-                         weight_decay=wd, train_batch_size=world * b)
+                         weight_decay=wd, train_batch_size=world * b, f32_matmul=matmul)
             RT.reset()
             RT.device = torch.device('cuda', devno)
             strategy = comm.Strategy()
@@ -104,7 +105,7 @@ def _worker(rank, world, port, q, backend='gloo'):
             for v in model.variables if v.name in ns64)
         # the same two replicas against the REFERENCE's own two-replica step (tf2/run.py:557-622 compiled from its source and run on two
         # emulated replicas, tests/golden/reference_pin.npz): replica r's scaled loss = (con_r + sup_r + weight_decay) / R
-        if world == 2 and os.environ.get('SIMCLR_PEER_STATS') != '1':
+        if world == 2 and os.environ.get('SIMCLR_PEER_STATS') != '1' and depth == 18 and matmul == 'exact':
             from tests import gpu_checks as gc
             mg, ref = gc.reference_pin()
             pin = {}
@@ -149,13 +150,13 @@ def _run(world, backend, env=None):
     for k, v in (env or {}).items():
         os.environ[k] = v
     try:
-        return _run_inner(world, backend)
+        return _run_inner(world, backend, fast_mode=bool(env and env.get('SIMCLR_TEST_F32_MATMUL', 'exact') != 'exact'))
     finally:
         for k in (env or {}):
             os.environ.pop(k, None)
 
 
-def _run_inner(world, backend):
+def _run_inner(world, backend, fast_mode=False):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -166,6 +167,15 @@ def _run_inner(world, backend):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == 'ok' for r in res), res
+    if fast_mode:
+        # the product default (three fp16-piece terms forward, three bf16-piece terms backward, pre-split gradients, fused fp32 tails with
+        # Gram statistics all-reduced over the replicas): forward quantities as tight as the exact mode, gradients at the three-term level
+        for _, _, m in res:
+            assert m['loss_rel'] < 1e-5 and m['bn_moving_worst_rel'] < 1e-4, m
+            # (worst tensor, max-abs relative: ResNet-50 at 32 px normalises over 16 rows in its last group -- measured 1.1e-2 here, round 6)
+            assert m['grad_worst_rel'] < 3e-2 and m['param_worst_rel'] < 5e-4, m
+            assert m['hidden_collectives'] == 2, m
+        return [m for _, _, m in sorted(res)]
     for _, _, m in res:
         # fp32 parity mode, reference initialisation: tight
         assert m['loss_rel'] < 1e-5, m
@@ -194,6 +204,14 @@ def _gloo2():
 def test_two_replica_step_equals_global_batch_oracle():
     res = _gloo2()
     assert all('pin_scaled_loss_rel' in m and len(m['pin_scaled_loss_rel']) == 2 for m in res), res
+
+
+def test_two_replica_step_in_the_default_fast_parity_mode():
+    """ResNet-50 (bottleneck blocks: fused fp32 tails whose Gram-matrix statistics travel through the SyncBN exchange, folded tail BatchNorm
+    backward, pre-split gradients) on two replicas in the product's default arithmetic ('f16x3_3') = ONE replica on the global batch (float64
+    oracle).  Covers what the 8-GPU run of the headline mode executes per rank."""
+    res = _run(2, 'gloo', env={'SIMCLR_PEER_STATS': '0', 'SIMCLR_TEST_DEPTH': '50', 'SIMCLR_TEST_F32_MATMUL': 'f16x3_3'})
+    assert len(res) == 2 and all(m['stat_collectives'] > 50 for m in res), res
 
 
 def _peer_worker(rank, world, port, q, soak):
