@@ -83,16 +83,24 @@ def _worker(rank, world, port, q, backend='gloo'):
         res = {}
         res['loss_rel'] = abs(float(lt) / world - float(t64['con_loss'])) / float(t64['con_loss'])
         byname = {v.name: v for v in model._flat_order}
-        worst = 0.0
+        worst, worst_name, num, den = 0.0, None, 0.0, 0.0
         for k, ref in t64['grads'].items():
             if ref is None or float(ref.abs().max()) < 1e-12:
                 continue
-            e = float((byname[k].grad.double().cpu() - ref).abs().max()) / float(ref.abs().max())
-            worst = max(worst, e)
+            d = byname[k].grad.double().cpu() - ref
+            e = float(d.abs().max()) / float(ref.abs().max())
+            num += float((d * d).sum())
+            den += float((ref * ref).sum())
+            if e > worst:
+                worst, worst_name = e, k
         res['grad_worst_rel'] = worst
+        res['grad_worst_name'] = worst_name
+        res['grad_rel_l2'] = (num / den) ** 0.5                 # over ALL gradient tensors at once
         res['param_worst_rel'] = max(
             float((byname[k].value.double().cpu() - np64[k]).abs().max()) / (float(np64[k].abs().max()) + 1e-30)
             for k in np64)
+        res['param_rel_l2'] = (sum(float(((byname[k].value.double().cpu() - np64[k]) ** 2).sum()) for k in np64)
+                               / sum(float((np64[k] ** 2).sum()) for k in np64)) ** 0.5
         res['stat_collectives'] = strategy.stat_collectives
         res['hidden_collectives'] = strategy.hidden_collectives
         res['peer_exchanges'] = strategy.peer_stats.exchanges if strategy.peer_stats is not None else 0
@@ -172,8 +180,12 @@ def _run_inner(world, backend, fast_mode=False):
         # Gram statistics all-reduced over the replicas): forward quantities as tight as the exact mode, gradients at the three-term level
         for _, _, m in res:
             assert m['loss_rel'] < 1e-5 and m['bn_moving_worst_rel'] < 1e-4, m
-            # (worst tensor, max-abs relative: ResNet-50 at 32 px normalises over 16 rows in its last group -- measured 1.1e-2 here, round 6)
-            assert m['grad_worst_rel'] < 3e-2 and m['param_worst_rel'] < 5e-4, m
+            # all gradients at once: the gate of tools/step_modes.py (2e-3 relative L2); the worst single tensor, max-abs relative, is looser
+            # (ResNet-50 at 32 px normalises over 16 rows in its last group -- measured 1.1e-2 here, round 6).  A zero-initialised variable
+            # (BatchNorm beta, the zero-initialised gamma of each block's last BatchNorm) becomes -lr * gradient after one step, so the
+            # worst updated variable carries exactly its gradient's relative error; all variables at once stay at the 1e-4 * that level.
+            assert m['grad_rel_l2'] < 2e-3 and m['grad_worst_rel'] < 3e-2, m
+            assert m['param_worst_rel'] < 3e-2 and m['param_rel_l2'] < 1e-4, m
             assert m['hidden_collectives'] == 2, m
         return [m for _, _, m in sorted(res)]
     for _, _, m in res:
