@@ -2437,6 +2437,7 @@ struct StemP {
   void* y;         // [M][N]
   float* stats;
   int V, HP, WP, OH, OW, N, KHP, KWP, stride, M, KP, nslot, m_tiles;
+  int diag;          // diagnostic build only (SIMCLR_DIAG): 1 = no MFMA, 2 = no activation loads in the tile loop, 4 = no stores
 };
 
 // KS > 0 (the 7x7 stem in bf16: 7 k-steps, one padded kernel row of 8 taps x 4 channels each): the k-loop is unrolled and
@@ -2445,9 +2446,17 @@ struct StemP {
 // SPL (fp32 storage, simclr_set_f32_matmul): 3 / 6 split-bf16 terms per product instead of the exact fp32 MFMA -- two
 // consecutive 16-element k-steps of a lane become the eight reduction elements of one v_mfma_f32_16x16x32_bf16 (the same pairing
 // for the activation and the weight operand, so every product is formed exactly once; an odd trailing k-step is paired with zeros).
+// SPL > 0 with KS > 0 (fp32 storage, KS = the padded K in 16-element k-steps, even: 14 for the 7x7 stem): the k-loop is unrolled, the
+// weights sit PRE-SPLIT in LDS (hi pieces in the even k-step's chunk, lo pieces in the odd one's: split once per workgroup instead of
+// once per tile) and the activation fragments ROLL: as soon as the two k-steps of a pair have been split into their pieces, the same
+// registers are reloaded with the NEXT tile's fragments, so the L2 round trip of a tile's 28 loads hides behind the previous tile's
+// 168 MFMAs (the runtime loop waited for it seven times per tile: 2.5 ms for 0.45 ms of matrix work, profiles/r06_notes.md).
 template <typename T, bool STATS, int KS = 0, int SPL = 0>
-__global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
-  static_assert(SPL == 0 || (sizeof(T) == 4 && KS == 0), "split-bf16 terms: fp32 storage, runtime k-loop");
+__global__ __launch_bounds__(256, (SPL > 0 && KS > 0) ? 2 : 1) void stem_conv_fwd(const StemP p) {
+  static_assert(SPL == 0 || sizeof(T) == 4, "split terms: fp32 storage");
+  static_assert(SPL == 0 || KS % 2 == 0, "split terms, unrolled: whole k-step pairs");
+  constexpr bool ROLL = SPL > 0 && KS > 0;
+  constexpr bool PSW = ROLL && (SPL == 3 || SPL == 13);     // weights pre-split in LDS (two planes: the three-term products only)
   constexpr int EPC = Elem<T>::EPC;
   constexpr int KSTEP = 4 * EPC;     // elements per MFMA k-step
   constexpr int BN = 64;
@@ -2459,6 +2468,20 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
   const int pitch = p.KP * (int)sizeof(T) + 16;  // bytes per weight row in LDS (+16: bank spread)
   const T* __restrict__ Wt = (const T*)p.w;
   const int cpr = p.KP / EPC;  // chunks per weight row
+  if constexpr (PSW) {
+    // (row, k-step pair, lane group): the eight values a lane multiplies in one MFMA = chunks (2 kp) * 4 + g and (2 kp + 1) * 4 + g
+    for (int id = tid; id < BN * (KS / 2) * 4; id += 256) {
+      const int r = id / (KS * 2), q = id % (KS * 2), kp = q >> 2, gq = q & 3;
+      u32x4 c0 = zero16(), c1 = zero16(), hi, lo;
+      if (n0 + r < p.N) {
+        c0 = ld16(Wt + (long long)(n0 + r) * p.KP + ((2 * kp) * 4 + gq) * EPC);
+        c1 = ld16(Wt + (long long)(n0 + r) * p.KP + ((2 * kp + 1) * 4 + gq) * EPC);
+      }
+      if constexpr (SPL == 13) split_terms2_f16(c0, c1, hi, lo); else split_terms2(c0, c1, hi, lo);
+      *(u32x4*)(smem + r * pitch + ((2 * kp) * 4 + gq) * 16) = hi;
+      *(u32x4*)(smem + r * pitch + ((2 * kp + 1) * 4 + gq) * 16) = lo;
+    }
+  } else
   for (int id = tid; id < BN * cpr; id += 256) {
     const int r = id / cpr, c = id % cpr;
     u32x4 v = zero16();
@@ -2479,26 +2502,82 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { st_s[i][r] = 0.f; st_q[i][r] = 0.f; }
   float* cst = red + 4 * BN * 2;               // bf16: [128][64] C staging tile (16 KB) behind the reduction scratch
+  auto tile_rows = [&](int mt_, long long* base_, bool* ok_) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mt_ * 128 + wave * 32 + i * 16 + fl;
+      ok_[i] = m < p.M;
+      const int mm = ok_[i] ? m : 0;
+      const int v = mm / (p.OH * p.OW);
+      const int rem = mm - v * (p.OH * p.OW);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      base_[i] = (((long long)v * p.HP + oy * p.stride) * p.WP + ox * p.stride) * 4;
+    }
+  };
+  // element offset of k-step ks of this lane's group inside the packed image (kernel row, position in the row)
+  int koff[ROLL ? KS : 1];           // (computed once: a runtime division per k-step)
+  if constexpr (ROLL) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * KSTEP + g * EPC;
+      const int kh = e / row_elems, within = e - kh * row_elems;
+      koff[ks] = kh * p.WP * 4 + within;
+    }
+  }
+  auto k_off = [&](int ks) -> int { return koff[ks]; };
+  u32x4 roll[ROLL ? KS : 1][2];      // ROLL: the activation fragments of the tile about to be computed
+  if constexpr (ROLL) {
+    if ((int)blockIdx.x < p.m_tiles) {
+      long long b0[2];
+      bool k0[2];
+      tile_rows(blockIdx.x, b0, k0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) roll[ks][i] = ld16(X + b0[i] + k_off(ks));      // (rows beyond M read pixel 0: zeroed below)
+    }
+  }
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
     const int mw = mt * 128 + wave * 32;
     long long base[2];
     bool ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = mw + i * 16 + fl;
-      ok[i] = m < p.M;
-      const int mm = ok[i] ? m : 0;
-      const int v = mm / (p.OH * p.OW);
-      const int rem = mm - v * (p.OH * p.OW);
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      base[i] = (((long long)v * p.HP + oy * p.stride) * p.WP + ox * p.stride) * 4;
-    }
+    tile_rows(mt, base, ok);
     f32x4 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (KS > 0) {
+    if constexpr (ROLL) {
+      const int mtn = mt + gridDim.x;
+      long long nbase[2];
+      bool nok[2];
+      tile_rows(mtn < p.m_tiles ? mtn : mt, nbase, nok);
+      if (mt * 128 + 128 > p.M) {                            // the partial last tile: rows beyond M multiply zeros
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (!ok[i]) roll[ks][i] = zero16();
+      }
+#pragma unroll
+      for (int kp = 0; kp < KS; kp += 2) {
+        if (!DIAG(1))
+        mma_f32_chunks<4, 2, false, SPL, PSW>(&acc[0][0],
+            [&](int ni, int h) { return *(const u32x4*)(smem + (ni * 16 + fl) * pitch + ((kp + h) * 4 + g) * 16); },
+            [&](int mi, int h) { return roll[kp + h][mi]; });
+        // (unconditional: a workgroup's last tile re-reads its own fragments -- a branch here would make the compiler count the loads
+        // of this tile as possibly absent and wait for ALL outstanding ones at the later pairs)
+        // The scheduling fences keep the reloads where they are written: left alone, the scheduler gathers all 28 at the end of the tile.
+        __builtin_amdgcn_sched_barrier(0);
+        if (!DIAG(2)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) roll[kp + h][i] = ld16(X + nbase[i] + k_off(kp + h));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (KS > 0) {
       u32x4 afk[KS > 0 ? KS : 1][2];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -2584,7 +2663,7 @@ __global__ __launch_bounds__(256) void stem_conv_fwd(const StemP p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int m = mw + mi * 16 + fl;
-          if (m < p.M && n < p.N)
+          if (m < p.M && n < p.N && !DIAG(4))
             *(float4*)(Y + (long long)m * p.N + n) = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
         }
       }
@@ -3749,7 +3828,11 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     const int grid_s = p.k_tiles * p.n_tiles * ceil_div(p.splits, 8) * 8;
     // 8 waves (4 along the 256 k-rows x 2 along n): 4 k-fragments and 4 LDS-DMA source states per wave -- the 4-wave shape keeps 8 + 8
     // of them next to the split fragments and spills ~100 registers
-    if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, 256, 64, 2, 2, 4, 2, false, true, 3>), dim3(grid_s), dim3(512), lds_s, stream, p);
+    // SIMCLR_STEM_WGRAD_STAGES=3: a three-deep ring (120 KB) -- two 32-pixel chunks in flight behind the one being multiplied
+    static const int stem_stages = getenv("SIMCLR_STEM_WGRAD_STAGES") ? atoi(getenv("SIMCLR_STEM_WGRAD_STAGES")) : 2;
+    if (p.split == 3 && stem_stages == 3)
+      hipLaunchKernelGGL((conv_wgrad_dma<float, 256, 64, 2, 3, 4, 2, false, true, 3>), dim3(grid_s), dim3(512), lds_s / 2 * 3, stream, p);
+    else if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, 256, 64, 2, 2, 4, 2, false, true, 3>), dim3(grid_s), dim3(512), lds_s, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_dma<float, 256, 64, 2, 2, 4, 2, false, true, 6>), dim3(grid_s), dim3(512), lds_s, stream, p);
   } else if (stem_dma) {
     const size_t lds_s = (size_t)2 * 64 * (256 + 64) * 2;      // 2 stages x 64 pixels x (256 + 64) bf16
@@ -3886,6 +3969,9 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
   SIMCLR_CHECK_ARG((KWP * 4) % epc == 0, "stem_conv_fwd: KWP*4 must be a multiple of %d", epc);
   SIMCLR_CHECK_ARG(Cout % (dtype == SIMCLR_DT_BF16 ? 8 : 4) == 0, "stem_conv_fwd: Cout=%d must be a multiple of %d", Cout, dtype == SIMCLR_DT_BF16 ? 8 : 4);
   p.m_tiles = ceil_div(p.M, 128);
+#ifdef SIMCLR_DIAG
+  { const char* e = getenv("SIMCLR_DIAG"); p.diag = e ? atoi(e) : 0; }
+#endif
   const size_t esz = dtype == SIMCLR_DT_BF16 ? 2 : 4;
   const size_t lds = 64 * (p.KP * esz + 16) + 4 * 64 * 2 * sizeof(float) + (esz == 2 ? 128 * 64 * 2 : 0);
   dim3 grid(min(p.m_tiles, 2048), ceil_div(Cout, 64));
@@ -3903,9 +3989,14 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
     // keep ~2^-21 relative in their unscaled lo pieces; -0.8 ms per step against six bf16 terms, profiles/r06_notes.md)
     constexpr bool stem_f16_on = true;
     const int spl = stem_split_on ? ((terms == 13 && !stem_f16_on) ? 6 : terms) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
+    // the 7x7 stem (7 padded kernel rows of 8 taps x 4 channels = 14 k-steps of 16): unrolled, weights pre-split in LDS, rolling fragments
+    static const bool stem_roll_on = !getenv("SIMCLR_STEM_ROLL") || atoi(getenv("SIMCLR_STEM_ROLL")) != 0;
+    const bool roll = stem_roll_on && p.KP == 14 * 16;
 #define LSF(STv)                                                                                              \
     do {                                                                                                       \
-      if (spl == 13) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 13>), grid, dim3(256), lds, stream, p);  \
+      if (spl == 13 && roll) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 14, 13>), grid, dim3(256), lds, stream, p);  \
+      else if (spl == 3 && roll) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 14, 3>), grid, dim3(256), lds, stream, p);    \
+      else if (spl == 13) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 13>), grid, dim3(256), lds, stream, p);  \
       else if (spl == 3) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 3>), grid, dim3(256), lds, stream, p);    \
       else if (spl == 6) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 0, 6>), grid, dim3(256), lds, stream, p); \
       else hipLaunchKernelGGL((stem_conv_fwd<float, STv>), grid, dim3(256), lds, stream, p);                   \

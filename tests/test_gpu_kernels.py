@@ -543,6 +543,16 @@ def test_stem_conv(V, H, k, s, dtype):
     _assert(gc.check_stem(V, H, k, s, 64, dtype))
 
 
+@pytest.mark.parametrize('matmul', ['bf16x3', 'f16x3_3'])
+def test_stem_conv_f32_rolling_fragments_over_many_tiles(matmul):
+    """The unrolled 7x7 stem forward of the three-term modes (stem_conv_fwd<float, ., 14, 3 | 13>: weights pre-split in LDS, the activation
+    fragments of the NEXT tile reloaded into the registers the current tile has just consumed): 225 px give 113 x 113 outputs, 24 views =
+    306 456 rows = 2 394 tiles + 24 rows on 2 048 persistent workgroups, so some workgroups compute a second tile from rolled fragments
+    and the last tile is partial."""
+    from tests import gpu_checks as gc
+    _assert(gc.check_stem(24, 225, 7, 2, 64, F32, matmul=matmul))
+
+
 @pytest.mark.parametrize('matmul', ['bf16x6_3', 'bf16x3', 'bf16x6', 'f16x3_3'])
 @pytest.mark.parametrize('V,H,k,s', [(4, 32, 7, 2), (4, 16, 3, 1), (2, 224, 7, 2), (2, 33, 7, 2), (6, 48, 3, 2)])
 def test_stem_conv_f32_split_bf16_matmul(V, H, k, s, matmul):
