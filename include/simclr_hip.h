@@ -224,6 +224,17 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
                          simclr_stream_t stream);
 int simclr_unpack_stem_dw(const float* src, float* dst, int KH, int KW, int Cin, int Cout, int KWP,
                           int accumulate, simclr_stream_t stream);
+/* Stem weight gradient of the three-term parity mode (fp32 storage, three bf16-piece backward terms) from PRE-SPLIT operands
+   (tf2/resnet.py:593-599 under tape.gradient): xq = simclr_presplit_packed(xp) -- every packed pixel [4] fp32 becomes four bf16 hi
+   pieces followed by four bf16 lo pieces, same 16 bytes --, dy_ps [V*OH*OW][64] in the pre-split block format
+   (simclr_bn_bwd_apply with SIMCLR_FMT_PS_OUT).  dw_kn: fp32 [KH*KWP*4][64], the layout simclr_unpack_stem_dw reads; workspace:
+   simclr_stem_wgrad_ps_workspace_bytes.  Only the 7x7 / stride-2 stem with 64 output channels (simclr_stem_wgrad_ps_supported);
+   every other stem keeps simclr_conv2d_wgrad on the packed input. */
+int simclr_presplit_packed(const void* xp, void* xq, long long npix, simclr_stream_t stream);
+int simclr_stem_wgrad_ps_supported(int KH, int KWP, int stride, int Cout);
+size_t simclr_stem_wgrad_ps_workspace_bytes(int V, int OH, int OW, int KH);
+int simclr_stem_wgrad_ps(const void* xq, const void* dy_ps, float* dw_kn, int accumulate, void* workspace, int V, int HP,
+                         int WP, int OH, int OW, int Cout, int KH, int KWP, int stride, simclr_stream_t stream);
 
 /* ---- BatchNorm: tf2/resnet.py:31-78 (BatchNormRelu), residual tail :382/:487 ------------------- */
 int simclr_bn_reduce_slots(const float* partial, int nslot, int C, double* sums, simclr_stream_t stream);

@@ -90,7 +90,8 @@ class _Lib:
         self._int_fns = {n for n, (r, _) in self.signatures.items() if r is ctypes.c_int}
         self._no_check = {'simclr_abi_version', 'simclr_lars_chunk_elems', 'simclr_conv2d_stats_slots',
                           'simclr_stem_stats_slots', 'simclr_bn_bwd_reduce_slots', 'simclr_bn_bwd_pool_slots',
-                          'simclr_prep_chunk_elems', 'simclr_get_f32_matmul', 'simclr_conv2d_last_split_parts', 'simclr_conv2d_last_presplit'}
+                          'simclr_prep_chunk_elems', 'simclr_get_f32_matmul', 'simclr_conv2d_last_split_parts', 'simclr_conv2d_last_presplit',
+                          'simclr_stem_wgrad_ps_supported'}
 
     def last_error(self):
         return self._dll.simclr_last_error().decode()

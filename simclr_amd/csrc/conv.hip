@@ -2786,6 +2786,164 @@ __global__ __launch_bounds__(256) void prep_weights_pair_multi(const long long* 
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Stem weight gradient of the three-term parity mode from PRE-SPLIT operands (tf2/resnet.py:593-599 under tape.gradient, fp32 storage).
+// The multi-tap tile of conv_wgrad_dma above splits both operands in registers (2.75 VALU per element, redone by every wave that
+// shares a row), reads them with 4-byte LDS loads and gathers every packed pixel SEVEN times (once per kernel row): 3.3 ms per step
+// for 0.3 ms of matrix work (profiles/r06_notes.md).  Here both operands arrive as bf16 pieces:
+//   xq  [V][HP][WP] packed pixels of 16 bytes: the four hi pieces (c0..c3; c3 = 0), then the four lo pieces (simclr_presplit_packed);
+//   dy  [M][64] in the pre-split block format of common.h (simclr_bn_bwd_apply with SIMCLR_FMT_PS_OUT).
+// A workgroup (two waves) walks 32-pixel segments of output rows.  Per segment ONE window of the image -- KH rows x (31 * STRIDE + 8)
+// packed pixels, 7.7 KB for the 7x7 / stride-2 stem instead of 28 KB of gathered rows -- and the 8 KB gradient tile arrive by LDS-DMA
+// (ring of STAGES segments).  Every MFMA fragment is two transposing LDS reads (ds_read_b64_tr_b16), no VALU: for the image operand
+// lane (fl, g) addresses packed pixel STRIDE * (8 g + (fl >> 2)) + tap (tap = 4 * half + (fl & 3)) of kernel row r, i.e. the k-rows
+// r * 32 + half * 16 .. + 15 = (four taps x four channels) of fragment 2 r + half; the gradient operand is read as in the PSD = 1
+// instantiation above.  Wave w owns fragments KH * w .. KH * w + KH - 1 (7 x 4 accumulator tiles for the 7x7 stem) over all 64
+// output channels: per segment 8 + 4 * KH transposing reads feed 12 * KH MFMAs.
+// Output: fp32 slabs [split][KH * 32][64] (k = kh * 32 + kw * 4 + ci, the layout unpack_stem_dw reads) reduced by slab_reduce.
+// ------------------------------------------------------------------------------------
+struct StemWgP {
+  const void* xq;
+  const void* dy;
+  float* dw;
+  const void* zero;
+  int HP, WP, OH, OW, segs;
+  int chunks, splits, chunks_per_split;
+};
+
+template <int KH, int STRIDE, int STAGES>
+__global__ __launch_bounds__(128, 2) void stem_wgrad_ps(const StemWgP p) {
+  constexpr int WCOLS = 31 * STRIDE + 8;                 // packed pixels per window row
+  constexpr int WSLOTS = KH * WCOLS;
+  constexpr int WJ = (WSLOTS + 63) / 64;                 // LDS-DMA instructions per window
+  constexpr int WBYTES = WJ * 1024;
+  constexpr int DJ = 8;                                  // ... per gradient tile: 32 pixels x 256 bytes
+  constexpr int STAGE = WBYTES + DJ * 1024;
+  constexpr int WJW = (WJ + 1) / 2, DJW = DJ / 2;        // per wave
+  constexpr int LPC = WJW + DJW;
+  constexpr int NI = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, fl = lane & 15;
+  const int split = blockIdx.x;
+  if (split >= p.splits) return;
+  const int c_begin = split * p.chunks_per_split, c_end = min(p.chunks, c_begin + p.chunks_per_split);
+  const unsigned char* __restrict__ XQ = (const unsigned char*)p.xq;
+  const unsigned char* __restrict__ DY = (const unsigned char*)p.dy;
+  auto key_b = [](int px) __attribute__((always_inline)) { return (px & 3) | (((px >> 3) & 1) << 2); };
+
+  // ---- per-lane source state: fixed for the whole kernel, only the segment's base moves ----
+  int w_off[WJW], w_col[WJW];       // byte offset of this lane's packed pixel inside the window's image rows; its column (-1: no slot)
+#pragma unroll
+  for (int j = 0; j < WJW; ++j) {
+    const int slot = (wave * WJW + j) * 64 + lane;
+    const int r = slot / WCOLS, col = slot - r * WCOLS;
+    const bool ok = slot < WSLOTS && wave * WJW + j < WJ;
+    w_col[j] = ok ? col : -1;
+    w_off[j] = (r * p.WP + col) * 16;
+  }
+  int d_off[DJW], d_px[DJW];
+#pragma unroll
+  for (int j = 0; j < DJW; ++j) {
+    const int px = (wave * DJW + j) * 4 + (lane >> 4), pc = lane & 15;
+    const int lc = (((pc >> 1) ^ key_b(px)) << 1) | (pc & 1);          // logical 16-byte chunk held by this LDS slot
+    d_px[j] = px;
+    d_off[j] = px * 256 + lc * 16;
+  }
+  auto issue = [&](int stage, int c) __attribute__((always_inline)) {
+    const int row = c / p.segs, seg = c - row * p.segs;                 // (workgroup-uniform)
+    const int v = row / p.OH, oy = row - v * p.OH, ox0 = seg * 32;
+    const long long xbase = (((long long)v * p.HP + oy * STRIDE) * p.WP + ox0 * STRIDE) * 16;
+    const long long dbase = ((long long)row * p.OW + ox0) * 256;
+    unsigned char* w_dst = smem + stage * STAGE + wave * (WJW * 1024);
+    unsigned char* d_dst = smem + stage * STAGE + WBYTES + wave * (DJW * 1024);
+#pragma unroll
+    for (int j = 0; j < WJW; ++j) {
+      if (wave * WJW + j < WJ) {
+        const bool ok = w_col[j] >= 0 && ox0 * STRIDE + w_col[j] < p.WP;
+        const void* src = ok ? (const void*)(XQ + xbase + w_off[j]) : p.zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w_dst + j * 1024), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DJW; ++j) {
+      const void* src = ox0 + d_px[j] < p.OW ? (const void*)(DY + dbase + d_off[j]) : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(d_dst + j * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[KH][NI];
+#pragma unroll
+  for (int i = 0; i < KH; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    const unsigned char* Ws = smem + stage * STAGE;
+    const unsigned char* Ds = Ws + WBYTES;
+    const int px0 = g * 8 + (fl >> 2);
+    mma_f32_chunks<NI, KH, true, 3, true, true>(&acc[0][0],
+        [&](int nf, int h) {                                     // gradient: 16-position run nf of the block format, h = 0 hi | 1 lo
+          const int byte = (nf >> 1) * 128 + h * 64 + (nf & 1) * 32 + (fl & 3) * 8;
+          auto off = [&](int px) { return px * 256 + (((byte >> 5) ^ key_b(px)) << 5) + (byte & 31); };
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ds + off(px0)));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ds + off(px0 + 4)));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          return (u32x4){l2[0], l2[1], h2[0], h2[1]};
+        },
+        [&](int i, int h) {                                      // image: fragment f = 2 r + half of this wave
+          const int f = wave * KH + i, r = f >> 1, half = f & 1;
+          const int slot = r * WCOLS + STRIDE * px0 + 4 * half + (fl & 3);
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ws + slot * 16 + h * 8));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Ws + (slot + 4 * STRIDE) * 16 + h * 8));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          return (u32x4){l2[0], l2[1], h2[0], h2[1]};
+        });
+  };
+
+  int issued = c_begin;
+#pragma unroll
+  for (int s_ = 0; s_ < STAGES - 1; ++s_)
+    if (issued < c_end) { issue(s_, issued); ++issued; }
+  int cs = 0, is = STAGES - 1;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int ahead = issued - c - 1;
+    if (STAGES >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPC) : "memory");
+    else if (STAGES >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (issued < c_end) { issue(is, issued); ++issued; is = (is + 1 == STAGES) ? 0 : is + 1; }
+    compute(cs);
+    cs = (cs + 1 == STAGES) ? 0 : cs + 1;
+  }
+  // D[n position g * 4 + reg of run nf][k row fl of fragment f]  ->  slab[split][f * 16 + fl][channel .. + 3]
+  float* slab = p.dw + (long long)split * (KH * 32 * 64);
+#pragma unroll
+  for (int i = 0; i < KH; ++i) {
+    const int kk = (wave * KH + i) * 16 + fl;
+#pragma unroll
+    for (int nf = 0; nf < NI; ++nf) {
+      const int Q = 4 * (nf & 1) + g;
+      const int n = (nf >> 1) * 32 + (Q & 1) * 16 + (Q >> 1) * 4;
+      *(float4*)(slab + kk * 64 + n) = make_float4(acc[i][nf][0], acc[i][nf][1], acc[i][nf][2], acc[i][nf][3]);
+    }
+  }
+}
+
+// packed image [npix][4] fp32 -> [npix] x (four bf16 hi pieces, four bf16 lo pieces): the image operand of stem_wgrad_ps
+__global__ __launch_bounds__(256) void presplit_packed(const float4* __restrict__ src, u32x4* __restrict__ dst, long long npix) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += (long long)gridDim.x * 256ll) {
+    const float4 v = src[i];
+    uint32_t h0, l0, h1, l1;
+    split_pair<false>(v.x, v.y, h0, l0);
+    split_pair<false>(v.z, v.w, h1, l1);
+    dst[i] = (u32x4){h0, h1, l0, l1};
+  }
+}
+
 // stem wgrad result [KHP*KWP*4][CO] -> HWIO [KH][KW][CI][CO]  (+= if accumulate)
 __global__ void unpack_stem_dw(const float* __restrict__ src, float* __restrict__ dst, int KH, int KW,
                                int CI, int CO, int KWP, int accumulate) {
@@ -4060,6 +4218,55 @@ int simclr_prep_weights_pair_multi(const long long* table, const long long* chun
     hipLaunchKernelGGL((prep_weights_pair_multi<uint16_t>), dim3(nchunks), dim3(256), 0, stream, table, chunks);
   else
     hipLaunchKernelGGL((prep_weights_pair_multi<float>), dim3(nchunks), dim3(256), 0, stream, table, chunks);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- stem weight gradient from pre-split operands (three bf16 backward terms; see stem_wgrad_ps) ----
+int simclr_presplit_packed(const void* xp, void* xq, long long npix, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(xp && xq && npix > 0, "presplit_packed: empty input");
+  hipLaunchKernelGGL(presplit_packed, dim3((unsigned)min((npix + 255) / 256, 65536ll)), dim3(256), 0, stream, (const float4*)xp,
+                     (u32x4*)xq, npix);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+// 1 if simclr_stem_wgrad_ps has a kernel for this stem (the 7x7 / stride-2 ImageNet stem with 64 output channels)
+int simclr_stem_wgrad_ps_supported(int KH, int KWP, int stride, int Cout) { return KH == 7 && KWP == 8 && stride == 2 && Cout == 64; }
+static int stem_wgrad_ps_splits(long long chunks, int* cps) {
+  // four two-wave workgroups per CU (two per SIMD pair), every one of them resident for the whole launch
+  static const int want_env = getenv("SIMCLR_STEM_WGRAD_BLOCKS") ? atoi(getenv("SIMCLR_STEM_WGRAD_BLOCKS")) : 1024;
+  const int want = (int)max(1ll, min((long long)max(8, min(want_env, 1024)), chunks));
+  *cps = (int)((chunks + want - 1) / want);
+  return (int)((chunks + *cps - 1) / *cps);
+}
+size_t simclr_stem_wgrad_ps_workspace_bytes(int V, int OH, int OW, int KH) {
+  int cps;
+  const long long chunks = (long long)V * OH * ((OW + 31) / 32);
+  return (size_t)stem_wgrad_ps_splits(chunks, &cps) * KH * 32 * 64 * sizeof(float);
+}
+// xq: simclr_presplit_packed of the packed views [V][HP][WP][4]; dy_ps [V*OH*OW][64] in the pre-split block format;
+// dw_kn: fp32 [KH*KWP*4][64] (what simclr_unpack_stem_dw reads); accumulate != 0: dw_kn += result.
+int simclr_stem_wgrad_ps(const void* xq, const void* dy_ps, float* dw_kn, int accumulate, void* workspace, int V, int HP, int WP,
+                         int OH, int OW, int Cout, int KH, int KWP, int stride, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(simclr_stem_wgrad_ps_supported(KH, KWP, stride, Cout), "stem_wgrad_ps: only the 7x7 / stride-2 stem with 64 output channels "
+                   "(KH=%d KWP=%d stride=%d Cout=%d)", KH, KWP, stride, Cout);
+  SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31) && (long long)V * HP * WP * 16 < (1ll << 40), "stem_wgrad_ps: sizes overflow");
+  SIMCLR_CHECK_ARG(HP >= (OH - 1) * stride + KH && WP >= (OW - 1) * stride + KWP, "stem_wgrad_ps: packed image %d x %d too small", HP, WP);
+  StemWgP p = {};
+  p.xq = xq; p.dy = dy_ps; p.dw = (float*)workspace; p.zero = zero_page();
+  SIMCLR_CHECK_ARG(p.zero != nullptr, "stem_wgrad_ps: zero page symbol not found");
+  p.HP = HP; p.WP = WP; p.OH = OH; p.OW = OW; p.segs = (OW + 31) / 32;
+  const long long chunks = (long long)V * OH * p.segs;
+  p.chunks = (int)chunks;
+  p.splits = stem_wgrad_ps_splits(chunks, &p.chunks_per_split);
+  static const int stages_env = getenv("SIMCLR_STEM_WGRAD_PS_STAGES") ? atoi(getenv("SIMCLR_STEM_WGRAD_PS_STAGES")) : 2;
+  constexpr int stage_bytes = ((7 * 70 + 63) / 64 + 8) * 1024;
+  if (stages_env == 3) hipLaunchKernelGGL((stem_wgrad_ps<7, 2, 3>), dim3(p.splits), dim3(128), 3 * stage_bytes, stream, p);
+  else hipLaunchKernelGGL((stem_wgrad_ps<7, 2, 2>), dim3(p.splits), dim3(128), 2 * stage_bytes, stream, p);
+  SIMCLR_CHECK_LAUNCH();
+  const long long numel = (long long)KH * 32 * 64;
+  hipLaunchKernelGGL(slab_reduce, dim3(max(1, (int)ceil_div(numel / 4, 16))), dim3(256), 0, stream, (const float*)workspace, p.splits,
+                     numel, dw_kn, accumulate);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -417,11 +417,44 @@ def stem_conv_fwd(xp, w_s, geo, stride, stats=None):
     return y
 
 
-def stem_conv_wgrad(xp, dy, geo, KH, KW, stride, out=None, accumulate=False):
-    """dW (HWIO [KH,KW,3,Cout] fp32) of the stem from the packed input."""
+def stem_wgrad_ps_supported(geo, KH, stride, Cout):
+    """Does the pre-split stem weight gradient (simclr_stem_wgrad_ps) cover this stem?  fp32 storage with three bf16 backward terms
+    (ps_backward_enabled), the 7x7 / stride-2 stem with 64 output channels; SIMCLR_STEM_WGRAD_PS=0 keeps the multi-tap kernel."""
+    import os
+    if os.environ.get('SIMCLR_STEM_WGRAD_PS', '1') in ('', '0') or not ps_backward_enabled():
+        return False
+    return bool(lib().stem_wgrad_ps_supported(KH, geo['KWP'], stride, Cout))
+
+
+def presplit_packed(xp):
+    """The packed views [V, HP, WP, 4] fp32 as (four bf16 hi pieces | four bf16 lo pieces) per pixel: the image operand of
+    stem_conv_wgrad when the gradient arrives pre-split."""
+    assert xp.dtype == torch.float32 and xp.shape[-1] == 4 and xp.is_contiguous()
+    xq = torch.empty_like(xp)
+    lib().presplit_packed(_p(xp), _p(xq), xp.numel() // 4, _s())
+    return xq
+
+
+def stem_conv_wgrad(xp, dy, geo, KH, KW, stride, out=None, accumulate=False, xq=None):
+    """dW (HWIO [KH,KW,3,Cout] fp32) of the stem from the packed input.  A pre-split dy (bn_bwd_apply(ps_out=True), tagged `_ps`) takes
+    simclr_stem_wgrad_ps with xq = presplit_packed(xp) (computed here when the caller has not kept one)."""
     Cout = dy.shape[3]
     kp = geo['KHP'] * geo['KWP'] * 4
     tmp = torch.empty(kp, Cout, device=dy.device, dtype=torch.float32)
+    if ps_kind(dy):
+        assert ps_kind(dy) == 'b16' and stem_wgrad_ps_supported(geo, KH, stride, Cout), 'pre-split dy without a pre-split stem kernel'
+        if xq is None:
+            xq = presplit_packed(xp)
+        V, OH, OW = dy.shape[0], dy.shape[1], dy.shape[2]
+        ws = _workspace(lib().stem_wgrad_ps_workspace_bytes(V, OH, OW, geo['KHP']), dy.device)
+        M = V * OH * OW
+        _launch('conv_wgrad', 2.0 * M * kp * Cout, 4 * (xp.numel() + M * Cout) + 4 * kp * Cout,
+                lambda: lib().stem_wgrad_ps(_p(xq), _pp(dy), _p(tmp), 0, _p(ws), V, geo['HP'], geo['WP'], OH, OW, Cout, geo['KHP'],
+                                            geo['KWP'], stride, _s()))
+        if out is None:
+            out = torch.empty(KH, KW, 3, Cout, device=dy.device, dtype=torch.float32)
+        lib().unpack_stem_dw(_p(tmp), _p(out), KH, KW, 3, Cout, geo['KWP'], int(accumulate), _s())
+        return out
     # one 'tap' per kernel row: KWP*4 = 32 contiguous elements, pixel pitch 4
     conv2d_wgrad(xp, dy, geo['KHP'], 1, stride, 0, Cin=geo['KWP'] * 4, pixpitch=4, out=tmp)
     if out is None:

@@ -355,7 +355,12 @@ def _ps_grad_ok(conv):
     if conv is None or RT.dtype != torch.float32 or not isinstance(conv, Conv2dFixedPadding):
         return False
     sv = conv.saved
-    if sv is None or 'packed' in sv or conv.kernel is None or conv.padded or not conv.kernel.trainable:
+    if sv is not None and 'packed' in sv:
+        # the stem: its weight gradient is the only consumer (no data gradient); simclr_stem_wgrad_ps covers the 7x7 / stride-2 stem
+        pk = sv['packed']
+        return (conv.kernel is not None and conv.kernel.trainable and conv.cout_p == conv.filters
+                and ops.stem_wgrad_ps_supported(pk.geo, conv.kernel_size, conv.strides, conv.cout_p))
+    if sv is None or conv.kernel is None or conv.padded or not conv.kernel.trainable:
         return False
     return conv.cin_p % 64 == 0 and conv.cout_p % 32 == 0 and ops.ps_backward_enabled()
 
@@ -1118,7 +1123,8 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
                 self.stem_bn.saved = None
             else:
                 d = ops.maxpool_bwd(d, self._pool['arg'], self._pool['H'], self._pool['W'], 3, 2)
-                draw, _ = self.stem_bn.backward(d, mask_mode=2)      # ReLU mask recomputed from x*scale+shift
+                # ReLU mask recomputed from x*scale+shift; the gradient goes to the stem's weight gradient only: pre-split where it takes it
+                draw, _ = self.stem_bn.backward(d, mask_mode=2, ps_for=self.stem_conv)
             self._pool = None
         else:
             draw, _ = self.stem_bn.backward(d)

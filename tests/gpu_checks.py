@@ -368,9 +368,21 @@ def _check_stem(V, H, k, stride, Cout, dtype, seed, matmul):
     y_ref = yr.detach().permute(0, 2, 3, 1)
     bwd_scale = 2.0 if matmul in ('bf16x3', 'bf16x6_3', 'f16x3_3') else 1.0          # three-term backward arithmetic: ~2^-17 per product
     fwd_scale = 4.0 if matmul == 'bf16x3' else 1.0
-    return [_res('stem_fwd ' + tag, y, y_ref, t * fwd_scale),
-            _res('stem_stats_sq ' + tag, sums[1], (y_ref ** 2).sum((0, 1, 2)), 1e-4),
-            _res('stem_wgrad ' + tag, dw, wr.grad, (2e-5 if dtype == torch.float32 else 1e-4) * bwd_scale)]
+    res = [_res('stem_fwd ' + tag, y, y_ref, t * fwd_scale),
+           _res('stem_stats_sq ' + tag, sums[1], (y_ref ** 2).sum((0, 1, 2)), 1e-4),
+           _res('stem_wgrad ' + tag, dw, wr.grad, (2e-5 if dtype == torch.float32 else 1e-4) * bwd_scale)]
+    if dtype == torch.float32 and ops.stem_wgrad_ps_supported(geo, k, stride, Cout):
+        # the same weight gradient from pre-split operands (simclr_stem_wgrad_ps: image pieces per packed pixel, gradient in the block
+        # format): the pieces are the three-term operands, so the float64 bar of the in-register split applies
+        dw_ps = ops.stem_conv_wgrad(xp, ps_encode(dy.to(DEV)), geo, k, k, stride)
+        xq = ops.presplit_packed(xp)
+        raw = xq.view(torch.int16).view(torch.bfloat16).reshape(-1, 8).float().cpu()
+        xf = xp.reshape(-1, 4).cpu()
+        torch.cuda.synchronize()
+        res += [_res('stem_wgrad_presplit ' + tag, dw_ps, wr.grad, 2e-5 * bwd_scale),
+                _res('stem_xq_hi ' + tag, raw[:, :4], xf.bfloat16().float(), 0.0),
+                _res('stem_xq_lo ' + tag, raw[:, 4:], (xf - xf.bfloat16().float()).bfloat16().float(), 0.0)]
+    return res
 
 
 # ------------------------------------------------------------------ BN
@@ -884,6 +896,20 @@ def ps_decode(t, kind='b16'):
     lo[:, :, ch.reshape(-1)] = pieces[:, :, 4:].reshape(raw.shape[0], C // 32, 32)
     shp = tuple(t.shape)
     return (hi + lo).reshape(shp), hi.reshape(shp), lo.reshape(shp)
+
+
+def ps_encode(t):
+    """float32 [..., C] (C % 32 == 0) -> the pre-split block format with bf16 pieces (the inverse of ps_decode; hi = bf16(x) to nearest
+    even, lo = bf16(x - hi)), tagged `_ps` like the tensors simclr_bn_bwd_apply writes."""
+    C = t.shape[-1]
+    x = t.detach().float().cpu().reshape(-1, C // 32, 32)
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    ch = torch.tensor([[4 * g + i if i < 4 else 16 + 4 * g + i - 4 for i in range(8)] for g in range(4)]).reshape(-1)
+    blk = torch.cat([hi[:, :, ch], lo[:, :, ch]], dim=2).contiguous()           # [rows, blocks, 64 pieces] = 128 bytes
+    out = blk.view(torch.int16).view(torch.float32).reshape(t.shape).contiguous().to(t.device)
+    out._ps = 'b16'
+    return out
 
 
 def check_ps_backward(V, H, Cin, Cout, k, stride, seed=0, matmul='bf16x3'):
