@@ -2379,16 +2379,17 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ sla
 }
 
 // pivot[n] = the convolution output at output pixel (image 0, OH / 2, OW / 2) -- an interior pixel, so that every tap of a
-// padded 3x3 convolution contributes -- for the fp32 forward's pivoted statistics (ConvP::pivot).  One wave per output
-// channel, lanes stride the K = KH * KW * Cin reduction (w_t rows are K-contiguous: coalesced), fixed-order combine.
+// padded 3x3 convolution contributes -- for the fp32 forward's pivoted statistics (ConvP::pivot).  One workgroup per output
+// channel, its 256 threads stride the K = KH * KW * Cin reduction (w_t rows are K-contiguous: coalesced; 18 dependent iterations
+// for the 3x3 x 512 layers instead of the 72 of a single wave), fixed-order combine.
 __global__ __launch_bounds__(256) void conv_pivot_row(const float* __restrict__ x, const float* __restrict__ w_t, float* __restrict__ pivot,
                                                       int IH, int IW, int Cin, int pixpitch, int OH, int OW, int Cout, int KH, int KW,
                                                       int stride, int pad) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= Cout) return;
+  __shared__ float red[4];
+  const int n = blockIdx.x, lane = threadIdx.x & 63;
   const int oy = OH / 2, ox = OW / 2, K = KH * KW * Cin;
   float a = 0.f;
-  for (int k = lane; k < K; k += 64) {
+  for (int k = threadIdx.x; k < K; k += 256) {
     const int tap = k / Cin, ci = k - tap * Cin;
     const int iy = oy * stride - pad + tap / KW, ix = ox * stride - pad + tap % KW;
     if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
@@ -2396,7 +2397,9 @@ __global__ __launch_bounds__(256) void conv_pivot_row(const float* __restrict__ 
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
-  if (lane == 0) pivot[n] = a;
+  if (lane == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) pivot[n] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // Pre-split copy of an fp32 matrix [rows][K] (K a multiple of 32) for the three-term split-bf16 product (PSB / PSA
@@ -3601,7 +3604,7 @@ int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* st
   const bool persistent = Cout <= 64 * 64 && !getenv("SIMCLR_NO_GLDS") && !getenv("SIMCLR_NO_PERSISTENT");
   if (persistent) {
     if (!dry_run())
-      hipLaunchKernelGGL(conv_pivot_row, dim3(ceil_div(Cout, 4)), dim3(256), 0, stream, (const float*)x, (const float*)w_t, pivot,
+      hipLaunchKernelGGL(conv_pivot_row, dim3(Cout), dim3(256), 0, stream, (const float*)x, (const float*)w_t, pivot,
                          IH, IW, Cin, Cin, OH, OW, Cout, KH, KW, stride, pad);
     p.pivot = pivot;
   } else if (!dry_run()) {

@@ -181,6 +181,42 @@ __device__ __forceinline__ void maxpool_gather(const T* __restrict__ dy, const u
 #pragma unroll
   for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
   const int ty = iy + pad_t, tx = ix + pad_l;
+  if (ksz == 3 && stride == 2) {
+    // the stem pool, as in maxpool_bwd: the (at most) 2 x 2 windows are requested back to back from clamped addresses and the
+    // invalid ones masked afterwards; same windows, same order of additions as the loop below
+    const int oy1 = ty >> 1, ox1 = tx >> 1;
+    const int oys[2] = {oy1, oy1 - 1}, oxs[2] = {ox1, ox1 - 1};
+    const bool vy[2] = {oy1 <= OH - 1, oy1 >= 1 && oy1 - 1 <= OH - 1 && (ty & 1) == 0};
+    const bool vx[2] = {ox1 <= OW - 1, ox1 >= 1 && ox1 - 1 <= OW - 1 && (tx & 1) == 0};
+    u32x4 dv[4];
+    uint32_t av[4][EPC / 4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = min(max(oys[a], 0), OH - 1), ox = min(max(oxs[b], 0), OW - 1);
+        const long long op = (((long long)v * OH + oy) * OW + ox) * C + c0;
+        dv[a * 2 + b] = *(const u32x4*)(dy + op);
+        const uint32_t* ap = (const uint32_t*)(arg + op);
+#pragma unroll
+        for (int q = 0; q < EPC / 4; ++q) av[a * 2 + b][q] = ap[q];
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool ok = vy[a] && vx[b];
+        const uint32_t tapid = (uint32_t)((ty - oys[a] * 2) * 3 + (tx - oxs[b] * 2));
+        float d[EPC];
+        chunk_to_f32<T>(dv[a * 2 + b], d);
+#pragma unroll
+        for (int q = 0; q < EPC / 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ok && ((av[a * 2 + b][q] >> (8 * e)) & 0xffu) == tapid) acc[4 * q + e] += d[4 * q + e];
+      }
+    return;
+  }
   const int oy_hi = min(OH - 1, ty / stride), ox_hi = min(OW - 1, tx / stride);
   const int oy_lo = max(0, (ty - ksz + stride) / stride), ox_lo = max(0, (tx - ksz + stride) / stride);
   for (int oy = oy_hi; oy >= oy_lo; --oy) {
@@ -227,8 +263,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool(
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
     for (long long r = r0 + trow; r < r1; r += rl) {
-      const unsigned row = (unsigned)(r / W);
-      const int ix = (int)(r - (long long)row * W), v = (int)(row / (unsigned)H), iy = (int)(row - (unsigned)v * H);
+      const unsigned ru = (unsigned)r;                       // V*H*W < 2^31 (checked by the host): 32-bit divisions
+      const unsigned row = ru / (unsigned)W;
+      const int ix = (int)(ru - row * (unsigned)W), v = (int)(row / (unsigned)H), iy = (int)(row - (unsigned)v * H);
       float d[EPC], xf[EPC];
       maxpool_gather<T>(dy, arg, v, iy, ix, c0, C, OH, OW, ksz, stride, pad_t, pad_l, d);
       chunk_to_f32<T>(*(const u32x4*)(x + r * C + c0), xf);
@@ -262,17 +299,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool(
 }
 
 // ... and the APPLY: dx = scale * (dm - c1 - x^ * c2), dm gathered / masked as above
-template <typename T>
+// PSO (fp32, C % 32 == 0): dx in the pre-split block format with bf16 pieces (common.h) -- its only consumer is the stem's weight gradient
+template <typename T, bool PSO = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_pool(
     const T* __restrict__ dy, const uint8_t* __restrict__ arg, const T* __restrict__ x, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ c1, const float* __restrict__ c2, T* __restrict__ dx, int V, int H, int W, int C, int OH,
     int OW, int ksz, int stride, int pad_t, int pad_l) {
   constexpr int EPC = Elem<T>::EPC;
+  static_assert(!PSO || sizeof(T) == 4, "pre-split output: fp32 storage");
   const int cpr = C / EPC;
+  const bool pow2 = (cpr & (cpr - 1)) == 0;
+  const int cshift = __ffs(cpr) - 1;
   const long long total = (long long)V * H * W * cpr;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256ll) {
-    const unsigned pix = (unsigned)(i / cpr);
+    const unsigned pix = pow2 ? (unsigned)(i >> cshift) : (unsigned)(i / cpr);
     const int c0 = (int)(i - (long long)pix * cpr) * EPC;
     const unsigned row = pix / (unsigned)W;
     const int ix = (int)(pix - row * W), v = (int)(row / (unsigned)H), iy = (int)(row - (unsigned)v * H);
@@ -286,7 +327,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool(
       const float xh = (xf[e] - mean[c0 + e]) * rstd[c0 + e];
       o[e] = sc * (dm - c1[c0 + e] - xh * c2[c0 + e]);
     }
-    *(u32x4*)(dx + (long long)pix * C + c0) = f32_to_chunk<T>(o);
+    if constexpr (PSO) ps_store_quad<false>(dx, i, o);           // quad i = channels c0 .. c0 + 3 of pixel pix
+    else *(u32x4*)(dx + (long long)pix * C + c0) = f32_to_chunk<T>(o);
   }
 }
 
@@ -807,10 +849,20 @@ int simclr_bn_bwd_apply_pool(const void* dy, const unsigned char* arg, const voi
                              const float* shift, const float* mean, const float* rstd, const float* c1, const float* c2,
                              void* dx, int V, int H, int W, int C, int OH, int OW, int ksz, int stride, int pad_t, int pad_l,
                              int dtype, hipStream_t stream) {
+  // dtype | SIMCLR_FMT_PS_OUT (fp32, C a multiple of 32): dx in the pre-split block format with bf16 pieces
+  const bool ps_out = (dtype & SIMCLR_FMT_PS_OUT) != 0;
+  dtype &= 0xff;
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(C % epc == 0, "bn_bwd_apply_pool: C %% %d != 0", epc);
+  SIMCLR_CHECK_ARG(!ps_out || (dtype == SIMCLR_DT_F32 && C % 32 == 0), "bn_bwd_apply_pool: the pre-split output needs fp32 storage and C %% 32 == 0 (C=%d)", C);
   SIMCLR_CHECK_ARG((long long)V * H * W < (1ll << 31), "bn_bwd_apply_pool: pixel count overflows int32");
   const long long total = (long long)V * H * W * (C / epc);
+  if (ps_out) {
+    hipLaunchKernelGGL((bn_bwd_apply_pool<float, true>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)dy, arg,
+                       (const float*)x, scale, shift, mean, rstd, c1, c2, (float*)dx, V, H, W, C, OH, OW, ksz, stride, pad_t, pad_l);
+    SIMCLR_CHECK_LAUNCH();
+    return 0;
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((bn_bwd_apply_pool<uint16_t>), dim3(grid_for(total)), dim3(256), 0, stream, (const uint16_t*)dy,
                                 arg, (const uint16_t*)x, scale, shift, mean, rstd, c1, c2, (uint16_t*)dx, V, H, W, C, OH, OW,

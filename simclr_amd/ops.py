@@ -921,14 +921,17 @@ def bn_bwd_reduce_pool(dy, arg, x, scale, shift, mean, rstd, ksz=3, stride=2):
     return partial
 
 
-def bn_bwd_apply_pool(dy, arg, x, scale, shift, mean, rstd, c1, c2, ksz=3, stride=2):
+def bn_bwd_apply_pool(dy, arg, x, scale, shift, mean, rstd, c1, c2, ksz=3, stride=2, ps_out=False):
+    """ps_out (fp32, C % 32 == 0): dx in the pre-split block format with bf16 pieces (tagged `_ps`), for the stem's weight gradient."""
     V, H, W, C = x.shape
     _, OH, OW, _ = dy.shape
     _, pt = same_pad(H, ksz, stride)
     _, pl = same_pad(W, ksz, stride)
     dx = torch.empty_like(x)
     lib().bn_bwd_apply_pool(_p(dy), _p(arg), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(c1), _p(c2), _p(dx), V, H,
-                            W, C, OH, OW, ksz, stride, pt, pl, dt(x), _s())
+                            W, C, OH, OW, ksz, stride, pt, pl, dt(x) | (FMT_PS_OUT if ps_out else 0), _s())
+    if ps_out:
+        dx._ps = 'b16'
     return dx
 
 

@@ -633,10 +633,15 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
 
 
 def _pool_fusion_enabled():
-    """Opt-in (SIMCLR_POOL_FUSION=1): measured 0.4 ms/step SLOWER than writing the un-pooled gradient once (77.4 vs 77.0 ms,
-    interleaved runs on one MI355X, profiles/r02_notes.md) -- the 4-window gather is recomputed in both passes."""
+    """Max-pool backward fused into the stem BatchNorm's backward (the un-pooled gradient is never written or re-read).  Default: on in
+    fp32 storage (round 6, with the four windows of a pixel requested up front: 3.28 against 3.94 ms for the three unfused kernels,
+    -0.8 ms per step in three interleaved pairs), off in bf16 (round 2: 0.4 ms per step slower, profiles/r02_notes.md);
+    SIMCLR_POOL_FUSION=0 | 1 overrides."""
     import os
-    return os.environ.get('SIMCLR_POOL_FUSION', '0') not in ('', '0')
+    e = os.environ.get('SIMCLR_POOL_FUSION')
+    if e is not None and e != '':
+        return e != '0'
+    return RT.dtype == torch.float32
 
 
 def _bn_s2_enabled():
@@ -1119,7 +1124,8 @@ class Resnet(Layer):  # tf2/resnet.py:529-699
                 # ([V,112,112,64], the largest tensor of the backward pass) is never written or re-read
                 part = ops.bn_bwd_reduce_pool(d, self._pool['arg'], sb['x'], sb['scale'], sb['shift'], sb['mean'], sb['rstd'])
                 c1, c2 = self.stem_bn._bwd_finalize(part, sb['count'])
-                draw = ops.bn_bwd_apply_pool(d, self._pool['arg'], sb['x'], sb['scale'], sb['shift'], sb['mean'], sb['rstd'], c1, c2)
+                draw = ops.bn_bwd_apply_pool(d, self._pool['arg'], sb['x'], sb['scale'], sb['shift'], sb['mean'], sb['rstd'], c1, c2,
+                                             ps_out=_ps_grad_ok(self.stem_conv))
                 self.stem_bn.saved = None
             else:
                 d = ops.maxpool_bwd(d, self._pool['arg'], self._pool['H'], self._pool['W'], 3, 2)

@@ -1663,8 +1663,17 @@ def check_pool_bn_bwd_fusion(V, H, C, dtype, seed=0):
     tag = 'V%d %d C%d %s' % (V, H, C, str(dtype).split('.')[-1])
     bf = dtype == torch.bfloat16
     # in bf16 the un-fused path rounds the un-pooled gradient to bf16 before summing; the fused one sums fp32 values
-    return [_res('poolfuse_dx ' + tag, dx, xr.grad, 1e-2 if bf else 5e-5),
-            _res('poolfuse_sums_vs_unfused ' + tag, ops.bn_reduce_slots(part), ops.bn_reduce_slots(part_un), 2e-3 if bf else 1e-5)]
+    res = [_res('poolfuse_dx ' + tag, dx, xr.grad, 1e-2 if bf else 5e-5),
+           _res('poolfuse_sums_vs_unfused ' + tag, ops.bn_reduce_slots(part), ops.bn_reduce_slots(part_un), 2e-3 if bf else 1e-5)]
+    if not bf and C % 32 == 0:
+        # pre-split output (the stem's weight gradient reads bf16 pieces): exactly bf16(dx) and bf16(dx - hi) of the plain output
+        dps = ops.bn_bwd_apply_pool(dy.to(DEV), arg, xd, scale, shift, mean_d, rstd_d, c1, c2, ps_out=True)
+        torch.cuda.synchronize()
+        _, hi, lo = ps_decode(dps)
+        want_hi = dx.cpu().bfloat16().float()
+        res += [_res('poolfuse_ps_hi ' + tag, hi, want_hi, 0.0),
+                _res('poolfuse_ps_lo ' + tag, lo, (dx.cpu() - want_hi).bfloat16().float(), 0.0)]
+    return res
 
 
 def check_small_gemm(M, N, K, seed=0):
