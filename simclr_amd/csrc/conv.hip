@@ -3080,10 +3080,16 @@ static bool igemm_use_wide(const ConvP& p, bool fwd) {
 // MFMA / staging of another and the store phase of a third overlap (the gathered operand is then re-read from L2 by N/64
 // workgroups instead of N/128 -- irrelevant for an HBM-bound layer).  Measured in the step: 66.49 / 66.33 vs 66.72 / 66.66 ms
 // (-0.3 ms, two interleaved pairs, profiles/r03_notes.md); K <= 64 alone and K <= 256 give 66.60 / 66.50.
-static bool igemm_narrow(const ConvP& p, size_t esz) {
+static bool igemm_narrow(const ConvP& p, size_t esz, bool dgrad = false) {
   // Round 5 (three interleaved runs each on one box, profiles/r05_notes.md section 8): K <= 64 only -- 63.19 -> 62.56 ms per step; the K = 128
   // layers (28^2 128 -> 512) are better off on the 128-wide tile now that its epilogues carry their options as compile-time constants.
   static const int kmax = getenv("SIMCLR_IGEMM_BN64_K") ? atoi(getenv("SIMCLR_IGEMM_BN64_K")) : 64;
+  // fp32 storage, three-term DATA GRADIENT launches (their 64-wide tiles run three per CU): K <= 128 (SIMCLR_IGEMM_BN64_K32).  Measured in
+  // the step, three interleaved triples on one box (r06_call23): data-gradient family 44.40 -> 43.63 ms (K <= 64: 43.93); the forward
+  // launches LOSE on the narrow tile (38.69 -> 39.77 ms) and keep 128 columns.
+  static const int kmax32 = getenv("SIMCLR_IGEMM_BN64_K32") ? atoi(getenv("SIMCLR_IGEMM_BN64_K32")) : 128;
+  if (esz == 4)
+    return dgrad && kmax32 > 0 && p.split == 3 && p.N > 64 && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.x2 && p.K <= kmax32 && p.N / 64 <= 64;
   return esz == 2 && p.N > 64 && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.x2 && p.K <= kmax && p.N / 64 <= 64;
 }
 
@@ -3236,7 +3242,7 @@ static const void* presplit_weights(const void* w, long long rows, int K, hipStr
 
 template <typename T, int MODE>
 void launch_igemm_one(ConvP p, hipStream_t stream) {
-  const bool narrow = igemm_narrow(p, sizeof(T));
+  const bool narrow = igemm_narrow(p, sizeof(T), MODE == MODE_DGRAD);
   const int BN = (p.N <= 64 || narrow) ? 64 : 128;
   p.m_tiles = ceil_div(p.M, 128);
   p.n_tiles = ceil_div(p.N, BN);
