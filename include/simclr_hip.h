@@ -274,6 +274,9 @@ int simclr_bn_bwd_apply(const void* dy, const void* x, const void* mask_src, con
 /* ---- view packing / pooling: tf2/model.py:250-259, tf2/resnet.py:602-611, :693-696 ------------- */
 int simclr_pack_views(const float* images, void* xp, int b, int H, int W, int k, int HP, int WP, int pad,
                       int dtype, simclr_stream_t stream);
+/* the same with the pre-split copy of the packed pixels (simclr_presplit_packed) written in the same pass; fp32 only */
+int simclr_pack_views_ps(const float* images, void* xp, void* xq, int b, int H, int W, int k, int HP, int WP, int pad,
+                         simclr_stream_t stream);
 int simclr_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y,
                               unsigned char* arg, int V, int H, int W, int C, int OH, int OW, int ksz,
                               int stride, int pad_t, int pad_l, int dtype, simclr_stream_t stream);

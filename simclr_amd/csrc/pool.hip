@@ -14,7 +14,7 @@ namespace {
 // images f32 [b][H][W][3k] -> xp T [k*b][HP][WP][4], interior at (pad, pad), zero elsewhere
 template <typename T>
 __global__ void pack_views(const float* __restrict__ img, T* __restrict__ xp, int b, int H, int W,
-                           int k, int HP, int WP, int pad) {
+                           int k, int HP, int WP, int pad, u32x4* __restrict__ xq = nullptr) {
   const long long total = (long long)k * b * HP * WP;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -30,6 +30,12 @@ __global__ void pack_views(const float* __restrict__ img, T* __restrict__ xp, in
     }
     if (sizeof(T) == 4) {
       *(float4*)((float*)xp + i * 4) = make_float4(c[0], c[1], c[2], c[3]);
+      if (xq) {            // the same pixel as (four bf16 hi pieces, four bf16 lo pieces): simclr_presplit_packed in the same pass
+        uint32_t h0, l0, h1, l1;
+        split_pair<false>(c[0], c[1], h0, l0);
+        split_pair<false>(c[2], c[3], h1, l1);
+        xq[i] = (u32x4){h0, h1, l0, l1};
+      }
     } else {
       u32x2 pk; pk[0] = pack_bf16x2(c[0], c[1]); pk[1] = pack_bf16x2(c[2], c[3]);
       *(u32x2*)((uint16_t*)xp + i * 4) = pk;
@@ -750,6 +756,17 @@ int simclr_pack_views(const float* images, void* xp, int b, int H, int W, int k,
                                 (uint16_t*)xp, b, H, W, k, HP, WP, pad),
              hipLaunchKernelGGL((pack_views<float>), dim3(grid_for(total)), dim3(256), 0, stream, images,
                                 (float*)xp, b, H, W, k, HP, WP, pad));
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// fp32 packed views AND their pre-split copy (simclr_presplit_packed) in one pass over the images
+int simclr_pack_views_ps(const float* images, void* xp, void* xq, int b, int H, int W, int k, int HP, int WP, int pad,
+                         hipStream_t stream) {
+  SIMCLR_CHECK_ARG(b > 0 && k > 0 && HP >= H + pad && WP >= W + pad && xp && xq, "pack_views_ps: bad geometry");
+  const long long total = (long long)k * b * HP * WP;
+  hipLaunchKernelGGL((pack_views<float>), dim3(grid_for(total)), dim3(256), 0, stream, images, (float*)xp, b, H, W, k, HP, WP, pad,
+                     (u32x4*)xq);
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

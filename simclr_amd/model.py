@@ -277,7 +277,10 @@ class Model(Layer):
             inputs = data_util.batch_random_blur_tensor(inputs, FLAGS.image_size, FLAGS.image_size)
         num_transforms = inputs.shape[3] // 3
         k, s = self.resnet_model.stem_kernel_stride
-        packed = PackedInput(inputs.contiguous(), num_transforms, k, s, RT.dtype)   # split + concat, :250-259
+        # (training: the 7x7 stem's weight gradient reads the image as bf16 pieces in the three-term modes -- written by the packing pass)
+        rm = self.resnet_model
+        ps_cout = rm.stem_conv.filters if (training and not rm.stem_pre and not rm.cifar_stem) else 0
+        packed = PackedInput(inputs.contiguous(), num_transforms, k, s, RT.dtype, presplit_for_cout=ps_cout)   # split + concat, :250-259
         hiddens = self.resnet_model(packed, training=training)                     # :262
         proj, sup_in = self._projection_head(hiddens, training)                    # :265-266
         self._proj_is_encoder = proj is hiddens

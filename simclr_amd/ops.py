@@ -397,10 +397,16 @@ def stem_geometry(H, W, KH, KW, stride):
     return dict(pad=pad, OH=OH, OW=OW, KHP=KHP, KWP=KWP, HP=HP, WP=WP)
 
 
-def pack_views(images, k, geo, dtype):
+def pack_views(images, k, geo, dtype, with_presplit=False):
+    """with_presplit (fp32): also returns presplit_packed(xp), written in the same pass -> (xp, xq)."""
     b, H, W, C = images.shape
     assert C == 3 * k and images.dtype == torch.float32
     xp = torch.empty(k * b, geo['HP'], geo['WP'], 4, device=images.device, dtype=dtype)
+    if with_presplit:
+        assert dtype == torch.float32
+        xq = torch.empty_like(xp)
+        lib().pack_views_ps(_p(images), _p(xp), _p(xq), b, H, W, k, geo['HP'], geo['WP'], geo['pad'], _s())
+        return xp, xq
     lib().pack_views(_p(images), _p(xp), b, H, W, k, geo['HP'], geo['WP'], geo['pad'], dt(xp), _s())
     return xp
 

@@ -133,11 +133,16 @@ class Act:
 class PackedInput:
     """The k views of the input batch, packed by simclr_pack_views for the stem conv."""
 
-    def __init__(self, images, num_views, kernel_size, strides, dtype):
+    def __init__(self, images, num_views, kernel_size, strides, dtype, presplit_for_cout=0):
         b, H, W, _ = images.shape
         self.geo = ops.stem_geometry(H, W, kernel_size, kernel_size, strides)
         self.H, self.W = H, W
-        self.xp = ops.pack_views(images, num_views, self.geo, dtype)
+        self.xq = None
+        if presplit_for_cout and dtype == torch.float32 and ops.stem_wgrad_ps_supported(self.geo, kernel_size, strides, presplit_for_cout):
+            # the stem's weight gradient reads the image as bf16 pieces (simclr_stem_wgrad_ps): written in the packing pass
+            self.xp, self.xq = ops.pack_views(images, num_views, self.geo, dtype, with_presplit=True)
+        else:
+            self.xp = ops.pack_views(images, num_views, self.geo, dtype)
         self.V = num_views * b
 
 
@@ -611,9 +616,9 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
                 pk = sv['packed']
                 with _wgrad_side_stream(pk.xp, dy):      # same stream as every other wgrad: they share one workspace
                     if self.cout_p == self.filters:
-                        ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, out=self.kernel.ensure_grad())
+                        ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, out=self.kernel.ensure_grad(), xq=pk.xq)
                     else:
-                        self._store_wgrad(ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s))
+                        self._store_wgrad(ops.stem_conv_wgrad(pk.xp, dy, pk.geo, k, k, s, xq=pk.xq))
             return None
         if train_w:
             with _wgrad_side_stream(sv['x'], dy):

@@ -376,12 +376,15 @@ def _check_stem(V, H, k, stride, Cout, dtype, seed, matmul):
         # format): the pieces are the three-term operands, so the float64 bar of the in-register split applies
         dw_ps = ops.stem_conv_wgrad(xp, ps_encode(dy.to(DEV)), geo, k, k, stride)
         xq = ops.presplit_packed(xp)
+        xp2, xq2 = ops.pack_views(img.to(DEV), 2, geo, dtype, with_presplit=True)      # the same two tensors from ONE pass over the images
         raw = xq.view(torch.int16).view(torch.bfloat16).reshape(-1, 8).float().cpu()
         xf = xp.reshape(-1, 4).cpu()
         torch.cuda.synchronize()
         res += [_res('stem_wgrad_presplit ' + tag, dw_ps, wr.grad, 2e-5 * bwd_scale),
                 _res('stem_xq_hi ' + tag, raw[:, :4], xf.bfloat16().float(), 0.0),
-                _res('stem_xq_lo ' + tag, raw[:, 4:], (xf - xf.bfloat16().float()).bfloat16().float(), 0.0)]
+                _res('stem_xq_lo ' + tag, raw[:, 4:], (xf - xf.bfloat16().float()).bfloat16().float(), 0.0),
+                _res('stem_pack_ps_xp ' + tag, xp2, xp, 0.0),
+                _res('stem_pack_ps_xq ' + tag, xq2.view(torch.int32).double(), xq.view(torch.int32).double(), 0.0)]
     return res
 
 
