@@ -27,7 +27,10 @@
  *                            (g < 4) = hi = bf16(x) of channels {4g..4g+3, 16+4g..16+4g+3}, chunk 4 + g =
  *                            lo = bf16(x - hi) of the same channels -- so that the three-term GEMMs read
  *                            their operand pieces without splitting anything in the k-loop;
- *       SIMCLR_FMT_PS_OUT    simclr_bn_bwd_apply writes dx in that format (channels % 32 == 0).
+ *       SIMCLR_FMT_PS_OUT    simclr_bn_bwd_apply / simclr_bn_bwd_apply_pool write dx in that format (channels % 32 == 0);
+ *       SIMCLR_FMT_PS_W      the WEIGHT operand of simclr_conv2d_fwd / _fwd_pivoted / _fwd_bn_apply (terms 13) or of
+ *                            simclr_conv2d_dgrad / _dgrad_bn (terms 3) is the pre-split copy simclr_presplit_weights_multi
+ *                            made of it (once per optimizer step instead of once per launch inside the library).
  */
 #ifndef SIMCLR_HIP_H_
 #define SIMCLR_HIP_H_
@@ -43,6 +46,7 @@ extern "C" {
 #define SIMCLR_FMT_PS_IN 0x100
 #define SIMCLR_FMT_PS_OUT 0x200
 #define SIMCLR_FMT_TERMS(t) (((t) + 1) << 12)
+#define SIMCLR_FMT_PS_W 0x100000
 
 typedef struct ihipStream_t* simclr_stream_t; /* == hipStream_t */
 
@@ -231,6 +235,11 @@ int simclr_unpack_stem_dw(const float* src, float* dst, int KH, int KW, int Cin,
    simclr_stem_wgrad_ps_workspace_bytes.  Only the 7x7 / stride-2 stem with 64 output channels (simclr_stem_wgrad_ps_supported);
    every other stem keeps simclr_conv2d_wgrad on the packed input. */
 int simclr_presplit_packed(const void* xp, void* xq, long long npix, simclr_stream_t stream);
+/* Pre-split copies of n compute-weight matrices in ONE launch (what the three-term forward / data-gradient launches otherwise make of
+   their weight operand per call): table [n][4] int64 on the device = (source fp32 [rows][K], K % 32 == 0; destination, same size;
+   128-byte k-blocks = rows * K / 32; pieces: 0 = bf16 -- a data-gradient call's w_d --, 1 = fp16 of 2^8 * w -- a forward call's w_t);
+   max_blocks = the largest block count in the table.  Pass the destination as the weight argument together with SIMCLR_FMT_PS_W. */
+int simclr_presplit_weights_multi(const long long* table, int n, long long max_blocks, simclr_stream_t stream);
 int simclr_stem_wgrad_ps_supported(int KH, int KWP, int stride, int Cout);
 size_t simclr_stem_wgrad_ps_workspace_bytes(int V, int OH, int OW, int KH);
 int simclr_stem_wgrad_ps(const void* xq, const void* dy_ps, float* dw_kn, int accumulate, void* workspace, int V, int HP,

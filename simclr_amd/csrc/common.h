@@ -81,6 +81,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #define SIMCLR_FMT_PS_OUT 0x200   // dtype flag: the output tensor is written pre-split
 #define SIMCLR_FMT_PS_F16 0x400   // the pieces are fp16 (default: bf16)
 #define SIMCLR_FMT_PS_IN2 0x800   // the second tensor operand (wgrad: x; bn_apply: res) is pre-split
+#define SIMCLR_FMT_PS_W 0x100000  // the WEIGHT operand of a forward / data-gradient call is the caller's pre-split copy (simclr_presplit_weights_multi)
 typedef _Float16 hw_f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
   const hw_f32x2_t v = {lo, hi};

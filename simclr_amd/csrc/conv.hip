@@ -87,6 +87,8 @@ struct ConvP {
   float* part_ws;
   unsigned* part_flags;
   unsigned* part_err;
+  int w_ps;          // fp32, three-term launches: p.w is ALREADY the pre-split copy (SIMCLR_FMT_PS_W: simclr_presplit_weights_multi wrote it
+                     // once per optimizer step) -> no per-launch presplit_rows
   int x_ps;          // fp32 dgrad, three bf16 terms: the gathered tensor p.x (the upstream gradient) is in the pre-split block format
                      // (common.h; written by simclr_bn_bwd_apply with SIMCLR_FMT_PS_OUT) -> PSX instantiation, no splitting in the k-loop
   unsigned x_bytes;  // conv_igemm_wide: size of the gathered tensor in bytes (range check of its buffer descriptor)
@@ -2384,7 +2386,9 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ sla
 // for the 3x3 x 512 layers instead of the 72 of a single wave), fixed-order combine.
 __global__ __launch_bounds__(256) void conv_pivot_row(const float* __restrict__ x, const float* __restrict__ w_t, float* __restrict__ pivot,
                                                       int IH, int IW, int Cin, int pixpitch, int OH, int OW, int Cout, int KH, int KW,
-                                                      int stride, int pad) {
+                                                      int stride, int pad, int w_ps) {
+  // w_ps: w_t is the pre-split forward copy (fp16 pieces of 2^8 * w per 128-byte k-block, see presplit_rows): element k of a row =
+  // (hi + lo) * 2^-8 -- the pivot only has to be NEAR the channel mean, any finite value gives the same statistics
   __shared__ float red[4];
   const int n = blockIdx.x, lane = threadIdx.x & 63;
   const int oy = OH / 2, ox = OW / 2, K = KH * KW * Cin;
@@ -2392,8 +2396,17 @@ __global__ __launch_bounds__(256) void conv_pivot_row(const float* __restrict__ 
   for (int k = threadIdx.x; k < K; k += 256) {
     const int tap = k / Cin, ci = k - tap * Cin;
     const int iy = oy * stride - pad + tap / KW, ix = ox * stride - pad + tap % KW;
-    if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
-      a = fmaf(x[((long long)iy * IW + ix) * pixpitch + ci], w_t[(long long)n * K + k], a);
+    if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) {
+      float wv;
+      if (w_ps) {
+        const int within = k & 31, c16 = within >> 2, e = within & 3;
+        const _Float16* blk = (const _Float16*)(w_t + (long long)n * K + (k & ~31)) + (c16 & 3) * 8 + (c16 >> 2) * 4 + e;
+        wv = ((float)blk[0] + (float)blk[32]) * (1.0f / (float)(1 << F16_WSCALE_LOG2));
+      } else {
+        wv = w_t[(long long)n * K + k];
+      }
+      a = fmaf(x[((long long)iy * IW + ix) * pixpitch + ci], wv, a);
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
@@ -2936,6 +2949,29 @@ __global__ __launch_bounds__(128, 2) void stem_wgrad_ps(const StemWgP p) {
   }
 }
 
+// presplit_rows for many matrices in one launch (blockIdx.y = matrix): table [n][4] = (src, dst, 128-byte blocks, fp16 pieces?)
+__global__ __launch_bounds__(256) void presplit_rows_multi(const long long* __restrict__ table, float f16_scale) {
+  const long long* e = table + 4ll * blockIdx.y;
+  const float* __restrict__ src = (const float*)e[0];
+  uint32_t* __restrict__ dst = (uint32_t*)e[1];
+  const long long nchunks = e[2] * 8;
+  const bool f16 = e[3] != 0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256ll) {
+    const long long blk = i >> 3;
+    const int c = (int)(i & 7), gq = c & 3;
+    u32x4 c0 = *(const u32x4*)(src + blk * 32 + gq * 4), c1 = *(const u32x4*)(src + blk * 32 + 16 + gq * 4);
+    u32x4 hi, lo;
+    if (f16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { c0[q] = __float_as_uint(__uint_as_float(c0[q]) * f16_scale); c1[q] = __float_as_uint(__uint_as_float(c1[q]) * f16_scale); }
+      split_terms2_f16(c0, c1, hi, lo);
+    } else {
+      split_terms2(c0, c1, hi, lo);
+    }
+    *(u32x4*)(dst + i * 4) = (c < 4) ? hi : lo;
+  }
+}
+
 // packed image [npix][4] fp32 -> [npix] x (four bf16 hi pieces, four bf16 lo pieces): the image operand of stem_wgrad_ps
 __global__ __launch_bounds__(256) void presplit_packed(const float4* __restrict__ src, u32x4* __restrict__ dst, long long npix) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < npix; i += (long long)gridDim.x * 256ll) {
@@ -2973,6 +3009,14 @@ static int terms_of(int* dtype, bool fwd) {
   *dtype &= ~(0xff << 12);
   if (f == 0) return fwd ? g_f32_terms_fwd : g_f32_terms_bwd;
   return valid_terms(f - 1, fwd) ? f - 1 : -1;
+}
+
+// dtype | SIMCLR_FMT_PS_W (fp32 storage): the weight operand of this call is the pre-split copy simclr_presplit_weights(_multi) made of it --
+// fp16 pieces of 2^8 * w for a forward call (terms 13), bf16 pieces for a data-gradient call (terms 3).  Strips the flag.
+static bool take_ps_w(int* dtype) {
+  const bool f = (*dtype & SIMCLR_FMT_PS_W) != 0;
+  *dtype &= ~SIMCLR_FMT_PS_W;
+  return f;
 }
 
 // ---- which instantiation ran: ONE place that records every forward / dgrad launch decision ----------
@@ -3343,18 +3387,25 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     if constexpr (sizeof(T) == 4 && MODE == MODE_DGRAD) {
       g_last_presplit = 0;
       if (p.split == 3) {
-        const void* ws = presplit_weights(p.w, p.N, p.K, stream);
-        if (ws) { p.w = ws; psb = true; g_last_presplit = 1; }
+        if (p.w_ps) { psb = true; g_last_presplit = 1; }
+        else {
+          const void* ws = presplit_weights(p.w, p.N, p.K, stream);
+          if (ws) { p.w = ws; psb = true; g_last_presplit = 1; }
+        }
       }
     }
     if (p.x_ps && !psb) { g_igemm_fail = 1; return; }      // a pre-split operand cannot be read as floats: refuse (the entry point reports it)
     // split-fp16 forward (13): fp16 weight planes times 2^F16_WSCALE_LOG2, once per launch; no scratch -> six bf16 terms
     if constexpr (sizeof(T) == 4 && MODE == MODE_FWD) {
       if (p.split == 13) {
-        const void* ws = presplit_weights(p.w, p.N, p.K, stream, true);
-        if (ws) { p.w = ws; psb = true; } else p.split = 6;
+        if (p.w_ps) psb = true;
+        else {
+          const void* ws = presplit_weights(p.w, p.N, p.K, stream, true);
+          if (ws) { p.w = ws; psb = true; } else p.split = 6;
+        }
       }
     }
+    if (p.w_ps && !psb) { g_igemm_fail = 1; return; }      // pre-split weights on a launch that would read them as floats (other terms): refuse
     // fused BatchNorm-backward-reduce epilogue with its mask mode / accumulate flag compiled in (EPS instantiations, bf16):
     // 1 = (mode 2, store), 3 = (mode 4, store), 4 = (mode 4, accumulate); SIMCLR_BNEPI_SPECIAL=0 (read per launch) = generic
     int eps = 0;
@@ -3453,7 +3504,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
 #undef LPE
     return;
   }
-  if (p.x_ps) { g_igemm_fail = 1; return; }
+  if (p.x_ps || (p.w_ps && p.ntaps > 0)) { g_igemm_fail = 1; return; }
 #define L(BNv, STv)                                                                                    \
   do {                                                                                                 \
     if (no_glds) SIMCLR_LAUNCH((conv_igemm<T, MODE, BNv, STv, false>), dim3(grid), dim3(256), lds, stream, p); \
@@ -3557,6 +3608,8 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
                       int pad, int dtype, hipStream_t stream) {
   const int terms = terms_of(&dtype, true);
   SIMCLR_CHECK_ARG(terms >= 0, "conv2d_fwd: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
+  const bool w_ps = take_ps_w(&dtype);
+  SIMCLR_CHECK_ARG(!w_ps || ((dtype & 0xff) == SIMCLR_DT_F32 && terms == 13), "conv2d_fwd: pre-split weights (SIMCLR_FMT_PS_W) need fp32 storage and terms 13");
   const int epc = dtype == SIMCLR_DT_BF16 ? 8 : 4;
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_fwd: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cin % (8 * epc) == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 8 * epc);
@@ -3567,6 +3620,7 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd: at most 9 taps (got %dx%d)", KH, KW);
   SIMCLR_CHECK_ARG(y || (stats && dtype == SIMCLR_DT_BF16), "conv2d_fwd: y == NULL (statistics-only pass) needs stats and bf16");
   ConvP p = {};
+  p.w_ps = w_ps ? 1 : 0;
   p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
@@ -3574,8 +3628,10 @@ int simclr_conv2d_fwd(const void* x, const void* w_t, void* y, float* stats, int
   p.V = V; p.IH = IH; p.IW = IW; p.IC = Cin; p.OH = OH; p.OW = OW; p.N = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pixpitch = Cin;
   p.M = V * OH * OW; p.K = KH * KW * Cin;
+  g_igemm_fail = 0;
   if (dtype == SIMCLR_DT_BF16) launch_igemm<uint16_t, MODE_FWD>(p, stream);
   else launch_igemm<float, MODE_FWD>(p, stream);
+  SIMCLR_CHECK_ARG(!g_igemm_fail, "conv2d_fwd: no kernel reads pre-split weights on this launch path");
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -3591,6 +3647,8 @@ int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* st
                               int pad, int dtype, hipStream_t stream) {
   const int terms = terms_of(&dtype, true);
   SIMCLR_CHECK_ARG(terms >= 0, "conv2d_fwd_pivoted: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
+  const bool w_ps = take_ps_w(&dtype);
+  SIMCLR_CHECK_ARG(!w_ps || ((dtype & 0xff) == SIMCLR_DT_F32 && terms == 13), "conv2d_fwd_pivoted: pre-split weights (SIMCLR_FMT_PS_W) need fp32 storage and terms 13");
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_F32, "conv2d_fwd_pivoted: fp32 only (dtype %d)", dtype);
   SIMCLR_CHECK_ARG(Cin % 32 == 0, "conv2d_fwd_pivoted: Cin=%d must be a multiple of 32", Cin);
   SIMCLR_CHECK_ARG(Cout % 4 == 0, "conv2d_fwd_pivoted: Cout=%d must be a multiple of 4", Cout);
@@ -3599,6 +3657,7 @@ int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* st
   SIMCLR_CHECK_ARG(x && w_t && y && stats && pivot && nslot > 0, "conv2d_fwd_pivoted: null argument");
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd_pivoted: at most 9 taps (got %dx%d)", KH, KW);
   ConvP p = {};
+  p.w_ps = w_ps ? 1 : 0;
   p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
@@ -3611,12 +3670,14 @@ int simclr_conv2d_fwd_pivoted(const void* x, const void* w_t, void* y, float* st
   if (persistent) {
     if (!dry_run())
       hipLaunchKernelGGL(conv_pivot_row, dim3(Cout), dim3(256), 0, stream, (const float*)x, (const float*)w_t, pivot,
-                         IH, IW, Cin, Cin, OH, OW, Cout, KH, KW, stride, pad);
+                         IH, IW, Cin, Cin, OH, OW, Cout, KH, KW, stride, pad, p.w_ps);
     p.pivot = pivot;
   } else if (!dry_run()) {
     if (hipMemsetAsync(pivot, 0, (size_t)Cout * sizeof(float), stream) != hipSuccess) { simclr_set_error("conv2d_fwd_pivoted: memset failed"); return 2; }
   }
+  g_igemm_fail = 0;
   launch_igemm<float, MODE_FWD>(p, stream);
+  SIMCLR_CHECK_ARG(!g_igemm_fail, "conv2d_fwd_pivoted: no kernel reads pre-split weights on this launch path");
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -3635,6 +3696,8 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
                                hipStream_t stream) {
   const int terms = terms_of(&dtype, true);
   SIMCLR_CHECK_ARG(terms >= 0, "conv2d_fwd_bn_apply: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
+  const bool w_ps = take_ps_w(&dtype);
+  SIMCLR_CHECK_ARG(!w_ps || ((dtype & 0xff) == SIMCLR_DT_F32 && terms == 13), "conv2d_fwd_bn_apply: pre-split weights (SIMCLR_FMT_PS_W) need fp32 storage and terms 13");
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_fwd_bn_apply: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(Cin % (dtype == SIMCLR_DT_BF16 ? 64 : 32) == 0, "conv2d_fwd_bn_apply: Cin=%d must be a multiple of %d", Cin, dtype == SIMCLR_DT_BF16 ? 64 : 32);
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || (Cout <= 64 * 64 && !getenv("SIMCLR_NO_GLDS") && !getenv("SIMCLR_NO_PERSISTENT")),
@@ -3646,6 +3709,7 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   SIMCLR_CHECK_ARG((long long)V * OH * OW < (1ll << 31), "conv2d_fwd_bn_apply: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9, "conv2d_fwd_bn_apply: at most 9 taps (got %dx%d)", KH, KW);
   ConvP p = {};
+  p.w_ps = w_ps ? 1 : 0;
   (void)terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
@@ -3656,8 +3720,10 @@ int simclr_conv2d_fwd_bn_apply(const void* x, const void* w_t, void* y, const fl
   p.fapply = 1; p.bn_scale = scale; p.bn_shift = shift; p.bn_x = res; p.bn_mask = relu_bits; p.bn_mode = relu ? 1 : 0;
   p.bn_mean = rscale; p.bn_rstd = rshift;
   (void)terms;
+  g_igemm_fail = 0;
   if (dtype == SIMCLR_DT_F32) { p.split = terms; launch_igemm<float, MODE_FWD>(p, stream); }
   else launch_igemm<uint16_t, MODE_FWD>(p, stream);
+  SIMCLR_CHECK_ARG(!g_igemm_fail, "conv2d_fwd_bn_apply: no kernel reads pre-split weights on this launch path");
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }
@@ -3669,6 +3735,8 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
                         int dtype, hipStream_t stream) {
   const int terms = terms_of(&dtype, false);
   SIMCLR_CHECK_ARG(terms >= 0, "conv2d_dgrad: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
+  const bool w_ps = take_ps_w(&dtype);
+  SIMCLR_CHECK_ARG(!w_ps || ((dtype & 0xff) == SIMCLR_DT_F32 && terms == 3), "conv2d_dgrad: pre-split weights (SIMCLR_FMT_PS_W) need fp32 storage and terms 3");
   // dtype | SIMCLR_FMT_PS_IN (fp32, three bf16 backward terms, Cout a multiple of 32): dy is in the pre-split block format (common.h)
   const bool dy_ps = (dtype & SIMCLR_FMT_PS_IN) != 0;
   dtype &= 0xff;
@@ -3681,6 +3749,7 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9 && stride <= 2, "conv2d_dgrad: at most 9 taps and stride <= 2");
   ConvP p = {};
+  p.w_ps = w_ps ? 1 : 0;
   p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
@@ -3709,6 +3778,8 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
                            int stride, int pad, int dtype, hipStream_t stream) {
   const int terms = terms_of(&dtype, false);
   SIMCLR_CHECK_ARG(terms >= 0, "conv2d_dgrad_bn: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
+  const bool w_ps = take_ps_w(&dtype);
+  SIMCLR_CHECK_ARG(!w_ps || ((dtype & 0xff) == SIMCLR_DT_F32 && terms == 3), "conv2d_dgrad_bn: pre-split weights (SIMCLR_FMT_PS_W) need fp32 storage and terms 3");
   const bool dy_ps = (dtype & SIMCLR_FMT_PS_IN) != 0;          // see simclr_conv2d_dgrad
   dtype &= 0xff;
   SIMCLR_CHECK_ARG(!dy_ps || (dtype == SIMCLR_DT_F32 && terms == 3 && Cout % 32 == 0),
@@ -3724,6 +3795,7 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 / 3 / 4 need bn_mask");
   SIMCLR_CHECK_ARG(mask_mode != 2 || (bn_scale && bn_shift), "conv2d_dgrad_bn: mask_mode 2 needs scale/shift");
   ConvP p = {};
+  p.w_ps = w_ps ? 1 : 0;
   p.split = terms;
   p.zero = zero_page();
   SIMCLR_CHECK_ARG(p.zero != nullptr, "conv2d: zero page symbol not found");
@@ -4227,6 +4299,17 @@ int simclr_prep_weights_pair_multi(const long long* table, const long long* chun
     hipLaunchKernelGGL((prep_weights_pair_multi<uint16_t>), dim3(nchunks), dim3(256), 0, stream, table, chunks);
   else
     hipLaunchKernelGGL((prep_weights_pair_multi<float>), dim3(nchunks), dim3(256), 0, stream, table, chunks);
+  SIMCLR_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- pre-split weight copies, made once per optimizer step by the caller (SIMCLR_FMT_PS_W) ----
+// table [n][4] (device, int64): source fp32 matrix, destination, 128-byte k-blocks (rows * K / 32), pieces (0 = bf16: the data
+// gradient's copy of w_d; 1 = fp16 of 2^8 * w: the split-fp16 forward's copy of w_t).  One launch for all n matrices.
+int simclr_presplit_weights_multi(const long long* table, int n, long long max_blocks, hipStream_t stream) {
+  SIMCLR_CHECK_ARG(table && n > 0 && max_blocks > 0, "presplit_weights_multi: empty table");
+  const unsigned gx = (unsigned)min((max_blocks * 8 + 255) / 256, 4096ll);
+  hipLaunchKernelGGL(presplit_rows_multi, dim3(gx, n), dim3(256), 0, stream, table, (float)(1 << F16_WSCALE_LOG2));
   SIMCLR_CHECK_LAUNCH();
   return 0;
 }

@@ -71,7 +71,7 @@ def _p(t):
 
 # ---- pre-split block format (csrc/common.h): an fp32-typed tensor whose 128-byte blocks hold (hi, lo) 16-bit pieces -----------
 # Tensors in that format carry the Python attribute `_ps` ('b16' | 'f16'); only the operations that name it accept them (_pp).
-FMT_PS_IN, FMT_PS_OUT, FMT_PS_F16, FMT_PS_IN2 = 0x100, 0x200, 0x400, 0x800
+FMT_PS_IN, FMT_PS_OUT, FMT_PS_F16, FMT_PS_IN2, FMT_PS_W = 0x100, 0x200, 0x400, 0x800, 0x100000
 
 
 def ps_kind(t):
@@ -84,6 +84,15 @@ def _pp(t):
         return None
     assert t.is_cuda and t.is_contiguous(), 'need contiguous device tensor'
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _pw(w, fwd):
+    """(pointer, dtype flag) of a compute-weight operand: its pre-split copy (WeightPairBatch) with SIMCLR_FMT_PS_W when one exists for the
+    terms this call runs with, else the fp32 matrix itself."""
+    ps = getattr(w, '_psw', None)
+    if ps is not None and ps[1] == (_TERMS[0] if fwd else _TERMS[1]):
+        return ctypes.c_void_p(ps[0].data_ptr()), FMT_PS_W
+    return _p(w), 0
 
 
 def ps_backward_enabled():
@@ -234,6 +243,25 @@ class WeightPairBatch:
         self.table = torch.tensor(table, dtype=torch.int64).to(dev)
         self.chunks = torch.tensor(chunks, dtype=torch.int64).view(-1).to(dev)
         self.nchunks = len(chunks)
+        # fp32 storage, three-term modes: the pre-split copies the forward (fp16 pieces of 2^8 w_t) and the data gradient (bf16 pieces of
+        # w_d) would otherwise make per launch -- 120 launches of 5 us per ResNet-50 step -- written by ONE launch per refresh
+        # (simclr_presplit_weights_multi) and handed to the library with SIMCLR_FMT_PS_W.  SIMCLR_PS_W=0: per-launch copies as before.
+        import os
+        self.ps = None
+        if dtype == torch.float32 and os.environ.get('SIMCLR_PS_W', '1') not in ('', '0'):
+            rows_f, rows_b, self.ps_t, self.ps_d = [], [], [], []
+            for w_t, w_d in self.pairs:
+                ok = w_t.shape[1] % 32 == 0 and w_d.shape[1] % 32 == 0
+                pt = torch.empty_like(w_t) if ok else None
+                pd = torch.empty_like(w_d) if ok else None
+                self.ps_t.append(pt)
+                self.ps_d.append(pd)
+                if ok:
+                    rows_f += [w_t.data_ptr(), pt.data_ptr(), w_t.numel() // 32, 1]
+                    rows_b += [w_d.data_ptr(), pd.data_ptr(), w_d.numel() // 32, 0]
+            if rows_f:
+                self.ps = dict(f=torch.tensor(rows_f, dtype=torch.int64).to(dev), b=torch.tensor(rows_b, dtype=torch.int64).to(dev),
+                               n=len(rows_f) // 4, maxb=max(rows_f[2::4] + rows_b[2::4]))
 
     def matches(self, entries, dtype):
         return dtype == self.dtype and self.key == tuple(w.data_ptr() for w, _, _ in entries)
@@ -241,6 +269,15 @@ class WeightPairBatch:
     def run(self):
         lib().prep_weights_pair_multi(_p(self.table), _p(self.chunks), self.nchunks,
                                       DT_BF16 if self.dtype == torch.bfloat16 else DT_F32, _s())
+        if self.ps is not None:
+            fwd, bwd = _TERMS[0] == 13, _TERMS[1] == 3
+            if fwd:
+                lib().presplit_weights_multi(_p(self.ps['f']), self.ps['n'], self.ps['maxb'], _s())
+            if bwd:
+                lib().presplit_weights_multi(_p(self.ps['b']), self.ps['n'], self.ps['maxb'], _s())
+            for (w_t, w_d), pt, pd in zip(self.pairs, self.ps_t, self.ps_d):
+                w_t._psw = (pt, 13) if (fwd and pt is not None) else None
+                w_d._psw = (pd, 3) if (bwd and pd is not None) else None
         return self.pairs
 
 
@@ -255,9 +292,10 @@ def conv2d_fwd(x, w_t, KH, KW, stride, pad, OH, OW, stats=None, out=None, store=
         out = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
     M, K = V * OH * OW, KH * KW * Cin
     esz = x.element_size()
+    wp, wf = _pw(w_t, True)
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, esz * (V * IH * IW * Cin + (M * Cout if store else 0) + K * Cout),
-            lambda: lib().conv2d_fwd(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0] if stats is not None else 0, V,
-                                     IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x) | _tf(), _s()))
+            lambda: lib().conv2d_fwd(_p(x), wp, _p(out), _p(stats), stats.shape[0] if stats is not None else 0, V,
+                                     IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x) | _tf() | wf, _s()))
     return out
 
 
@@ -277,9 +315,10 @@ def conv2d_fwd_with_stats(x, w_t, KH, KW, stride, pad, OH, OW, stats):
     out = torch.empty(V, OH, OW, Cout, device=x.device, dtype=x.dtype)
     pivot = torch.empty(Cout, device=x.device, dtype=torch.float32)
     M, K = V * OH * OW, KH * KW * Cin
+    wp, wf = _pw(w_t, True)
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, 4 * (V * IH * IW * Cin + M * Cout + K * Cout),
-            lambda: lib().conv2d_fwd_pivoted(_p(x), _p(w_t), _p(out), _p(stats), stats.shape[0], _p(pivot), V, IH, IW, Cin, OH, OW,
-                                             Cout, KH, KW, stride, pad, dt(x) | _tf(), _s()))
+            lambda: lib().conv2d_fwd_pivoted(_p(x), wp, _p(out), _p(stats), stats.shape[0], _p(pivot), V, IH, IW, Cin, OH, OW,
+                                             Cout, KH, KW, stride, pad, dt(x) | _tf() | wf, _s()))
     sums = torch.empty(2, Cout, device=x.device, dtype=torch.float64)
     lib().bn_reduce_slots_pivoted(_p(stats), stats.shape[0], Cout, _p(pivot), float(M), _p(sums), _s())
     return out, None, sums
@@ -299,11 +338,12 @@ def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=N
     # algorithmic bytes = SURVEY 8(d)'s strict count (input + output + weights); the residual read and the mask write of
     # the fused epilogue (bn3's own traffic) are counted under impl_bytes only
     nb = esz * (V * IH * IW * Cin + M * Cout + K * Cout)
+    wp, wf = _pw(w_t, True)
     _launch('conv_igemm_fwd', 2.0 * M * K * Cout, nb,
             impl_bytes=nb + (esz * M * Cout if res is not None else 0) + (M * Cout // epc if want_bits else 0),
-            fn=lambda: lib().conv2d_fwd_bn_apply(_p(x), _p(w_t), _p(y), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift),
+            fn=lambda: lib().conv2d_fwd_bn_apply(_p(x), wp, _p(y), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift),
                                               int(relu), _p(bits), V,
-                                              IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x) | _tf(), _s()))
+                                              IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, dt(x) | _tf() | wf, _s()))
     return (y, bits) if want_bits else y
 
 
@@ -317,9 +357,10 @@ def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=Fals
     esz = dy.element_size()
     fmt = FMT_PS_IN if ps_kind(dy) else 0
     assert ps_kind(dy) in (None, 'b16')
+    wp, wf = _pw(w_d, False)
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + M * Cin + K * Cin),
-            lambda: lib().conv2d_dgrad(_pp(dy), _p(w_d), _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout,
-                                       KH, KW, stride, pad, dt(dy) | fmt | _tb(), _s()))
+            lambda: lib().conv2d_dgrad(_pp(dy), wp, _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout,
+                                       KH, KW, stride, pad, dt(dy) | fmt | _tb() | wf, _s()))
     return out
 
 
@@ -334,12 +375,13 @@ def conv2d_dgrad_bn(dy, w_d, KH, KW, pad, IH, IW, bn, out=None, accumulate=False
     partial = conv_stats(V * IH * IW, Cin, dy.device)
     K = KH * KW * Cout
     esz = dy.element_size()
+    wp, wf = _pw(w_d, False)
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + V * IH * IW * Cin + K * Cin),
             impl_bytes=esz * (V * OH * OW * Cout + (1 + (bn['mode'] != 4) + (bn['mode'] == 1) + int(accumulate)) * V * IH * IW * Cin + K * Cin),
-            fn=lambda: lib().conv2d_dgrad_bn(_pp(dy), _p(w_d), _p(out), int(accumulate), _p(bn.get('x')), _p(bn.get('mask')),
+            fn=lambda: lib().conv2d_dgrad_bn(_pp(dy), wp, _p(out), int(accumulate), _p(bn.get('x')), _p(bn.get('mask')),
                                           _p(bn.get('scale')), _p(bn.get('shift')), _p(bn.get('mean')), _p(bn.get('rstd')),
                                           bn['mode'], _p(partial), partial.shape[0], V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
-                                          pad, dt(dy) | (FMT_PS_IN if ps_kind(dy) else 0) | _tb(), _s()))
+                                          pad, dt(dy) | (FMT_PS_IN if ps_kind(dy) else 0) | _tb() | wf, _s()))
     return out, partial
 
 

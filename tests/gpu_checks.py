@@ -901,6 +901,45 @@ def ps_decode(t, kind='b16'):
     return (hi + lo).reshape(shp), hi.reshape(shp), lo.reshape(shp)
 
 
+def check_ps_weights(V, H, Cin, Cout, k, seed=0):
+    """Pre-split weight copies made once per refresh (ops.WeightPairBatch -> simclr_presplit_weights_multi, SIMCLR_FMT_PS_W) against the copies
+    the library makes per launch: same pieces, same kernels -- forward (with pivoted statistics), fused forward tail and data gradient must
+    agree BIT FOR BIT."""
+    ops.set_f32_matmul('f16x3_3')
+    try:
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        pad = (k - 1) // 2
+        w = torch.randn(k, k, Cin, Cout, device=DEV, generator=g) * (k * k * Cin) ** -0.5
+        batch = ops.WeightPairBatch([(w, 0, 0)], torch.float32)
+        (w_t, w_d), = batch.run()
+        assert ops.ps_kind(w_t) is None and w_t._psw is not None and w_t._psw[1] == 13 and w_d._psw[1] == 3
+        w_t0, w_d0 = w_t.clone(), w_d.clone()                         # untagged: the library splits them per launch
+        x = torch.randn(V, H, H, Cin, device=DEV, generator=g)
+        dy = torch.randn(V, H, H, Cout, device=DEV, generator=g)
+        M = V * H * H
+        y1, _, s1 = ops.conv2d_fwd_with_stats(x, w_t, k, k, 1, pad, H, H, ops.conv_stats(M, Cout, DEV))
+        y0, _, s0 = ops.conv2d_fwd_with_stats(x, w_t0, k, k, 1, pad, H, H, ops.conv_stats(M, Cout, DEV))
+        d1 = ops.conv2d_dgrad(dy, w_d, k, k, 1, pad, H, H)
+        d0 = ops.conv2d_dgrad(dy, w_d0, k, k, 1, pad, H, H)
+        sc, sh = torch.rand(Cout, device=DEV, generator=g) + 0.5, torch.randn(Cout, device=DEV, generator=g)
+        res = [_res('psw_fwd', y1, y0, 0.0), _res('psw_dgrad', d1, d0, 0.0),
+               # the pivot is decoded from the fp16 pieces (2^-22 off the fp32 weights): the raw moments agree to rounding, not bit for bit
+               _res('psw_fwd_sums', s1, s0, 5e-6)]
+        if k == 1:
+            f1 = ops.conv2d_fwd_bn_apply(x, w_t, 1, 1, 1, 0, H, H, sc, sh, res=y0, relu=True)
+            f0 = ops.conv2d_fwd_bn_apply(x, w_t0, 1, 1, 1, 0, H, H, sc, sh, res=y0, relu=True)
+            res.append(_res('psw_fwd_bn_apply', f1, f0, 0.0))
+        # a forward with other terms must not take the copy (an inference forward runs six bf16 terms)
+        ops.set_f32_matmul('bf16x6_3')
+        y6 = ops.conv2d_fwd(x, w_t, k, k, 1, pad, H, H)
+        y6_0 = ops.conv2d_fwd(x, w_t0, k, k, 1, pad, H, H)
+        torch.cuda.synchronize()
+        res.append(_res('psw_other_terms_fall_back', y6, y6_0, 0.0))
+        return res
+    finally:
+        ops.set_f32_matmul('exact')
+
+
 def ps_encode(t):
     """float32 [..., C] (C % 32 == 0) -> the pre-split block format with bf16 pieces (the inverse of ps_decode; hi = bf16(x) to nearest
     even, lo = bf16(x - hi)), tagged `_ps` like the tensors simclr_bn_bwd_apply writes."""

@@ -543,6 +543,12 @@ def test_stem_conv(V, H, k, s, dtype):
     _assert(gc.check_stem(V, H, k, s, 64, dtype))
 
 
+@pytest.mark.parametrize('V,H,Cin,Cout,k', [(8, 14, 256, 64, 1), (4, 14, 64, 128, 3), (8, 28, 64, 256, 1), (2, 7, 512, 512, 3)])
+def test_presplit_weight_copies_made_once_per_refresh(V, H, Cin, Cout, k):
+    from tests import gpu_checks as gc
+    _assert(gc.check_ps_weights(V, H, Cin, Cout, k))
+
+
 @pytest.mark.parametrize('matmul', ['bf16x3', 'f16x3_3'])
 def test_stem_conv_f32_rolling_fragments_over_many_tiles(matmul):
     """The unrolled 7x7 stem forward of the three-term modes (stem_conv_fwd<float, ., 14, 3 | 13>: weights pre-split in LDS, the activation
