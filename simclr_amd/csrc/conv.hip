@@ -1320,13 +1320,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
     for (int mi = 0; mi < MI; ++mi) {
       const int m = m0 + wm * (MI * 16) + mi * 16 + fl;
       long long off = -1;
+      // accumulate == 2: dx holds earlier data ONLY at the pixels with even row and even column (a stride-2 1x1 data gradient that
+      // skipped its empty pixel classes, accumulate == 3 there) -- the other three quarters are neither read nor zero-filled by anyone
+      bool prior = p.accumulate != 0;
       if (flat) {
         if (m < p.M) off = (long long)m * p.N;
+        if (p.accumulate == 2) {
+          const int rem = m % (p.OH * p.OW), iy = rem / p.OW, ix = rem - iy * p.OW;
+          prior = ((iy | ix) & 1) == 0;
+        }
       } else if (m < p.M) {
         const int v = m / cls_hw;
         const int rem = m - v * cls_hw;
         const int ca = rem / p.cls_w, cb = rem - ca * p.cls_w;
         off = (((long long)v * p.OH + ca * p.cs + p.py) * p.OW + cb * p.cs + p.px) * p.N;
+        if (p.accumulate == 2) prior = (((ca * p.cs + p.py) | (cb * p.cs + p.px)) & 1) == 0;
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -1350,7 +1358,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
             const float4 bi = *(const float4*)(bnp + 4 * BN + wn * 64 + ni * 16 + g * 4);
             v[0] += bi.x; v[1] += bi.y; v[2] += bi.z; v[3] += bi.w;
           }
-          if (p.accumulate) {
+          if (prior) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += Elem<T>::ld(dst + r);
           }
@@ -3504,7 +3512,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
 #undef LPE
     return;
   }
-  if (p.x_ps || (p.w_ps && p.ntaps > 0)) { g_igemm_fail = 1; return; }
+  if (p.x_ps || (p.w_ps && p.ntaps > 0) || p.accumulate == 2) { g_igemm_fail = 1; return; }
 #define L(BNv, STv)                                                                                    \
   do {                                                                                                 \
     if (no_glds) SIMCLR_LAUNCH((conv_igemm<T, MODE, BNv, STv, false>), dim3(grid), dim3(256), lds, stream, p); \
@@ -3557,7 +3565,11 @@ int launch_igemm(const ConvP& p0, hipStream_t stream) {
             q.taps[q.ntaps++] = ty * p.KW + tx;
           }
       q.M = p.V * q.cls_h * q.cls_w;
-      if (q.ntaps == 0 && p.accumulate) continue;   // nothing to add
+      // nothing to add (accumulate == 3: nothing to store, the class stays untouched; accumulate == 2: only a class of even pixels
+      // holds earlier data -- an empty class of other pixels has to be zero-filled like a plain store)
+      if (q.ntaps == 0 && p.accumulate == 2 && ((py | px) & 1)) q.accumulate = 0;
+      else if (q.ntaps == 0 && p.accumulate) continue;
+      if (p.accumulate == 3) q.accumulate = 0;      // sparse store: the classes with taps are plain stores
       if (q.ntaps == 0) q.x_ps = 0;                 // zero fill: the gathered tensor is not read at all
       launch_igemm_one<T, MODE>(q, stream);
     }
@@ -3748,6 +3760,11 @@ int simclr_conv2d_dgrad(const void* dy, const void* w_d, void* dx, int accumulat
   SIMCLR_CHECK_ARG(Cin % 4 == 0, "conv2d_dgrad: Cin=%d must be a multiple of 4", Cin);
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9 && stride <= 2, "conv2d_dgrad: at most 9 taps and stride <= 2");
+  // accumulate: 0 store | 1 dx += result | 2 (fp32) dx += result where dx holds earlier data only at even (row, column) pixels -- the
+  // output of a call with 3 | 3 (stride 2) store the pixel classes that receive a tap and leave the others UNTOUCHED (no zero fill)
+  SIMCLR_CHECK_ARG(accumulate >= 0 && accumulate <= 3, "conv2d_dgrad: accumulate must be 0 ... 3 (got %d)", accumulate);
+  SIMCLR_CHECK_ARG(accumulate != 2 || dtype == SIMCLR_DT_F32, "conv2d_dgrad: accumulate = 2 (sparse earlier data) is an fp32 path");
+  SIMCLR_CHECK_ARG(accumulate != 3 || stride == 2, "conv2d_dgrad: accumulate = 3 (sparse store) needs stride 2");
   ConvP p = {};
   p.w_ps = w_ps ? 1 : 0;
   p.split = terms;
@@ -3790,6 +3807,8 @@ int simclr_conv2d_dgrad_bn(const void* dy, const void* w_d, void* dx, int accumu
   SIMCLR_CHECK_ARG(Cin % 4 == 0, "conv2d_dgrad_bn: Cin=%d must be a multiple of 4", Cin);
   SIMCLR_CHECK_ARG((long long)V * IH * IW < (1ll << 31), "conv2d_dgrad_bn: M overflows int32");
   SIMCLR_CHECK_ARG(KH * KW <= 9 && stride == 1, "conv2d_dgrad_bn: stride-1 convolutions with <= 9 taps only");
+  SIMCLR_CHECK_ARG(accumulate >= 0 && accumulate <= 2 && (accumulate != 2 || dtype == SIMCLR_DT_F32),
+                   "conv2d_dgrad_bn: accumulate must be 0, 1 or (fp32) 2 = earlier data at even pixels only, see simclr_conv2d_dgrad (got %d)", accumulate);
   SIMCLR_CHECK_ARG(mask_mode >= 1 && mask_mode <= 4, "conv2d_dgrad_bn: mask_mode must be 1, 2, 3 or 4");
   SIMCLR_CHECK_ARG(stats && nslot > 0 && (mask_mode == 4 || (bn_x && bn_mean && bn_rstd)), "conv2d_dgrad_bn: null BN argument");
   SIMCLR_CHECK_ARG(mask_mode == 2 || bn_mask, "conv2d_dgrad_bn: mask_mode 1 / 3 / 4 need bn_mask");

@@ -347,20 +347,45 @@ def conv2d_fwd_bn_apply(x, w_t, KH, KW, stride, pad, OH, OW, scale, shift, res=N
     return (y, bits) if want_bits else y
 
 
-def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=False):
+def sparse_dgrad_enabled(dtype):
+    """fp32 storage: the data gradient of a stride-2 1x1 projection shortcut stores only the quarter of dx that receives a tap and the
+    accumulating data gradient of the block's first convolution reads earlier data there only (simclr_conv2d_dgrad accumulate = 3 / 2):
+    no zero fill of, and no read-back from, the other three quarters.  SIMCLR_SPARSE_DGRAD=0: zero fill + full accumulate."""
+    return dtype == torch.float32 and os.environ.get('SIMCLR_SPARSE_DGRAD', '1') not in ('', '0')
+
+
+def _acc_mode(out, accumulate):
+    """accumulate argument of the data-gradient entry points: 2 when `out` came from a sparse store (tag `_sparse2`, cleared here)."""
+    if not accumulate:
+        assert not getattr(out, '_sparse2', False), 'a sparsely stored gradient must be completed by an accumulating data gradient'
+        return 0
+    if getattr(out, '_sparse2', False):
+        out._sparse2 = False
+        return 2
+    return 1
+
+
+def conv2d_dgrad(dy, w_d, KH, KW, stride, pad, IH, IW, out=None, accumulate=False, sparse=False):
+    """sparse (fp32, stride-2 1x1): only the pixels with even row and column are written, the rest of the result is left
+    UNINITIALISED and the tensor is tagged `_sparse2`: its only legal consumer is an accumulating conv2d_dgrad / conv2d_dgrad_bn."""
     V, OH, OW, Cout = dy.shape
     Cin = w_d.shape[0]
     if out is None:
         assert not accumulate
         out = torch.empty(V, IH, IW, Cin, device=dy.device, dtype=dy.dtype)
+    if sparse:
+        assert not accumulate and stride == 2 and KH == 1 and KW == 1 and pad == 0 and dy.dtype == torch.float32
     M, K = V * IH * IW, KH * KW * Cout
     esz = dy.element_size()
     fmt = FMT_PS_IN if ps_kind(dy) else 0
     assert ps_kind(dy) in (None, 'b16')
     wp, wf = _pw(w_d, False)
+    acc = 3 if sparse else _acc_mode(out, accumulate)
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + M * Cin + K * Cin),
-            lambda: lib().conv2d_dgrad(_pp(dy), wp, _p(out), int(accumulate), V, IH, IW, Cin, OH, OW, Cout,
+            lambda: lib().conv2d_dgrad(_pp(dy), wp, _p(out), acc, V, IH, IW, Cin, OH, OW, Cout,
                                        KH, KW, stride, pad, dt(dy) | fmt | _tb() | wf, _s()))
+    if sparse:
+        out._sparse2 = True
     return out
 
 
@@ -376,9 +401,10 @@ def conv2d_dgrad_bn(dy, w_d, KH, KW, pad, IH, IW, bn, out=None, accumulate=False
     K = KH * KW * Cout
     esz = dy.element_size()
     wp, wf = _pw(w_d, False)
+    acc = _acc_mode(out, accumulate)
     _launch('conv_igemm_dgrad', 2.0 * V * OH * OW * K * Cin, esz * (V * OH * OW * Cout + V * IH * IW * Cin + K * Cin),
             impl_bytes=esz * (V * OH * OW * Cout + (1 + (bn['mode'] != 4) + (bn['mode'] == 1) + int(accumulate)) * V * IH * IW * Cin + K * Cin),
-            fn=lambda: lib().conv2d_dgrad_bn(_pp(dy), wp, _p(out), int(accumulate), _p(bn.get('x')), _p(bn.get('mask')),
+            fn=lambda: lib().conv2d_dgrad_bn(_pp(dy), wp, _p(out), acc, _p(bn.get('x')), _p(bn.get('mask')),
                                           _p(bn.get('scale')), _p(bn.get('shift')), _p(bn.get('mean')), _p(bn.get('rstd')),
                                           bn['mode'], _p(partial), partial.shape[0], V, IH, IW, Cin, OH, OW, Cout, KH, KW, 1,
                                           pad, dt(dy) | (FMT_PS_IN if ps_kind(dy) else 0) | _tb() | wf, _s()))
@@ -940,6 +966,7 @@ def small_gemm_nt(A, B):
 def conv2d_dgrad_bn_ext(dm, h, wext, bias, bn, out=None, accumulate=False):
     """1x1 stride-1 dgrad reading (dm [V,H,W,N], h [V,H,W,K]) with the K-extended weights of bn_fold_pre/post and the bias
     W d, plus the fused BN-backward reduce of the producer BN of h (`bn` as in conv2d_dgrad_bn).  Returns (dm_in, partial)."""
+    assert not getattr(out, '_sparse2', False), 'a sparsely stored gradient needs conv2d_dgrad / conv2d_dgrad_bn to complete it'
     V, H, W, N = dm.shape
     K = h.shape[3]
     if out is None:
@@ -994,6 +1021,7 @@ def bn_fold_s2(t1, w_d, mean, rstd, sums):
 
 def conv2d_dgrad_ext(dm, h, wext, bias, out=None, accumulate=False):
     """K-extended 1x1 dgrad with a plain epilogue (see conv2d_dgrad_bn_ext): dx [+]= dm (a*W)^T + h Q + W d."""
+    assert not getattr(out, '_sparse2', False), 'a sparsely stored gradient needs conv2d_dgrad / conv2d_dgrad_bn to complete it'
     V, H, W, N = dm.shape
     K = h.shape[3]
     if out is None:

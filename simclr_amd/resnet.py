@@ -604,9 +604,10 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             return ops.conv2d_dgrad_ext(dm, h, wext, e, out=dx_out, accumulate=accumulate), None
         return ops.conv2d_dgrad_bn_ext(dm, h, wext, e, fuse_bn)
 
-    def backward(self, dy, need_dx=True, dx_out=None, accumulate=False, fuse_bn=None):
+    def backward(self, dy, need_dx=True, dx_out=None, accumulate=False, fuse_bn=None, sparse=False):
         """Returns dx, or (dm, partial) when `fuse_bn` (BatchNormRelu.fusion_info of the layer that
-        produced this conv's input) asks for the fused BN-backward reduce (stride-1 convs only)."""
+        produced this conv's input) asks for the fused BN-backward reduce (stride-1 convs only).
+        sparse: see ops.conv2d_dgrad (a stride-2 1x1 convolution whose dx an accumulating data gradient completes)."""
         k, s = self.kernel_size, self.strides
         sv = self.saved
         self.saved = None
@@ -634,7 +635,7 @@ class Conv2dFixedPadding(Layer):  # tf2/resnet.py:183-208
             return ops.conv2d_dgrad_bn(dy, self.w_d, k, k, sv['pad'], sv['H'], sv['W'], fuse_bn, out=dx_out,
                                        accumulate=accumulate)
         return ops.conv2d_dgrad(dy, self.w_d, k, k, s, sv['pad'], sv['H'], sv['W'], out=dx_out,
-                                accumulate=accumulate)
+                                accumulate=accumulate, sparse=sparse)
 
 
 def _pool_fusion_enabled():
@@ -809,9 +810,12 @@ class _Shortcut(Layer):
         self.bn.saved = None
         return d
 
-    def backward(self, d_sum, coeffs=None):
+    def backward(self, d_sum, coeffs=None, sparse=False):
+        """sparse: the caller completes the result with an accumulating data gradient (the block's conv1) -- a strided 1x1 projection
+        then stores only the quarter of dx that receives a tap (ops.conv2d_dgrad sparse: no zero fill, nothing read back from it)."""
         d_raw, _ = self.bn.backward(d_sum, mask_mode=0, coeffs=coeffs, ps_for=self.conv)
-        d = self.conv.backward(d_raw)
+        sp = (sparse and not self.resnet_d and self.conv.strides == 2 and not self.conv.padded and ops.sparse_dgrad_enabled(RT.dtype))
+        d = self.conv.backward(d_raw, sparse=sp)
         if self.resnet_d:
             d = ops.avgpool2_bwd(d, self._hw[0], self._hw[1], self.strides)
         return d
@@ -829,7 +833,7 @@ def _block_entry(block, inputs, training):
     return raw_sc.t, sc_bn, block.bn1(raw1, training)
 
 
-def _block_tail_backward(block, bn_tail, dout, dout_partial, conv_tail=None):
+def _block_tail_backward(block, bn_tail, dout, dout_partial, conv_tail=None, sparse_shortcut=False):
     """Backward of relu(bn_tail(h) + shortcut): returns (dh, dx_shortcut_path).  When the tail's reduce arrived fused
     (dout_partial) and the block has a projection shortcut, the two BatchNorm backward reductions -- same upstream
     gradient -- share one statistics exchange."""
@@ -839,11 +843,11 @@ def _block_tail_backward(block, bn_tail, dout, dout_partial, conv_tail=None):
             sc_part = block.shortcut.bn.bwd_reduce(dsum, mask_mode=0)
             co_t, co_s = bwd_finalize_many([(bn_tail, dout_partial), (block.shortcut.bn, sc_part)])
             dh = bn_tail.backward_fused(dout, dout_partial, coeffs=co_t, ps_for=conv_tail)
-            return dh, block.shortcut.backward(dsum, coeffs=co_s)
+            return dh, block.shortcut.backward(dsum, coeffs=co_s, sparse=sparse_shortcut)
         dh = bn_tail.backward_fused(dout, dout_partial, ps_for=conv_tail)
     else:
         dh, dsum = bn_tail.backward(dout, mask_src=block.out, mask_mode=1, want_masked=True, ps_for=conv_tail)
-    dx = block.shortcut.backward(dsum) if block.shortcut is not None else dsum
+    dx = block.shortcut.backward(dsum, sparse=sparse_shortcut) if block.shortcut is not None else dsum
     return dh, dx
 
 
@@ -967,7 +971,7 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
             elif self.shortcut.foldable():
                 dx = self.shortcut.backward_folded(dout, dout_partial)
             else:
-                dx = self.shortcut.backward(dout)
+                dx = self.shortcut.backward(dout, sparse=True)        # completed by conv1's accumulating data gradient below
             self.out = None
             dm2, part2 = self.conv3.backward_folded(dout, self.bn3, dout_partial, fuse_bn=self.bn2.fusion_info(),
                                                     s2_from_gemm=_bn_s2_enabled())
@@ -982,7 +986,7 @@ class BottleneckBlock(Layer):  # tf2/resnet.py:385-487
                 return self.conv1.backward(dh1, dx_out=dx, accumulate=True, fuse_bn=prev_tail)
             self.conv1.backward(dh1, dx_out=dx, accumulate=True)
             return dx, None
-        dh3, dx = _block_tail_backward(self, self.bn3, dout, dout_partial, self.conv3)
+        dh3, dx = _block_tail_backward(self, self.bn3, dout, dout_partial, self.conv3, sparse_shortcut=True)
         self.out = None
         if self.sk is not None:
             dsk = self.conv3.backward(dh3)

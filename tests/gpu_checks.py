@@ -940,6 +940,44 @@ def check_ps_weights(V, H, Cin, Cout, k, seed=0):
         ops.set_f32_matmul('exact')
 
 
+def check_sparse_dgrad(V, H, Cs, Cin, Cmid, mode, seed=0, matmul='f16x3_3'):
+    """Stride-2 1x1 projection shortcut + the block's first convolution in the backward pass (fp32 storage): the shortcut's data gradient
+    stores only the even (row, column) pixels of dx (accumulate = 3, the rest UNINITIALISED -- poisoned with NaN here) and conv1's
+    accumulating data gradient reads earlier data there only (accumulate = 2); against the zero-filling store + full accumulate, bit for
+    bit.  mode 0: plain conv1 data gradient; 4: with the fused BatchNorm-backward sums of the previous block's tail."""
+    ops.set_f32_matmul(matmul)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        OH = H // 2
+        w_sc = torch.randn(1, 1, Cin, Cs, device=DEV, generator=g) * Cin ** -0.5          # shortcut: Cin -> Cs, stride 2
+        w_1 = torch.randn(1, 1, Cin, Cmid, device=DEV, generator=g) * Cin ** -0.5         # conv1: Cin -> Cmid, stride 1
+        _, wd_sc = ops.prep_weights_pair(w_sc, torch.float32)
+        _, wd_1 = ops.prep_weights_pair(w_1, torch.float32)
+        d_sc = torch.randn(V, OH, OH, Cs, device=DEV, generator=g)
+        d_1 = torch.randn(V, H, H, Cmid, device=DEV, generator=g)
+        mask = (torch.rand(V, H, H, Cin // 4, device=DEV, generator=g) * 16).to(torch.uint8)      # ReLU bits of the previous block's output
+
+        def run(sparse):
+            dx = torch.full((V, H, H, Cin), float('nan'), device=DEV)
+            ops.conv2d_dgrad(d_sc, wd_sc, 1, 1, 2, 0, H, H, out=dx, sparse=sparse)
+            if mode == 0:
+                ops.conv2d_dgrad(d_1, wd_1, 1, 1, 1, 0, H, H, out=dx, accumulate=True)
+                return dx, None
+            out, part = ops.conv2d_dgrad_bn(d_1, wd_1, 1, 1, 0, H, H, dict(mask=mask.view(V * H * H, -1), mode=4), out=dx, accumulate=True)
+            return out, ops.bn_reduce_slots(part)
+
+        a, pa = run(False)
+        b, pb = run(True)
+        torch.cuda.synchronize()
+        tag = 'V%d %d %d/%d/%d mode%d' % (V, H, Cs, Cin, Cmid, mode)
+        res = [_res('sparse_dgrad_dx ' + tag, b, a, 0.0)]
+        if pa is not None:
+            res.append(_res('sparse_dgrad_sums ' + tag, pb, pa, 0.0))
+        return res
+    finally:
+        ops.set_f32_matmul('exact')
+
+
 def ps_encode(t):
     """float32 [..., C] (C % 32 == 0) -> the pre-split block format with bf16 pieces (the inverse of ps_decode; hi = bf16(x) to nearest
     even, lo = bf16(x - hi)), tagged `_ps` like the tensors simclr_bn_bwd_apply writes."""

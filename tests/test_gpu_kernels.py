@@ -543,6 +543,14 @@ def test_stem_conv(V, H, k, s, dtype):
     _assert(gc.check_stem(V, H, k, s, 64, dtype))
 
 
+@pytest.mark.parametrize('matmul', ['f16x3_3', 'exact'])
+@pytest.mark.parametrize('V,H,Cs,Cin,Cmid,mode', [(4, 28, 512, 256, 128, 0), (4, 28, 512, 256, 128, 4), (3, 14, 1024, 512, 256, 4),
+                                                  (2, 30, 128, 64, 64, 0), (40, 14, 256, 128, 64, 4)])
+def test_strided_shortcut_data_gradient_without_zero_fill(V, H, Cs, Cin, Cmid, mode, matmul):
+    from tests import gpu_checks as gc
+    _assert(gc.check_sparse_dgrad(V, H, Cs, Cin, Cmid, mode, matmul=matmul))
+
+
 @pytest.mark.parametrize('V,H,Cin,Cout,k', [(8, 14, 256, 64, 1), (4, 14, 64, 128, 3), (8, 28, 64, 256, 1), (2, 7, 512, 512, 3)])
 def test_presplit_weight_copies_made_once_per_refresh(V, H, Cin, Cout, k):
     from tests import gpu_checks as gc
