@@ -1499,9 +1499,13 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
 // XOR key that spreads the 32-byte channel blocks of a pixel row over the LDS banks.
 //  bf16: the 8 pixel rows one 32-lane half touches in a ds_read_b64_tr_b16 (pixels 8g+q, q<4)
-//        get 8 distinct keys;   f32: consecutive pixels get consecutive keys.
+//        get 8 distinct keys;
+//  f32:  the four lane groups of a fragment read read 16 floats (64 bytes = TWO blocks) of four CONSECUTIVE pixels, so those pixels need
+//        keys that differ above bit 0: (px & 3) << 1 | bit 2 of px -- eight consecutive pixels still get eight distinct keys.  (Round 6:
+//        the old key px & 7 put pixels 4j and 4j + 1 into the same 64-byte bank range -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50
+//        on every fp32 weight-gradient launch that splits in registers and on the exact Gram launches, r06_call29.)
 template <typename T> __device__ __forceinline__ int px_key(int px) {
-  return sizeof(T) == 2 ? ((px & 3) | (((px >> 3) & 1) << 2)) : (px & 7);
+  return sizeof(T) == 2 ? ((px & 3) | (((px >> 3) & 1) << 2)) : (((px & 3) << 1) | ((px >> 2) & 1));
 }
 
 // MT (multi-tap k-tile): the BKW rows of the tile span SEVERAL taps of IC < BKW channels each (the stem: 7 kernel rows x 32
