@@ -89,9 +89,13 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
 }
 template <bool F16> __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& l) {
   if constexpr (F16) {
+    // lo = fp16(x - fp32(hi)) in ONE mixed-precision fma per element (v_fma_mixlo / mixhi_f16: fp16 source half, fp32 addend, the exact
+    // sum rounded once to fp16 -- x - hi is exact in fp32, so this IS the rounding of the two-step form): 3 VALU per pair instead of the
+    // compiler's 5 (v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32); the split sits in the forward k-loops.
+    // Checked against torch's float16 rounding over 40 binades (tests: presplit_weight_pieces_equal_torch_rounding).
     h = pack_f16x2(x0, x1);
-    const hw_f16x2_t hv = __builtin_bit_cast(hw_f16x2_t, h);
-    l = pack_f16x2(x0 - (float)hv[0], x1 - (float)hv[1]);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
   } else {
     h = pack_bf16x2(x0, x1);
     l = pack_bf16x2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));

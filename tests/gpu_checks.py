@@ -940,6 +940,35 @@ def check_ps_weights(V, H, Cin, Cout, k, seed=0):
         ops.set_f32_matmul('exact')
 
 
+def check_ps_weight_pieces(Cin, Cout, k, seed=0):
+    """The pieces simclr_presplit_weights_multi stores against torch's own rounding (an oracle independent of the device's split
+    instructions): forward copy = fp16 pieces of 2^8 w_t, hi = fp16(x), lo = fp16(x - hi); data-gradient copy = bf16 pieces of w_d.
+    The weights span 40 binades, so that lo pieces of every kind occur: normal, subnormal in fp16, zero."""
+    ops.set_f32_matmul('f16x3_3')
+    try:
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        w = torch.randn(k, k, Cin, Cout, device=DEV, generator=g)
+        w = w * torch.exp2(torch.randint(-36, 5, w.shape, device=DEV, generator=g).float())
+        w.view(-1)[::97] = 0.0
+        (w_t, w_d), = ops.WeightPairBatch([(w, 0, 0)], torch.float32).run()
+        torch.cuda.synchronize()
+        res = []
+        for name, wt, kind, scale in (('fwd_f16', w_t, 'f16', 256.0), ('dgrad_bf16', w_d, 'b16', 1.0)):
+            ps, terms = wt._psw
+            assert terms == (13 if kind == 'f16' else 3)
+            _, hi, lo = ps_decode(ps, kind)
+            x = (wt.detach() * scale).cpu()
+            pt = torch.float16 if kind == 'f16' else torch.bfloat16
+            hi_ref = x.to(pt)
+            lo_ref = (x - hi_ref.float()).to(pt)
+            res += [_res('psw_pieces_hi ' + name, hi, hi_ref.double(), 0.0), _res('psw_pieces_lo ' + name, lo, lo_ref.double(), 0.0)]
+            n_sub = int(((lo_ref != 0) & (lo_ref.float().abs() < 2.0 ** -14)).sum()) if kind == 'f16' else 1
+            res.append(dict(name='psw_pieces_subnormal_lo_present ' + name, ok=n_sub > 0, err=float(n_sub), tol=0.0))
+        return res
+    finally:
+        ops.set_f32_matmul('exact')
+
+
 def check_sparse_dgrad(V, H, Cs, Cin, Cmid, mode, seed=0, matmul='f16x3_3'):
     """Stride-2 1x1 projection shortcut + the block's first convolution in the backward pass (fp32 storage): the shortcut's data gradient
     stores only the even (row, column) pixels of dx (accumulate = 3, the rest UNINITIALISED -- poisoned with NaN here) and conv1's

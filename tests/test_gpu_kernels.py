@@ -543,6 +543,12 @@ def test_stem_conv(V, H, k, s, dtype):
     _assert(gc.check_stem(V, H, k, s, 64, dtype))
 
 
+@pytest.mark.parametrize('Cin,Cout,k', [(64, 64, 1), (128, 96, 3)])
+def test_presplit_weight_pieces_equal_torch_rounding(Cin, Cout, k):
+    from tests import gpu_checks as gc
+    _assert(gc.check_ps_weight_pieces(Cin, Cout, k))
+
+
 @pytest.mark.parametrize('matmul', ['f16x3_3', 'exact'])
 @pytest.mark.parametrize('V,H,Cs,Cin,Cmid,mode', [(4, 28, 512, 256, 128, 0), (4, 28, 512, 256, 128, 4), (3, 14, 1024, 512, 256, 4),
                                                   (2, 30, 128, 64, 64, 0), (40, 14, 256, 128, 64, 4)])
