@@ -609,7 +609,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   static_assert(!PSB || ((SPL == 3 || SPL == 13) && sizeof(T) == 4), "pre-split weights: fp32 storage, three terms");
   static_assert(!PSX || ((SPL == 3 || SPL == 13) && sizeof(T) == 4), "pre-split gathered operand: fp32 storage, three terms");
   static_assert(SPL != 13 || PSB, "split-fp16 terms need the pre-split (scaled) weight planes");
-  static_assert(!WIN || (sizeof(T) == 2 && STAGES == 2 && !EXT && NW == 4 && BM == 128), "halo-window variant: bf16, 2 stages");
+  // (fp32 storage, round 6: the three-term instantiations with pre-split weights -- a window row is the 128-byte block of 32 channels, the
+  // k-step of these kernels; with PSX the block is the pre-split gradient's -- read through mma_f32_chunks like the gathered tile)
+  static_assert(!WIN || (STAGES == 2 && !EXT && NW == 4 && BM == 128 && !FAPPLY && (sizeof(T) == 2 || ((SPL == 3 || SPL == 13) && PSB))),
+                "halo-window variant: 2 stages; bf16, or fp32 storage with three terms and pre-split weights");
   // FAPPLY (forward, bf16): the row-wise epilogue applies a BatchNorm (+ residual, + ReLU, + ReLU bit mask) to the tile
   // before it is stored -- y = act(bf16(conv) * scale + shift + res) with exactly the arithmetic of bn_apply (csrc/bn.hip),
   // so the convolution output itself never travels to HBM.  The statistics that scale / shift derive from come from a
@@ -935,11 +938,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
       auto win_step = [&](const u32x4* Wc, int zr, const u32x4* Bt, int t) __attribute__((always_inline)) {
         int rr[MI];
         win_rows(t, zr, rr);
+        if constexpr (sizeof(T) == 4) {
+          mma_f32_chunks<NI, MI, false, SPL, PSB, PSX>(&acc[0][0],
+              [&](int i, int ks) { const int r = wn * 64 + i * 16 + fl; return Bt[r * 8 + ((ks * 4 + g) ^ (r & 7))]; },
+              [&](int i, int ks) { return Wc[rr[i] * 8 + ((ks * 4 + g) ^ (rr[i] & 7))]; });
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           u32x4 af[MI], bf[NI];
           win_load(Wc, rr, Bt, ks, af, bf);
           win_mma(af, bf);
+        }
         }
       };
       for (int c = kt0; c < kt1; ++c) {
@@ -3392,8 +3401,11 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     const int bk_elems = 128 / (int)sizeof(T);
     const bool win3 = [&] {
       static const bool no_win = []{ const char* e = getenv("SIMCLR_CONV3_WIN"); return e && e[0] == '0'; }();
-      return sizeof(T) == 2 && !no_win && !p.fapply && !p.x2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.cs == 1 &&
-             p.ntaps == 9 && p.IH == p.OH && p.IW == p.OW && p.IW <= 62;
+      // fp32 storage (round 6, SIMCLR_CONV3_WIN32=0 switches back): the three-term launches with pre-split weights (checked below)
+      static const bool no_win32 = []{ const char* e = getenv("SIMCLR_CONV3_WIN32"); return e && e[0] == '0'; }();
+      if (sizeof(T) == 4 && (no_win32 || !(p.split == 3 || p.split == 13))) return false;
+      return !no_win && !p.fapply && !p.x2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.cs == 1 &&
+             p.ntaps == 9 && p.IH == p.OH && p.IW == p.OW && p.IW <= 62 && p.accumulate < 2;
     }();
     // reduction units the tail can be split in: k-steps, or 64-channel chunks on the halo-window path
     // (bf16 128 x 128 tiles only: the 64-wide tiles are the short-K streaming layers, the fp32 kernels keep whole tiles)
@@ -3482,12 +3494,31 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
 #undef LF
       return;
     }
-    // 3x3 stride-1 bf16: halo-window operand path (one window load per 64-channel chunk instead of nine gathers)
-    if (win3) {
+    // 3x3 stride-1: halo-window operand path (one window load per 128-byte channel chunk instead of nine gathers)
+    bool win_now = win3;
+    if constexpr (sizeof(T) == 4) {
+      // fp32 storage: forward = three fp16-piece terms with the pre-split weights; data gradient = three bf16-piece terms with both
+      // operands pre-split, plain or with the fused BatchNorm-backward reduce (the launches a ResNet step makes); everything else gathers
+      if (MODE == MODE_FWD) win_now = win3 && psb && p.split == 13 && !p.bn_mode;
+      else win_now = win3 && psb && p.split == 3 && p.x_ps && (p.bn_mode != 0) == st;
+    }
+    if (win_now) {
       const int rows = ((128 + 2 * (p.IW + 1)) + 31) / 32 * 32;
       p.win_j = rows / 32;
-      p.win_bytes = rows * 128 > 128 * BN * 2 ? rows * 128 : 128 * BN * 2;
+      p.win_bytes = (sizeof(T) == 4 || rows * 128 > 128 * BN * 2) ? rows * 128 : 128 * BN * 2;     // (bf16: doubles as the C staging tile)
       const size_t wlds = (size_t)p.win_bytes + 2 * BN * 128 + 5 * BN * sizeof(float) + 128 * sizeof(long long) + 128;
+      if constexpr (sizeof(T) == 4) {
+#define LW32(BNv, STv, BEv)                                                                                                   \
+        do {                                                                                                                   \
+          if constexpr (MODE == MODE_FWD) { if constexpr (!(BEv)) SIMCLR_LAUNCH((conv_igemm_persistent<float, MODE_FWD, 128, BNv, 4, 2, STv, false, false, true, false, 13, false, true>), dim3(pg), dim3(256), wlds, stream, p); } \
+          else SIMCLR_LAUNCH((conv_igemm_persistent<float, MODE_DGRAD, 128, BNv, 4, 2, STv, BEv, false, true, false, 3, false, true, 0, 0, true>), dim3(pg), dim3(256), wlds, stream, p); \
+        } while (0)
+        if (p.bn_mode) { if (BN == 64) LW32(64, true, true); else LW32(128, true, true); }
+        else if (BN == 64) { if (st) LW32(64, true, false); else LW32(64, false, false); }
+        else { if (st) LW32(128, true, false); else LW32(128, false, false); }
+#undef LW32
+        return;
+      } else {
 #define LW(BNv, STv, BEv)                                                                                                     \
       do {                                                                                                                     \
         if ((BNv) == 128 && p.rem_parts >= 2) SIMCLR_LAUNCH((conv_igemm_persistent<uint16_t, MODE, 128, 128, 4, 2, STv, BEv, false, true, false, 0, true>), dim3(pg), dim3(256), wlds, stream, p); \
@@ -3502,6 +3533,7 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
       else { if (st) LW(128, true, false); else LW(128, false, false); }
 #undef LW
       return;
+      }
     }
     if (!p.bn_mode && p.x2) {  // K-extended dgrad, plain epilogue (the conv input is not a BatchNorm output: block entry)
       if (BN == 64) LPX(64, false, false, true); else LPX(128, false, false, true);

@@ -1056,18 +1056,21 @@ def check_ps_backward(V, H, Cin, Cout, k, stride, seed=0, matmul='bf16x3'):
         lo_ref = (dx_plain - dx_plain.bfloat16().float()).bfloat16().double().cpu()
         res = [_res('ps_pieces_hi ' + tag, hi, hi_ref, 0.0), _res('ps_pieces_lo ' + tag, lo, lo_ref, 0.0),
                _res('ps_value ' + tag, val, ref, 2.0 ** -16)]
-        # data gradient: bitwise the in-register split
+        # data gradient: bitwise the in-register split -- except on the 3x3 stride-1 layers, where the pre-split launch takes the halo-window
+        # path (same products, summed chunk-major instead of tap-major) and the in-register split gathers: three-term rounding level there
+        win = k == 3 and stride == 1 and H <= 62
+        bit = 4e-5 if win else 0.0
         d_plain = ops.conv2d_dgrad(dx_plain, w_d, k, k, stride, pad, H, H)
         d_ps = ops.conv2d_dgrad(dx_ps, w_d, k, k, stride, pad, H, H)
-        res.append(_res('ps_dgrad_bitwise ' + tag, d_ps, d_plain, 0.0))
+        res.append(_res('ps_dgrad_bitwise ' + tag, d_ps, d_plain, bit))
         if stride == 1:
             bn_x = rnd((V, H, H, Cin), 1.5) + 0.3
             bn = dict(x=bn_x, mask=None, scale=torch.rand(Cin, device=DEV, generator=g) - 0.4, shift=0.3 * rnd((Cin,)),
                       mean=0.2 * rnd((Cin,)), rstd=0.5 + torch.rand(Cin, device=DEV, generator=g), mode=2)
             m_plain, p_plain = ops.conv2d_dgrad_bn(dx_plain, w_d, k, k, pad, H, H, bn)
             m_ps, p_ps = ops.conv2d_dgrad_bn(dx_ps, w_d, k, k, pad, H, H, bn)
-            res.append(_res('ps_dgrad_bn_bitwise ' + tag, m_ps, m_plain, 0.0))
-            res.append(_res('ps_dgrad_bn_sums_bitwise ' + tag, ops.bn_reduce_slots(p_ps), ops.bn_reduce_slots(p_plain), 0.0))
+            res.append(_res('ps_dgrad_bn_bitwise ' + tag, m_ps, m_plain, bit))
+            res.append(_res('ps_dgrad_bn_sums_bitwise ' + tag, ops.bn_reduce_slots(p_ps), ops.bn_reduce_slots(p_plain), 25 * bit))
         # weight gradient: float64 of the exact operands (the three-term gate of check_conv), and close to the plain kernel
         dw_plain = ops.conv2d_wgrad(x, dx_plain, k, k, stride, pad)
         dw_ps = ops.conv2d_wgrad(x, dx_ps, k, k, stride, pad)

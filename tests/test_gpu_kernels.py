@@ -113,7 +113,11 @@ def test_conv_f32_split_bf16_matmul(V, H, Cin, Cout, k, s, matmul):
 
 
 @pytest.mark.parametrize('V,H,Cin,Cout,k,s,bn_case', [(1024, 14, 256, 256, 3, 1, (2, 0)), (256, 56, 256, 64, 1, 1, (3, 1)),
-                                                       (256, 56, 128, 128, 3, 2, None), (256, 28, 128, 512, 1, 1, (1, 0))])
+                                                       (256, 56, 128, 128, 3, 2, None), (256, 28, 128, 512, 1, 1, (1, 0)),
+                                                       # fp32 halo-window forward (3 x 3 stride 1, W <= 62): borders in every tile, widest row,
+                                                       # the 64-wide and 128-wide tiles at bench sizes, W = 64 falls back to the gather
+                                                       (5, 9, 64, 64, 3, 1, (2, 0)), (3, 62, 64, 128, 3, 1, None), (2, 64, 64, 64, 3, 1, (2, 0)),
+                                                       (128, 56, 64, 64, 3, 1, (2, 0)), (256, 28, 128, 128, 3, 1, (3, 1)), (1024, 7, 512, 512, 3, 1, (1, 0))])
 @pytest.mark.parametrize('matmul', ['bf16x6_3', 'f16x3_3'])
 def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case, matmul):
     """Split-bf16 / split-fp16 arithmetic on the persistent / XCD-mapped code paths the benchmark runs (full-tensor float64 reference)."""
@@ -125,7 +129,11 @@ def test_conv_f32_split_bf16_bench_path(V, H, Cin, Cout, k, s, bn_case, matmul):
 
 @pytest.mark.parametrize('V,H,Cin,Cout,k,s', [(3, 14, 64, 128, 3, 1), (2, 16, 64, 256, 1, 2), (2, 15, 128, 64, 3, 2), (130, 1, 128, 64, 1, 1),
                                               (64, 56, 256, 64, 1, 1), (64, 28, 128, 128, 3, 1), (2, 9, 192, 96, 3, 1), (5, 7, 512, 2048, 1, 1),
-                                              (1024, 14, 256, 256, 3, 1)])      # the last one: split tail of the persistent grid (8 parts)
+                                              (1024, 14, 256, 256, 3, 1),       # (bf16 heritage: the split tail of the persistent grid)
+                                              # fp32 halo-window data gradient against the gathered in-register split: borders in every tile,
+                                              # widest row, W = 64 (gather on both sides: bitwise), 64-wide tile at 56^2, 7^2
+                                              (5, 9, 64, 64, 3, 1), (3, 62, 128, 64, 3, 1), (2, 64, 64, 64, 3, 1), (32, 56, 64, 64, 3, 1),
+                                              (512, 7, 512, 512, 3, 1)])
 def test_conv_backward_with_presplit_gradient(V, H, Cin, Cout, k, s):
     """Round 6: the gradient between a BatchNorm backward and the convolution in front of it kept as (hi, lo) bf16 pieces per 128-byte block
     (csrc/common.h): pieces exact, data gradient bitwise the in-register split, weight gradient (transposing LDS reads) within the
