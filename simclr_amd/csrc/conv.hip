@@ -4159,9 +4159,16 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
       else LW(float, 32, 64);
     }
   } else if (dtype != SIMCLR_DT_BF16) {
+    static const bool wk4 = !getenv("SIMCLR_WGRAD_WK4") || atoi(getenv("SIMCLR_WGRAD_WK4")) != 0;
 #define LDS_(A, B)                                                                                                          \
     do {                                                                                                                     \
-      if (p.split == 3 && p.dy_ps) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3, 1>), dim3(grid), dim3(256), lds, stream, p); \
+      if (p.split == 3 && p.dy_ps) {                                                                                         \
+        /* pre-split gradient: four waves along k (each 32 | 16 k-rows x all columns) -- the activation operand, the one still split in   \
+           registers, is then split ONCE per workgroup instead of once per column half (96 -> 48 VALU per 48 MFMAs) */                      \
+        if constexpr ((A) >= 64) { if (wk4) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 4, 1, false, false, 3, 1>), dim3(grid), dim3(256), lds, stream, p); \
+                                   else hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3, 1>), dim3(grid), dim3(256), lds, stream, p); } \
+        else hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3, 1>), dim3(grid), dim3(256), lds, stream, p); \
+      }                                                                                                                      \
       else if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
       else if (p.split == 6) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 6>), dim3(grid), dim3(256), lds, stream, p); \
       else LD(float, A, B, 2, 2);                                                                                            \
