@@ -621,6 +621,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
   // tails lose the convolution-output round trip too: 8 of a bottleneck block's 67 tensor passes)
   static_assert(!FAPPLY || (MODE == MODE_FWD && !STATS && !BNEPI && !EXT), "fused BN-apply epilogue: forward, no statistics");
   static_assert(SPL == 0 || sizeof(T) == 4, "split-bf16 terms: fp32 storage only");
+  constexpr bool WPS = WIN && sizeof(T) == 4 && !PSX && (SPL == 3 || SPL == 13);   // fp32 window split in place once per chunk (k-loop below)
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int WN = BN / 64;           // waves along N
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
         int rr[MI];
         win_rows(t, zr, rr);
         if constexpr (sizeof(T) == 4) {
-          mma_f32_chunks<NI, MI, false, SPL, PSB, PSX>(&acc[0][0],
+          mma_f32_chunks<NI, MI, false, SPL, PSB, PSX || WPS>(&acc[0][0],
               [&](int i, int ks) { const int r = wn * 64 + i * 16 + fl; return Bt[r * 8 + ((ks * 4 + g) ^ (r & 7))]; },
               [&](int i, int ks) { return Wc[rr[i] * 8 + ((ks * 4 + g) ^ (rr[i] & 7))]; });
         } else {
@@ -958,6 +959,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || STAGES == 3) ? 1 : (BN == 64 &
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           if (issued < total) issue_b();
+          if constexpr (WPS) {
+            if (t == 0) {
+              // the window of an fp32 tensor, split IN PLACE once per chunk: the two 16-byte chunks (g, 4 + g) of a row -- the eight values
+              // lane group g multiplies in one MFMA -- become their (hi, lo) pieces, i.e. the row becomes the pre-split block the nine tap
+              // steps of all four waves then read without any VALU work (in registers every element was split 9 taps x 2 waves times).
+              // Same split function on the same pairs: bitwise the in-register result.
+              const int nq = p.win_j * 32 * 4;
+              for (int q = tid; q < nq; q += NW * 64) {
+                const int row = q >> 2, gq = q & 3;
+                u32x4* w0 = Wn + row * 8 + (gq ^ (row & 7));
+                u32x4* w1 = Wn + row * 8 + ((4 + gq) ^ (row & 7));
+                u32x4 hi, lo;
+                if constexpr (SPL == 13) split_terms2_f16(*w0, *w1, hi, lo); else split_terms2(*w0, *w1, hi, lo);
+                *w0 = hi; *w1 = lo;
+              }
+              __syncthreads();
+            }
+          }
           win_step(Wn, zrow, Bw + buf * (BN * 8), t);
           buf ^= 1;
           ++consumed;
