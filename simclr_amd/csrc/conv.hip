@@ -1791,7 +1791,10 @@ template <typename T, int BKW, int BNW, int BRM, int STAGES, int WK = 2, int WNN
 __global__ __launch_bounds__(WK * WNN * 64,
                              WK * WNN == 8 ? 1 : ((SPL == 0 && STAGES * BRM * 4 * Elem<T>::EPC * (BKW + BNW) * (int)sizeof(T) <= 53 * 1024) ? 3 : 2))
 void conv_wgrad_dma(const WgradP p) {
-  static_assert(PSD == 0 || (PSD == 1 && SPL == 3 && sizeof(T) == 4 && !GRAM && !MT && BNW % 32 == 0), "pre-split dy: fp32 storage, three terms");
+  // PSD == 2: dy arrives as plain fp32 (a gradient nobody pre-split: conv3's h^T dm under the folded tail BatchNorm) and its LDS tile is
+  // rewritten IN PLACE into the pre-split block format once per chunk -- each value split once per workgroup instead of once per wave
+  // that reads it -- after which the PSD == 1 k-loop applies unchanged (transposing reads, no VALU for that operand).
+  static_assert(PSD == 0 || ((PSD == 1 || PSD == 2) && SPL == 3 && sizeof(T) == 4 && !GRAM && !MT && BNW % 32 == 0), "pre-split dy: fp32 storage, three terms");
   // LDS bank keys of the two tiles (XOR on the 32-byte blocks of a pixel row).  PSD: the dy tile takes the bf16 kernel's key (the 8
   // pixel rows {8g+q, q<4} of a half-wave transposing read get 8 distinct keys); the fp32 activation tile is read 16 lanes x 4 bytes
   // per lane group at pixels 8g+j, so the four groups need distinct 64-byte bank ranges: key = g << 1.
@@ -2000,7 +2003,7 @@ void conv_wgrad_dma(const WgradP p) {
                                                               __builtin_bit_cast(bf16x8, af[ki]), acs[ki], 0, 0, 0);
         }
       }
-    } else if constexpr (PSD == 1) {
+    } else if constexpr (PSD != 0) {
       // pre-split dy: transposing reads of the hi / lo runs (bf16 pieces), activation split in registers; lane group g = pixels 8g..8g+7
 #pragma unroll
       for (int ks = 0; ks < BR / 32; ++ks) {
@@ -2081,6 +2084,20 @@ void conv_wgrad_dma(const WgradP p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (issued < c_end) { issue(is); ++issued; is = (is + 1 == STAGES) ? 0 : is + 1; }
+    if constexpr (PSD == 2) {
+      // (pixel row, 128-byte block, lane-group chunk gq): chunks gq and 4 + gq -- the eight channels one lane group multiplies -- become
+      // their (hi, lo) bf16 pieces in the same two slots: the block is then what simclr_bn_bwd_apply(SIMCLR_FMT_PS_OUT) would have stored
+      unsigned char* Bt = smem + cs * BUF + BR * A_RB;
+      for (int q = tid; q < BR * (BNW / 32) * 4; q += NW * 64) {
+        const int gq = q & 3, blk = (q >> 2) % (BNW / 32), px = q / (BNW / 8);
+        u32x4* w0 = (u32x4*)(Bt + b_off(px, blk * 128 + gq * 16));
+        u32x4* w1 = (u32x4*)(Bt + b_off(px, blk * 128 + (4 + gq) * 16));
+        u32x4 hi, lo;
+        split_terms2(*w0, *w1, hi, lo);
+        *w0 = hi; *w1 = lo;
+      }
+      __syncthreads();
+    }
     compute(cs);
     cs = (cs + 1 == STAGES) ? 0 : cs + 1;
   }
@@ -2092,7 +2109,7 @@ void conv_wgrad_dma(const WgradP p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       int n = n0 + wn * (NI * 16) + ni * 16 + g * 4;
-      if constexpr (PSD == 1) {            // run position 4 g + reg of run nf -> channel (common.h block layout)
+      if constexpr (PSD != 0) {            // run position 4 g + reg of run nf -> channel (common.h block layout)
         const int nf = wn * NI + ni, Q = 4 * (nf & 1) + g;
         n = n0 + (nf >> 1) * 32 + (Q & 1) * 16 + (Q >> 1) * 4;
       }
@@ -4179,6 +4196,7 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     }
   } else if (dtype != SIMCLR_DT_BF16) {
     static const bool wk4 = !getenv("SIMCLR_WGRAD_WK4") || atoi(getenv("SIMCLR_WGRAD_WK4")) != 0;
+    static const bool ldsps = !getenv("SIMCLR_WGRAD_LDSPS") || atoi(getenv("SIMCLR_WGRAD_LDSPS")) != 0;
 #define LDS_(A, B)                                                                                                          \
     do {                                                                                                                     \
       if (p.split == 3 && p.dy_ps) {                                                                                         \
@@ -4188,7 +4206,12 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
                                    else hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3, 1>), dim3(grid), dim3(256), lds, stream, p); } \
         else hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3, 1>), dim3(grid), dim3(256), lds, stream, p); \
       }                                                                                                                      \
-      else if (p.split == 3) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
+      else if (p.split == 3) {                                                                                               \
+        /* plain fp32 gradient: split in LDS once per chunk (PSD = 2), then the pre-split kernel's loop with four waves along k */         \
+        if constexpr ((A) >= 64 && (B) % 32 == 0) { if (ldsps) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 4, 1, false, false, 3, 2>), dim3(grid), dim3(256), lds, stream, p); \
+                                   else hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); } \
+        else hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 3>), dim3(grid), dim3(256), lds, stream, p); \
+      }                                                                                                                      \
       else if (p.split == 6) hipLaunchKernelGGL((conv_wgrad_dma<float, A, B, 2, 2, 2, 2, false, false, 6>), dim3(grid), dim3(256), lds, stream, p); \
       else LD(float, A, B, 2, 2);                                                                                            \
     } while (0)
