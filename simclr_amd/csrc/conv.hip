@@ -2583,7 +2583,10 @@ __global__ __launch_bounds__(256, (SPL > 0 && KS > 0) ? 2 : 1) void stem_conv_fw
 #pragma unroll
     for (int r = 0; r < 4; ++r) { st_s[i][r] = 0.f; st_q[i][r] = 0.f; }
   float* cst = red + 4 * BN * 2;               // bf16: [128][64] C staging tile (16 KB) behind the reduction scratch
-  auto tile_rows = [&](int mt_, long long* base_, bool* ok_) {
+  // (ROLL: 32-bit BYTE offsets from the image base -- the launcher checks that the packed image is smaller than 4 GB; four registers less,
+  //  and the loads can take the scalar base + 32-bit lane offset form)
+  typedef typename std::conditional<ROLL, unsigned, long long>::type off_t_;
+  auto tile_rows = [&](int mt_, off_t_* base_, bool* ok_) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = mt_ * 128 + wave * 32 + i * 16 + fl;
@@ -2592,35 +2595,31 @@ __global__ __launch_bounds__(256, (SPL > 0 && KS > 0) ? 2 : 1) void stem_conv_fw
       const int v = mm / (p.OH * p.OW);
       const int rem = mm - v * (p.OH * p.OW);
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      base_[i] = (((long long)v * p.HP + oy * p.stride) * p.WP + ox * p.stride) * 4;
+      base_[i] = (off_t_)((((long long)v * p.HP + oy * p.stride) * p.WP + ox * p.stride) * 4 * (ROLL ? (int)sizeof(T) : 1));
     }
   };
   // element offset of k-step ks of this lane's group inside the packed image (kernel row, position in the row)
-  int koff[ROLL ? KS : 1];           // (computed once: a runtime division per k-step)
-  if constexpr (ROLL) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int e = ks * KSTEP + g * EPC;
-      const int kh = e / row_elems, within = e - kh * row_elems;
-      koff[ks] = kh * p.WP * 4 + within;
-    }
-  }
-  auto k_off = [&](int ks) -> int { return koff[ks]; };
+  // ROLL (the launcher guarantees one padded kernel row = 32 elements = two k-steps): k-step ks is half ks & 1 of kernel row ks >> 1, so
+  // the offset is a wave-uniform multiple of the packed row pitch plus ONE per-lane term -- a table of KS per-lane offsets cost 13
+  // registers, which this kernel (256 VGPRs at two workgroups per CU) spilled; the spill reloads at the top of every tile made the
+  // compiler wait for vmcnt(0) there, i.e. for the previous tile's STORES (r06: ISA of stem_conv_fwd<float, true, 14, 13>)
+  const unsigned wp4 = p.WP * 4 * (unsigned)sizeof(T), goff = g * 16;                              // bytes
+  auto k_off = [&](int ks) -> unsigned { return (ks >> 1) * wp4 + (ks & 1) * (KSTEP * (unsigned)sizeof(T)) + goff; };
   u32x4 roll[ROLL ? KS : 1][2];      // ROLL: the activation fragments of the tile about to be computed
   if constexpr (ROLL) {
     if ((int)blockIdx.x < p.m_tiles) {
-      long long b0[2];
+      off_t_ b0[2];
       bool k0[2];
       tile_rows(blockIdx.x, b0, k0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) roll[ks][i] = ld16(X + b0[i] + k_off(ks));      // (rows beyond M read pixel 0: zeroed below)
+        for (int i = 0; i < 2; ++i) roll[ks][i] = ld16((const unsigned char*)X + (b0[i] + k_off(ks)));      // (rows beyond M read pixel 0: zeroed below)
     }
   }
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
     const int mw = mt * 128 + wave * 32;
-    long long base[2];
+    off_t_ base[2];
     bool ok[2];
     tile_rows(mt, base, ok);
     f32x4 acc[4][2];
@@ -2630,7 +2629,7 @@ __global__ __launch_bounds__(256, (SPL > 0 && KS > 0) ? 2 : 1) void stem_conv_fw
       for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (ROLL) {
       const int mtn = mt + gridDim.x;
-      long long nbase[2];
+      off_t_ nbase[2];
       bool nok[2];
       tile_rows(mtn < p.m_tiles ? mtn : mt, nbase, nok);
       if (mt * 128 + 128 > p.M) {                            // the partial last tile: rows beyond M multiply zeros
@@ -2654,7 +2653,7 @@ __global__ __launch_bounds__(256, (SPL > 0 && KS > 0) ? 2 : 1) void stem_conv_fw
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) roll[kp + h][i] = ld16(X + nbase[i] + k_off(kp + h));
+          for (int i = 0; i < 2; ++i) roll[kp + h][i] = ld16((const unsigned char*)X + (nbase[i] + k_off(kp + h)));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -3437,9 +3436,9 @@ void launch_igemm_one(ConvP p, hipStream_t stream) {
     const int bk_elems = 128 / (int)sizeof(T);
     const bool win3 = [&] {
       static const bool no_win = []{ const char* e = getenv("SIMCLR_CONV3_WIN"); return e && e[0] == '0'; }();
-      // fp32 storage (round 6, SIMCLR_CONV3_WIN32=0 switches back): the three-term launches with pre-split weights (checked below)
-      static const bool no_win32 = []{ const char* e = getenv("SIMCLR_CONV3_WIN32"); return e && e[0] == '0'; }();
-      if (sizeof(T) == 4 && (no_win32 || !(p.split == 3 || p.split == 13))) return false;
+      // fp32 storage (round 6): the three-term launches with pre-split weights (checked below); SIMCLR_CONV3_WIN=0 gathers in both storages
+      // (A/B of the fp32 path: 143.94 / 144.15 / 144.00 -> 141.75 / 141.58 / 141.22 ms per step, r06_call35)
+      if (sizeof(T) == 4 && !(p.split == 3 || p.split == 13)) return false;
       return !no_win && !p.fapply && !p.x2 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.cs == 1 &&
              p.ntaps == 9 && p.IH == p.OH && p.IW == p.OW && p.IW <= 62 && p.accumulate < 2;
     }();
@@ -4195,8 +4194,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
       else LW(float, 32, 64);
     }
   } else if (dtype != SIMCLR_DT_BF16) {
-    static const bool wk4 = !getenv("SIMCLR_WGRAD_WK4") || atoi(getenv("SIMCLR_WGRAD_WK4")) != 0;
-    static const bool ldsps = !getenv("SIMCLR_WGRAD_LDSPS") || atoi(getenv("SIMCLR_WGRAD_LDSPS")) != 0;
+    // settled A/B switches of round 6 (profiles/r06_notes.md sections 16, 17): four waves along k on a pre-split gradient (family 39.93 ->
+    // 38.54 ms), plain fp32 gradients split in LDS (37.40 -> 37.21 ms)
+    constexpr bool wk4 = true, ldsps = true;
 #define LDS_(A, B)                                                                                                          \
     do {                                                                                                                     \
       if (p.split == 3 && p.dy_ps) {                                                                                         \
@@ -4343,7 +4343,8 @@ int simclr_stem_conv_fwd(const void* xp, const void* w_s, void* y, float* stats,
     const int spl = stem_split_on ? ((terms == 13 && !stem_f16_on) ? 6 : terms) : 0;     // split-fp16 forward: the stem keeps six bf16 terms
     // the 7x7 stem (7 padded kernel rows of 8 taps x 4 channels = 14 k-steps of 16): unrolled, weights pre-split in LDS, rolling fragments
     static const bool stem_roll_on = !getenv("SIMCLR_STEM_ROLL") || atoi(getenv("SIMCLR_STEM_ROLL")) != 0;
-    const bool roll = stem_roll_on && p.KP == 14 * 16;
+    const bool roll = stem_roll_on && p.KP == 14 * 16 && KWP * 4 == 32 &&     // (7 padded kernel rows of 8 taps x 4 channels)
+                      (long long)V * HP * WP * 16 < (1ll << 32);              // (32-bit byte offsets in the rolling kernel)
 #define LSF(STv)                                                                                              \
     do {                                                                                                       \
       if (spl == 13 && roll) hipLaunchKernelGGL((stem_conv_fwd<float, STv, 14, 13>), grid, dim3(256), lds, stream, p);  \
