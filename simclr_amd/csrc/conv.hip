@@ -2004,6 +2004,7 @@ void conv_wgrad_dma(const WgradP p) {
         }
       }
     } else if constexpr (PSD != 0) {
+      __builtin_amdgcn_s_setprio(1);
       // pre-split dy: transposing reads of the hi / lo runs (bf16 pieces), activation split in registers; lane group g = pixels 8g..8g+7
 #pragma unroll
       for (int ks = 0; ks < BR / 32; ++ks) {
@@ -2025,6 +2026,7 @@ void conv_wgrad_dma(const WgradP p) {
               return c;
             });
       }
+      __builtin_amdgcn_s_setprio(0);
     } else if constexpr (SPL != 0) {
       // split-bf16 terms: lane group g holds pixels {4j + g : j = 0..7} of a 32-pixel step for both operands
       static_assert(!GRAM && BR % 32 == 0, "split-bf16 weight gradient: 32-pixel reduction steps, no Gram variant");
