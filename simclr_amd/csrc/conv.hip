@@ -2324,6 +2324,205 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_bf16(const Wgrad3P p) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Nine-tap weight gradient of the stride-1 3x3 convolutions in fp32 storage, three bf16-piece terms, gradient pre-split (round 6).
+// The structure of conv_wgrad3x3_bf16 -- a workgroup owns 64 input x 64 output channels x ALL nine taps over a pixel range, one
+// activation window with a halo of W + 1 pixels either side per chunk, tap (dy, dx) = the window shifted by dy * W + dx -- with the
+// operands of the parity mode: dy arrives in the pre-split block format (written by simclr_bn_bwd_apply, SIMCLR_FMT_PS_OUT) and the
+// fp32 activation window is rewritten IN PLACE into that format once per chunk (chunks gq and 4 + gq of a 128-byte block -> their hi
+// and lo bf16 pieces), so every fragment of either operand is two ds_read_b64_tr_b16 per piece and the k-loop holds no VALU work
+// besides the edge masks.  Against the per-tap kernel (conv_wgrad_dma<float, ..., PSD = 1>): the gradient rows are loaded and read
+// once per nine taps, the activation once per window instead of once per tap -- 8 LDS-DMA instructions per wave and 32 pixels as
+// before, but for 108 MFMAs instead of 48 -- and nothing is split in registers.  32-pixel chunks (rows are 256 bytes: 64 fp32
+// channels = two blocks), two stages, two workgroups per CU: W <= 47 (28^2, 14^2, 7^2); 56^2 keeps the per-tap kernel.
+// Wave w owns the 16 positions of run w of the 64 input channels (block w >> 1, run w & 1: channels {0-3, 16-19, 4-7, 20-23} or
+// {8-11, 24-27, 12-15, 28-31} of the block) x all 64 output channels x nine taps; the slab store maps positions back to channels.
+// LDS bank key (XOR on the eight 32-byte blocks of a row): (row & 3) | bit 3 of the row << 2 -- the 8 rows {R..R+3, R+8..R+11} of a
+// half-wave transposing read get 8 distinct keys for EVERY window shift R.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int w3f_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f32ps(const Wgrad3P p) {
+  constexpr int BR = 32, RB = 256;                 // pixels per chunk, bytes per LDS row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, fl = lane & 15;
+  const int tiles = p.ci_tiles * p.co_tiles;
+  const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const int tile = bidx % tiles, split = (bidx / tiles) * 8 + xcd;
+  if (split >= p.splits) return;
+  const int ci0 = (tile % p.ci_tiles) * 64, n0 = (tile / p.ci_tiles) * 64;
+  const float* __restrict__ X = (const float*)p.x;
+  const float* __restrict__ DY = (const float*)p.dy;       // pre-split blocks: same bytes, same addresses as the fp32 tensor
+  const int W1 = p.W + 1;
+  const int stage_bytes = (p.hpp + BR) * RB;
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (p.M + BR - 1) / BR;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+
+  // ---- direct-to-LDS loads of chunk c into stage s: window rows [mc - W1, mc - W1 + hpp), gradient rows [mc, mc + 32); one
+  // instruction = 4 rows of 16 chunks; the XOR permutation of the 32-byte blocks is applied to the SOURCE chunk
+  const int lrow = lane >> 4, lpc = lane & 15;
+  auto issue = [&](int c, int s) __attribute__((always_inline)) {
+    unsigned char* xs = smem + s * stage_bytes;
+    unsigned char* ds = xs + p.hpp * RB;
+    const int mc = c * BR;
+    const int nxi = p.hpp >> 2;
+    for (int q = wave; q < nxi; q += 4) {
+      const int r = q * 4 + lrow;
+      const int lc = (((lpc >> 1) ^ w3f_key(r)) << 1) | (lpc & 1);        // logical chunk held by this LDS slot
+      const int gp = mc + r - W1;
+      const void* src = (gp >= 0 && gp < p.M) ? (const void*)(X + (long long)gp * p.pixpitch + ci0 + lc * 4) : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + q * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = wave * 2 + j;
+      const int r = q * 4 + lrow;
+      const int lc = (((lpc >> 1) ^ w3f_key(r)) << 1) | (lpc & 1);
+      const int m = mc + r;
+      const void* src = (m < p.M) ? (const void*)(DY + (long long)m * p.N + n0 + lc * 4) : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + q * 1024), 16, 0, 0);
+    }
+  };
+
+  // byte offset of (row, byte in the 256-byte row); the lo pieces of a run sit 64 bytes after its hi pieces: block index + 2 = the
+  // offset XOR 64 (the run's block index has bit 1 clear, every tile base is a multiple of 256)
+  auto off_of = [&](int row, int byte) -> int { return row * RB + (((byte >> 5) ^ w3f_key(row)) << 5) + (byte & 31); };
+  const int px_lane = g * 8 + (fl >> 2);                     // this lane's pixel row inside the 32-pixel chunk
+  const int xbyte = (wave >> 1) * 128 + (wave & 1) * 32 + (fl & 3) * 8;
+  // (register budget: 144 accumulators + 32 gradient fragment registers leave ~70 for everything else.  The offset of row + 4 is derived
+  //  from the offset of the row: + 1024 bytes, and key bit 2 flips when bit 2 of the row is set -- that bit travels in bit 0 of the stored
+  //  offset, which is a multiple of 8; the four edge masks stay 8-bit values and are widened per tap)
+  auto hi_of = [](int o) __attribute__((always_inline)) -> int { return ((o & ~7) + 4 * RB) ^ ((o & 1) << 7); };
+  int a_lo[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int r = px_lane + W1 + (t / 3 - 1) * p.W + (t % 3 - 1);
+    a_lo[t] = off_of(r, xbyte) | ((r >> 2) & 1);
+  }
+  int b_lo[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int nbyte = (ni >> 1) * 128 + (ni & 1) * 32 + (fl & 3) * 8;
+    b_lo[ni] = off_of(px_lane, nbyte) | ((px_lane >> 2) & 1);
+  }
+  auto frag = [&](const unsigned char* base, int o_lo, int o_hi) __attribute__((always_inline)) -> u32x4 {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + o_lo));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + o_hi));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return (u32x4){l2[0], l2[1], h2[0], h2[1]};
+  };
+
+  // ---- (row, column) of the first pixel of this lane's 8-pixel group, advanced per chunk
+  const int hw = p.H * p.W;
+  const int dq = BR / hw, drem = BR - dq * hw, drow = drem / p.W, dcol = drem - drow * p.W;
+  int gy, gx;
+  {
+    const int m = c_begin * BR + g * 8;
+    const int rem = m % hw;
+    gy = rem / p.W; gx = rem - gy * p.W;
+  }
+
+  auto convert = [&](int s) __attribute__((always_inline)) {
+    unsigned char* xs = smem + s * stage_bytes;
+    for (int q = tid; q < p.hpp * 8; q += 256) {
+      const int row = q >> 3, j = (q >> 2) & 1, gq = q & 3;
+      u32x4* w0 = (u32x4*)(xs + off_of(row, (j * 8 + gq) * 16));
+      u32x4* w1 = (u32x4*)(xs + off_of(row, (j * 8 + 4 + gq) * 16));
+      u32x4 hi, lo;
+      split_terms2(*w0, *w1, hi, lo);
+      *w0 = hi; *w1 = lo;
+    }
+  };
+
+  auto compute = [&](int s) __attribute__((always_inline)) {
+    const unsigned char* xs = smem + s * stage_bytes;
+    const unsigned char* ds = xs + p.hpp * RB;
+    u32x4 dh[4], dl[4];                    // gradient fragments (shared by the nine taps)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int o0 = b_lo[ni] & ~7, o1 = hi_of(b_lo[ni]);
+      dh[ni] = frag(ds, o0, o1);
+      dl[ni] = frag(ds, o0 ^ 64, o1 ^ 64);
+    }
+    // edge masks of this lane's 8 pixels, as in conv_wgrad3x3_bf16 (W >= 7: the 8 pixels cross at most one row end)
+    const int jw = p.W - gx;
+    const unsigned lowm = jw >= 8 ? 0xffu : ((1u << jw) - 1u);
+    const int y1 = (gy + 1 == p.H) ? 0 : gy + 1;
+    const unsigned up = (gy > 0 ? lowm : 0u) | (y1 > 0 ? (0xffu & ~lowm) : 0u);
+    const unsigned dn = (gy < p.H - 1 ? lowm : 0u) | (y1 < p.H - 1 ? (0xffu & ~lowm) : 0u);
+    const unsigned lf = 0xffu & ~((gx == 0 ? 1u : 0u) | (jw < 8 ? (1u << jw) : 0u));
+    const unsigned rt = 0xffu & ~((jw - 1 < 8 ? (1u << (jw - 1)) : 0u) | (jw - 1 + p.W < 8 ? (1u << (jw - 1 + p.W)) : 0u));
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ty = t / 3, tx = t % 3;
+      const int o0 = a_lo[t] & ~7, o1 = hi_of(a_lo[t]);
+      u32x4 xh = frag(xs, o0, o1);
+      u32x4 xl = frag(xs, o0 ^ 64, o1 ^ 64);
+      if (t != 4) {
+        const unsigned m8 = (ty == 0 ? up : ty == 2 ? dn : 0xffu) & (tx == 0 ? lf : tx == 2 ? rt : 0xffu);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {      // dword d holds pixels 2d, 2d + 1: two sign-extended mask bits -> 0x0000ffff | 0xffff0000
+          const unsigned w = ((unsigned)__builtin_amdgcn_sbfe((int)m8, 2 * d, 1) & 0x0000ffffu) |
+                             ((unsigned)__builtin_amdgcn_sbfe((int)m8, 2 * d + 1, 1) & 0xffff0000u);
+          xh[d] &= w; xl[d] &= w;
+        }
+      }
+      // three terms, small ones first, term-major (consecutive MFMAs write different accumulators) -- the order of mma_f32_chunks
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[t][ni] = mma_bf16(dl[ni], xh, acc[t][ni]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[t][ni] = mma_bf16(dh[ni], xl, acc[t][ni]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[t][ni] = mma_bf16(dh[ni], xh, acc[t][ni]);
+      __builtin_amdgcn_sched_barrier(0);          // one tap's fragments at a time (left alone the scheduler prefetches several taps and spills)
+    }
+    __builtin_amdgcn_s_setprio(0);
+    gx += dcol;
+    if (gx >= p.W) { gx -= p.W; ++gy; }
+    gy += drow;
+    if (gy >= p.H) gy -= p.H;
+  };
+
+  int issued = c_begin, cs = 0, is = 1;
+  if (issued < c_end) { issue(issued, 0); ++issued; }
+  for (int c = c_begin; c < c_end; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // chunk c has landed; every wave is done with the other stage
+    if (issued < c_end) { issue(issued, is); ++issued; is ^= 1; }
+    convert(cs);
+    __syncthreads();
+    compute(cs);
+    cs ^= 1;
+  }
+  // D[n position 4 g + reg of run ni][ci position fl of run `wave`]  ->  slab[split][tap * IC + ci][n .. n + 3]
+  float* slab = p.dw + (long long)split * 9 * p.IC * p.N;
+  const int Qx = 4 * (wave & 1) + (fl >> 2);
+  const int ci = ci0 + (wave >> 1) * 32 + (Qx & 1) * 16 + (Qx >> 1) * 4 + (fl & 3);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int kk = t * p.IC + ci;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int Q = 4 * (ni & 1) + g;
+      const int n = n0 + (ni >> 1) * 32 + (Q & 1) * 16 + (Q >> 1) * 4;
+      *(float4*)(slab + (long long)kk * p.N + n) = make_float4(acc[t][ni][0], acc[t][ni][1], acc[t][ni][2], acc[t][ni][3]);
+    }
+  }
+}
+
 // C[m][n] = sum_k A[m][k] * B[n][k]   (fp32, row-major, K contiguous in both; m, n multiples of 16, k of 32).
 // Small helper GEMM of the folded BatchNorm backward ((W*b) W^T and (h^T h) W: at most 512 x 2048 x 2048), exact f32
 // MFMA.  A workgroup owns a TT x TT tile (64: waves 2 x 2 of 32 x 32; 32: waves 2 x 2 of 16 x 16 -- picked so that the
@@ -4098,6 +4297,32 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
                        (const float*)workspace, q.splits, numel3, dw, accumulate);
     SIMCLR_CHECK_LAUNCH();
     return 0;
+  }
+  // fp32 storage, three backward terms, pre-split gradient: the nine-tap kernel for the 3x3 stride-1 layers whose window fits two
+  // workgroups per CU (W <= 47: 28^2, 14^2, 7^2); SIMCLR_WGRAD_3X3=0 keeps the per-tap kernel (read per call, as for bf16)
+  {
+    const char* e3 = getenv("SIMCLR_WGRAD_3X3");
+    const int hpp = (32 + 2 * IW + 2 + 31) / 32 * 32;
+    if (!(e3 && atoi(e3) <= 0) && dtype == SIMCLR_DT_F32 && terms == 3 && dy_ps && KH == 3 && KW == 3 && stride == 1 && pad == 1 &&
+        IH == OH && IW == OW && Cin % 64 == 0 && Cout % 64 == 0 && IW >= 7 && 2 * 2 * (hpp + 32) * 256 <= 160 * 1024) {
+      Wgrad3P q = {};
+      q.x = x; q.dy = dy; q.dw = (float*)workspace; q.zero = zero_page();
+      SIMCLR_CHECK_ARG(q.zero != nullptr, "conv2d_wgrad: zero page symbol not found");
+      q.V = V; q.H = IH; q.W = IW; q.IC = Cin; q.N = Cout; q.pixpitch = pixpitch; q.M = p.M;
+      q.ci_tiles = Cin / 64; q.co_tiles = Cout / 64;
+      const int tiles3 = q.ci_tiles * q.co_tiles;
+      const int want3 = min(2048, max(8, getenv("SIMCLR_WGRAD3_BLOCKS") ? atoi(getenv("SIMCLR_WGRAD3_BLOCKS")) : (tiles3 == 1 ? 2048 : 512)));
+      q.splits = wgrad_splits(p.M, Cin, Cout, 64, 64, 32, &q.chunks_per_split, 2048, want3);
+      q.hpp = hpp;
+      const int grid3 = tiles3 * ceil_div(q.splits, 8) * 8;
+      hipLaunchKernelGGL(conv_wgrad3x3_f32ps, dim3(grid3), dim3(256), (size_t)2 * (hpp + 32) * 256, stream, q);
+      SIMCLR_CHECK_LAUNCH();
+      const long long numel3 = (long long)p.K * p.N;
+      hipLaunchKernelGGL(slab_reduce, dim3(max(1, (int)ceil_div(numel3 / 4, 16))), dim3(256), 0, stream,
+                         (const float*)workspace, q.splits, numel3, dw, accumulate);
+      SIMCLR_CHECK_LAUNCH();
+      return 0;
+    }
   }
   int bkw, bnw;
   wgrad_tile(Cin, Cout, dtype, p.M, KH * KW, &bkw, &bnw);
