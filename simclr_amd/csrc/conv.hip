@@ -4221,7 +4221,7 @@ static bool wgrad_use_256() {
   return on;
 #endif
 }
-static void wgrad_tile(int Cin, int Cout, int dtype, long long M, int taps, int* bkw, int* bnw) {
+static void wgrad_tile(int Cin, int Cout, int dtype, long long M, int taps, int* bkw, int* bnw, bool f32ps256 = false) {
   *bkw = (Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : 32);
   *bnw = (Cout % 128 == 0 || Cout > 128) ? 128 : 64;
   if (*bkw == 32) *bnw = 64;
@@ -4230,6 +4230,11 @@ static void wgrad_tile(int Cin, int Cout, int dtype, long long M, int taps, int*
   // for the short ones (7x7, 14x14 1x1) where it leaves too few workgroups.
   if (dtype == SIMCLR_DT_BF16 && Cin % 256 == 0 && Cout % 256 == 0 && wgrad_use_256() &&
       (M >= 500000 || (taps == 9 && M >= 150000 && Cin == 256))) { *bkw = 256; *bnw = 256; }
+  // fp32 storage, pre-split gradient, 1x1 layers of 256-channel multiples: 256 x 256 tile, eight waves along k (32 k-rows x all 256 columns
+  // each: the activation operand split once per workgroup, 8 LDS-DMA instructions per wave for 96 MFMAs instead of 48), one workgroup per
+  // CU.  Per layer at 1024 views (r06_call48): 28^2 512->256 713 -> 673 us, 14^2 1024->512 659 -> 620, 1024->256 361 -> 358, 256->1024
+  // 366 -> 360, 7^2 340 -> 331 / 350 -> 340; no layer loses
+  if (f32ps256 && taps == 1 && Cin % 256 == 0 && Cout % 256 == 0) { *bkw = 256; *bnw = 256; }
 }
 
 size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int Cout, int KH, int KW,
@@ -4325,7 +4330,8 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
     }
   }
   int bkw, bnw;
-  wgrad_tile(Cin, Cout, dtype, p.M, KH * KW, &bkw, &bnw);
+  constexpr bool f32_256 = true;
+  wgrad_tile(Cin, Cout, dtype, p.M, KH * KW, &bkw, &bnw, f32_256 && dtype == SIMCLR_DT_F32 && terms == 3 && dy_ps && stride == 1);
   if ((pixpitch * (dtype == SIMCLR_DT_BF16 ? 2 : 4)) % 16 != 0 && bkw == 256) { bkw = 128; bnw = 128; }
   // stem (packed input, 32 elements per kernel row): all kernel rows in ONE 256-row k-tile, so dY is read once
   constexpr bool stem_mt_on = true;
@@ -4346,8 +4352,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   const bool big = bkw == 128 && bnw == 128;
   const bool big256 = bkw == 256 && !stem_mt;
   if (big256 && cfg == 0) cfg = 1;
-  const int brm = ((cfg >= 2 && big) || big256) ? 1 : 2;
-  const int stages = big256 ? 4 : (cfg <= 1 ? 2 : (big ? (cfg == 2 ? 3 : 4) : 3));
+  const bool bf = dtype == SIMCLR_DT_BF16;
+  const int brm = ((cfg >= 2 && big) || (big256 && bf)) ? 1 : 2;
+  const int stages = big256 ? (bf ? 4 : 2) : (cfg <= 1 ? 2 : (big ? (cfg == 2 ? 3 : 4) : 3));
   const int br = (dtype == SIMCLR_DT_BF16 ? 32 : 16) * brm;
   // workgroup target of the bf16 launches: 1024 (round 5 sweep, interleaved pairs on one box, ms per step at 768 / 1024 / 1536 / 2048 /
   // 3072: 64.1 / 63.7 / 63.9 / 64.6 / 65.1 -- fewer, longer pixel ranges write fewer fp32 slabs); the fp32 launches keep the 1536 of
@@ -4384,7 +4391,9 @@ int simclr_conv2d_wgrad(const void* x, const void* dy, float* dw, int accumulate
   static const bool stem_split_on = !getenv("SIMCLR_STEM_SPLIT") || atoi(getenv("SIMCLR_STEM_SPLIT")) != 0;
   const bool stem_dma_f32 = stem_mt && stem_dma_on && stem_split_on && dtype == SIMCLR_DT_F32 && p.split != 0 && KW == 1 && pad == 0 &&
                             pixpitch == 4 && Cin == 32;
-  if (big256) {
+  if (big256 && !bf) {
+    hipLaunchKernelGGL((conv_wgrad_dma<float, 256, 256, 2, 2, 8, 1, false, false, 3, 1>), dim3(grid), dim3(512), lds, stream, p);
+  } else if (big256) {
     hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 256, 256, 1, 4, 2, 4>), dim3(grid), dim3(512), lds, stream, p);
   } else if (stem_dma_f32) {
     const size_t lds_s = (size_t)2 * 32 * (256 + 64) * 4;      // 2 stages x 32 pixels x (256 + 64) fp32
