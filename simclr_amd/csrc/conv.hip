@@ -4245,7 +4245,10 @@ size_t simclr_conv2d_wgrad_workspace_bytes(int V, int OH, int OW, int Cin, int C
   int splits = wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps);
   splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, bkw, bnw, 32, &cps));
   if (KH == 3 && KW == 3 && Cin % 64 == 0 && Cout % 64 == 0)      // nine-tap kernel: 64x64 tiles of all taps, up to 2048 ranges
-    splits = max(splits, wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 64, &cps, 2048, 4096));
+    splits = max(splits, max(wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 64, &cps, 2048, 4096),
+                             wgrad_splits((long long)V * OH * OW, Cin, Cout, 64, 64, 32, &cps, 2048, 4096)));    // (fp32 nine-tap kernel: 32-pixel chunks)
+  if (dtype != SIMCLR_DT_BF16 && KH * KW == 1 && Cin % 256 == 0 && Cout % 256 == 0)   // fp32 256 x 256 tile on a pre-split gradient: fewer tiles, more ranges
+    splits = max(splits, wgrad_splits((long long)V * OH * OW, Cin, Cout, 256, 256, 32, &cps));
   if (Cin == 32 && KH * KW * Cin <= 256 && Cout <= 64)            // stem: one 256-row k-tile, up to 1024 pixel ranges
     splits = max(splits, wgrad_splits((long long)V * OH * OW, KH * KW * Cin, Cout, 256, 64, dtype == SIMCLR_DT_BF16 ? 64 : 32, &cps, 1024, 1024));
   return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);

@@ -969,6 +969,37 @@ def check_ps_weight_pieces(Cin, Cout, k, seed=0):
         ops.set_f32_matmul('exact')
 
 
+def check_wgrad_workspace_bound(V, H, Cin, Cout, k, matmul='f16x3_3', ps=True, seed=0):
+    """simclr_conv2d_wgrad writes its split-K slabs into a caller-provided workspace of simclr_conv2d_wgrad_workspace_bytes: every kernel
+    variant the launcher may pick (per-tap, nine-tap with 32-pixel chunks, the 256 x 256 tile) must stay inside it.  The workspace here is
+    EXACTLY that size, followed by a poisoned guard region that must come back untouched, and the result must equal the one computed
+    with the library's shared (larger) scratch buffer."""
+    from simclr_amd._lib import lib
+    ops.set_f32_matmul(matmul)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        pad = (k - 1) // 2
+        x = torch.randn(V, H, H, Cin, device=DEV, generator=g)
+        dy = torch.randn(V, H, H, Cout, device=DEV, generator=g) * 1e-3
+        if ps:
+            one, zero = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+            dy, _ = ops.bn_bwd_apply(dy, dy, None, one, zero, zero, one, zero, zero, 0, ps_out=True)
+        ref = ops.conv2d_wgrad(x, dy, k, k, 1, pad)
+        nbytes = lib().conv2d_wgrad_workspace_bytes(V, H, H, Cin, Cout, k, k, ops.dt(x))
+        guard = 1 << 20
+        buf = torch.full(((nbytes + 3) // 4 + guard,), 12345.0, device=DEV, dtype=torch.float32)
+        out = torch.empty(k * k * Cin, Cout, device=DEV, dtype=torch.float32)
+        lib().conv2d_wgrad(ops._p(x), ops._pp(dy), ops._p(out), 0, ops._p(buf), V, H, H, Cin, Cin, H, H, Cout, k, k, 1, pad,
+                           ops.dt(x) | (ops.FMT_PS_IN if ops.ps_kind(dy) else 0) | ops._tb(), ops._s())
+        torch.cuda.synchronize()
+        tag = 'V%d %dx%d %d->%d k%d %s' % (V, H, H, Cin, Cout, k, 'ps' if ps else 'plain')
+        tail = buf[(nbytes + 3) // 4:]
+        return [_res('wgrad_ws_guard_untouched ' + tag, tail, torch.full_like(tail, 12345.0), 0.0),
+                _res('wgrad_ws_same_result ' + tag, out, ref, 0.0)]
+    finally:
+        ops.set_f32_matmul('exact')
+
+
 def check_sparse_dgrad(V, H, Cs, Cin, Cmid, mode, seed=0, matmul='f16x3_3'):
     """Stride-2 1x1 projection shortcut + the block's first convolution in the backward pass (fp32 storage): the shortcut's data gradient
     stores only the even (row, column) pixels of dx (accumulate = 3, the rest UNINITIALISED -- poisoned with NaN here) and conv1's

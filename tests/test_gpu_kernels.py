@@ -551,6 +551,14 @@ def test_stem_conv(V, H, k, s, dtype):
     _assert(gc.check_stem(V, H, k, s, 64, dtype))
 
 
+@pytest.mark.parametrize('V,H,Cin,Cout,k,ps', [(30, 14, 64, 64, 3, True),      # nine-tap fp32 kernel, ONE tile: as many pixel ranges as 32-pixel chunks
+                                                (8, 14, 256, 256, 1, True),      # 256 x 256 tile: fewer tiles, more ranges than the 128-wide rule
+                                                (16, 14, 1024, 512, 1, True), (4, 28, 128, 128, 3, True), (8, 14, 256, 512, 1, False)])
+def test_weight_gradient_stays_inside_its_workspace(V, H, Cin, Cout, k, ps):
+    from tests import gpu_checks as gc
+    _assert(gc.check_wgrad_workspace_bound(V, H, Cin, Cout, k, ps=ps))
+
+
 @pytest.mark.parametrize('Cin,Cout,k', [(64, 64, 1), (128, 96, 3)])
 def test_presplit_weight_pieces_equal_torch_rounding(Cin, Cout, k):
     from tests import gpu_checks as gc
