@@ -369,7 +369,9 @@ int simclr_conv2d_dgrad_ext(const void* dm, const void* h, const void* w_ext, co
 /* sum(dm * x^) of the folded BatchNorm from t1 = h^T dm (no pass over the conv output): sums [2][N] fp64, sums[0] = sum dm given */
 int simclr_bn_fold_s2(const float* t1, const void* w, const float* mean, const float* rstd, double* sums, int K, int N,
                       int dtype, simclr_stream_t stream);
-/* h^T h [K*K] followed by colsum(h) [K] for h [M][K] (T), K in {64, 128, 256(bf16)}: the activation is streamed once */
+/* h^T h [K*K] followed by colsum(h) [K] for h [M][K] (T), K in {64, 128, 256(bf16)}: the activation is streamed once.
+ * fp32 storage: dtype may carry SIMCLR_FMT_TERMS of the forward pass the statistics serve -- exact arithmetic (or no field and an exact
+ * process default) = exact fp32 MFMA; any split mode = six bf16-piece terms (fp32-level products), column sums by exact fp32 MFMA */
 size_t simclr_conv2d_gram_workspace_bytes(long long M, int K, int dtype);
 int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, int K, int dtype, simclr_stream_t stream);
 /* C [M][N] = A [M][K] B[N][K]^T, fp32 on the matrix cores (the small K x K / K x N products of the folded form);

@@ -2029,7 +2029,9 @@ void conv_wgrad_dma(const WgradP p) {
       __builtin_amdgcn_s_setprio(0);
     } else if constexpr (SPL != 0) {
       // split-bf16 terms: lane group g holds pixels {4j + g : j = 0..7} of a 32-pixel step for both operands
-      static_assert(!GRAM && BR % 32 == 0, "split-bf16 weight gradient: 32-pixel reduction steps, no Gram variant");
+      // GRAM (six terms only: the statistics the Gram matrix feeds need fp32-level products): both operands come from the one tile; the
+      // column sums ride on the activation loader below as exact fp32 MFMAs against ones (one per 4-pixel group, as in the exact kernel)
+      static_assert((!GRAM || SPL == 6) && BR % 32 == 0, "split-bf16 weight gradient: 32-pixel reduction steps; Gram variant: six terms");
 #pragma unroll
       for (int ks = 0; ks < BR / 32; ++ks) {
         mma_f32_chunks<NI, KI, true, SPL>(&acc[0][0],
@@ -2045,6 +2047,10 @@ void conv_wgrad_dma(const WgradP p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 c[e] = *(const uint32_t*)(As + elem_off(A_RB, A_BLK, ks * 32 + (h * 4 + e) * 4 + g, wk * (KI * 16) + i * 16 + fl));
+              if (GRAM && wn == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acs[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, __uint_as_float(c[e]), acs[i], 0, 0, 0);
+              }
               return c;
             });
       }
@@ -4494,6 +4500,11 @@ size_t simclr_conv2d_gram_workspace_bytes(long long M, int K, int dtype) {
   return (size_t)splits * ((size_t)K * K + K) * sizeof(float);
 }
 int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, int K, int dtype, hipStream_t stream) {
+  // fp32 storage: dtype may carry the matrix-arithmetic field (SIMCLR_FMT_TERMS) of the forward pass this Gram matrix serves.  Exact
+  // arithmetic -> exact fp32 MFMA; any split mode -> SIX bf16-piece terms (fp32-level products at 2.7x the fp32 MFMA rate: the Gram
+  // launches were the last exact-fp32 matrix work of the fast parity step)
+  const int terms = terms_of(&dtype, true);
+  SIMCLR_CHECK_ARG(terms >= 0, "conv2d_gram: bad matrix-arithmetic field in dtype (SIMCLR_FMT_TERMS)");
   SIMCLR_CHECK_ARG(dtype == SIMCLR_DT_BF16 || dtype == SIMCLR_DT_F32, "conv2d_gram: bad dtype %d", dtype);
   SIMCLR_CHECK_ARG(K == 64 || K == 128 || (K == 256 && dtype == SIMCLR_DT_BF16), "conv2d_gram: K=%d not supported (64, 128, bf16 256)", K);
   SIMCLR_CHECK_ARG(M > 0 && M < (1ll << 31), "conv2d_gram: bad M");
@@ -4520,7 +4531,12 @@ int simclr_conv2d_gram(const void* h, float* out, void* workspace, long long M, 
       if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 64, 64, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
       else hipLaunchKernelGGL((conv_wgrad_dma<uint16_t, 128, 128, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
     } else {
-      if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<float, 64, 64, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
+      // (A/B on one box, r06_call52: step 140.16 -> 139.71 ms in three pairs; every gate of the fused-tail / fold / step tests unchanged)
+      if (terms != 0) {
+        if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<float, 64, 64, 2, 4, 2, 2, true, false, 6>), dim3(grid), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_dma<float, 128, 128, 2, 4, 2, 2, true, false, 6>), dim3(grid), dim3(256), lds, stream, p);
+      }
+      else if (K == 64) hipLaunchKernelGGL((conv_wgrad_dma<float, 64, 64, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
       else hipLaunchKernelGGL((conv_wgrad_dma<float, 128, 128, 2, 4, 2, 2, true>), dim3(grid), dim3(256), lds, stream, p);
     }
   }

@@ -935,7 +935,7 @@ def conv2d_gram(h):
     ws = _workspace(lib().conv2d_gram_workspace_bytes(M, K, dt(h)), h.device)
     esz = h.element_size()
     _launch('conv_wgrad', 2.0 * M * K * K, esz * M * K + 4 * K * K,
-            lambda: lib().conv2d_gram(_p(h), _p(out), _p(ws), M, K, dt(h), _s()))
+            lambda: lib().conv2d_gram(_p(h), _p(out), _p(ws), M, K, dt(h) | (_tf() if h.dtype == torch.float32 else 0), _s()))
     return out[:K * K].view(K, K), out[K * K:]
 
 
