@@ -15,7 +15,7 @@ from simclr_amd.run import make_single_step  # noqa: E402
 
 dev = torch.device('cuda', 0)
 FLAGS.reset()
-FLAGS.update(resnet_depth=50, image_size=64, train_batch_size=16, compute_dtype='bf16', use_blur=False)
+FLAGS.update(resnet_depth=50, image_size=64, train_batch_size=16, compute_dtype=(sys.argv[1] if len(sys.argv) > 1 else 'bf16'), use_blur=False)
 RT.reset(); RT.device = dev
 model = model_lib.Model(10)
 opt = model_lib.build_optimizer(0.1)
